@@ -1,0 +1,158 @@
+/*
+ * varnet_hip.h -- C ABI of libvarnet_hip.so, the MI355X (gfx950) engine behind the VarNet
+ * variational-loss training loop.
+ *
+ * The reference has no FFI layer: its device boundary is the `TFNN` object that
+ * `VarNet` / `ManageTrainData` drive through `sess.run(feed_dict)`.  Every entry point below
+ * replaces one of those call sites (cited as /root/reference/<file>:<line>).  All functions
+ * are `extern "C"`, take plain pointers and sizes, return 0 on success and a non-zero
+ * VN_E* code on failure (message via vn_last_error()).
+ *
+ * Conventions
+ *   - "dev" pointers are device (HBM) addresses owned by the caller; they must stay valid
+ *     while registered.  "host" pointers are ordinary host memory.
+ *   - Rows of the interior arrays are grouped by test function: row r = k*integ_num + p
+ *     (test function k, quadrature point p), exactly the reference's `Input` layout
+ *     (VarNet.py:576-588, VarNetUtility.py:820).
+ *   - Flat parameter order: W_1[d_in,H_1] row-major, b_1[H_1], ..., w_o[H_L,1], b_o[1]
+ *     (Keras kernel is [in,out]; TFModel.py:208-242).
+ *   - All work is enqueued on the stream given to vn_set_stream (default: the null stream);
+ *     no entry point synchronises with the host unless its comment says so.
+ *   - A handle is not thread-safe; use one handle per GPU / per process.
+ */
+#ifndef VARNET_HIP_H
+#define VARNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VN_MAX_LAYERS 6   /* hidden layers                                   */
+#define VN_MAX_WIDTH  64  /* hidden width                                    */
+#define VN_MAX_DIN    8   /* network inputs: dim + time + MOR parameters     */
+
+enum {
+  VN_OK = 0,
+  VN_EINVAL = 1,   /* bad argument                                             */
+  VN_EHIP = 2,     /* a HIP runtime call failed                                */
+  VN_ESTATE = 3,   /* call order violated (e.g. step before data registered)   */
+  VN_ENOMEM = 4,
+  VN_EUNSUPPORTED = 5
+};
+
+enum { VN_ACT_SIGMOID = 0 };
+enum { VN_OPT_ADAM = 0 };
+enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 };
+
+typedef struct vn_engine vn_engine;
+
+/* Replaces the arguments of TFNN.__init__ (TFModel.py:85-191) + lossOpt (VarNet.py:182-185). */
+typedef struct vn_config {
+  int32_t dim;                      /* spatial dimension                                   */
+  int32_t d_in;                     /* network inputs (VarNet.py:174-180)                  */
+  int32_t n_layers;                 /* hidden layers L                                     */
+  int32_t widths[VN_MAX_LAYERS];    /* layerWidth                                          */
+  int32_t activation;               /* VN_ACT_SIGMOID                                      */
+  int32_t integ_num;                /* quadrature points per test function (FiniteElement.py:416) */
+  int32_t time_dependent;           /* TFModel.py:537,646,655                              */
+  int32_t has_source;               /* lossOpt['isSource']  (TFModel.py:656)               */
+  int32_t has_integw;               /* lossOpt['integWflag'] (TFModel.py:660)              */
+  int32_t device;                   /* HIP device ordinal                                  */
+  int32_t optimizer;                /* VN_OPT_ADAM (TFModel.py:183-184)                    */
+  int32_t kernel;                   /* VN_KERNEL_*                                         */
+  double  lr, beta1, beta2, eps;    /* TF-1 Adam defaults 1e-3, .9, .999, 1e-8             */
+} vn_config;
+
+const char* vn_last_error(void);
+int  vn_abi_version(void);
+
+/* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
+int vn_create(const vn_config* cfg, vn_engine** out);
+int vn_destroy(vn_engine* h);
+/* Stream all later work is enqueued on (pass torch.cuda.current_stream().cuda_stream). */
+int vn_set_stream(vn_engine* h, void* hip_stream);
+
+/* Number of trainable scalars P. */
+int vn_param_count(const vn_engine* h, int64_t* n);
+/* sess.run(global_variables_initializer()) (TFModel.py:326, VarNet.py:1412): glorot-uniform
+ * kernels, zero biases, zero Adam slots, step 0.  Deterministic in `seed`. */
+int vn_params_init(vn_engine* h, uint64_t seed);
+/* saver.save / restore of the trainable variables, saveNNparam (VarNet.py:1362,1498,2231).
+ * Host buffers of P floats.  These two synchronise the stream. */
+int vn_params_get(vn_engine* h, float* host, int64_t n);
+int vn_params_set(vn_engine* h, const float* host, int64_t n);
+/* Full optimiser state {theta, m, v, step}: what tf.train.Saver writes (TFModel.py:307).
+ * Layout: int64 step, then 3*P floats.  Synchronises. */
+int vn_state_size(const vn_engine* h, int64_t* bytes);
+int vn_state_export(vn_engine* h, void* host, int64_t bytes);
+int vn_state_import(vn_engine* h, const void* host, int64_t bytes);
+
+/* Feed of tower.N / tower.dNt / tower.integW (VarNetUtility.py:845-852) for the uniform case,
+ * where those nT-row arrays are period-integ_num tables (FiniteElement.py:426-432).
+ * Host pointers, integ_num floats each; integW may be NULL (all ones). */
+int vn_set_fe_table(vn_engine* h, const float* N, const float* dNt, const float* integW);
+
+/* Feed of tower.Input / gcoef / source / intShape / detJ for one (mini-|MOR-)batch
+ * (VarNetUtility.py:840-854).  Device pointers: Input [n_k*integ_num, d_in], gcoef
+ * [n_k*integ_num, dim], source [n_k*integ_num] or NULL.  detJ_dev: per-test-function
+ * determinants [n_k] (the reference's detJvec=True case) or NULL to use the scalar `detJ`.
+ * N_rows/dNt_rows: per-row basis arrays [n_k*integ_num] (non-uniform supports) or NULL to use
+ * the table of vn_set_fe_table. */
+int vn_set_interior(vn_engine* h, int32_t batch, const float* Input_dev, const float* gcoef_dev,
+                    const float* source_dev, int64_t n_k, const float* detJ_dev, double detJ,
+                    const float* N_rows_dev, const float* dNt_rows_dev);
+/* Feed of tower.biInput / biLabel / bDof / biDimVal (VarNetUtility.py:841-849).
+ * biInput [nB, d_in], biLabel [nB]; rows [0,bDof) are boundary, [bDof,nB) initial condition. */
+int vn_set_bic(vn_engine* h, const float* biInput_dev, const float* biLabel_dev, int64_t nB,
+               int64_t bDof, double biDimVal);
+/* updateDictFields('trainW') (VarNetUtility.py:921-922); the caller applies the
+ * w[0:2] /= batchNum*puNum rule (VarNetUtility.py:900-901). */
+int vn_set_weights(vn_engine* h, const double w[3]);
+
+/* Optional externally owned gradient buffer of P+4 floats (gradient | loss, BC, IC, var) so
+ * that the host can all-reduce it (tower gradient SUM, TFModel.py:342-377) between vn_grad
+ * and vn_apply.  NULL restores the internal buffer. */
+int vn_bind_grad_buffer(vn_engine* h, float* dev);
+
+/* compute_gradients(loss) (TFModel.py:709): forward, weak-form loss, backward for `batch`;
+ * leaves d loss/d theta and the 4 loss scalars in the gradient buffer. */
+int vn_grad(vn_engine* h, int32_t batch);
+/* optimizer.apply_gradients (TFModel.py:313): TF-1 Adam step from the gradient buffer. */
+int vn_apply(vn_engine* h);
+/* sess.run([optMinimize, loss]) (VarNetUtility.py:1044) = vn_grad + vn_apply.  If
+ * loss_out_dev != NULL the pre-update loss is copied there (device scalar, async). */
+int vn_train_step(vn_engine* h, int32_t batch, float* loss_out_dev);
+
+/* ManageTrainData.splitLoss (VarNetUtility.py:1080-1088): out = {loss, BCloss, ICloss,
+ * varLoss} (host doubles), lossVec_dev [n_k] or NULL.  Synchronises. */
+int vn_eval_loss(vn_engine* h, int32_t batch, double out[4], float* lossVec_dev);
+
+/* runSession(['model']) (VarNetUtility.py:1123-1128,1142; VarNet.py:1930): u = model(X). */
+int vn_forward(vn_engine* h, const float* X_dev, int64_t n, float* u_dev);
+int vn_forward_f64(vn_engine* h, const double* X_dev, int64_t n, double* u_dev);
+/* runSession(['model','residual']) (VarNetUtility.py:1130-1142; TFModel.py:743-754):
+ * res = -u_t + diff*Lap(u) - (vel - diff_dx).grad(u) + source.  diff [n], vel [n,dim],
+ * source [n] or NULL, diff_dx [n,dim] or NULL.  fp32 and fp64 forms. */
+int vn_residual(vn_engine* h, const float* X_dev, const float* diff_dev, const float* vel_dev,
+                const float* source_dev, const float* diff_dx_dev, int64_t n, float* u_dev,
+                float* res_dev);
+int vn_residual_f64(vn_engine* h, const double* X_dev, const double* diff_dev,
+                    const double* vel_dev, const double* source_dev, const double* diff_dx_dev,
+                    int64_t n, double* u_dev, double* res_dev);
+
+/* Adam step counter (global_step, TFModel.py:312). */
+int vn_get_step(const vn_engine* h, int64_t* step);
+
+/* Name / mean duration (ms, HIP events on the engine's stream) of the dominant kernel of the
+ * last `vn_profile_begin` .. `vn_profile_end` window: used by bench.py for the roofline
+ * object.  vn_profile_end synchronises. */
+int vn_profile_begin(vn_engine* h);
+int vn_profile_end(vn_engine* h, double* mean_ms, int64_t* launches, char* name, int32_t name_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VARNET_HIP_H */

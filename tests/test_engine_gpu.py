@@ -1,0 +1,163 @@
+"""
+GPU parity tests proper: the HIP path (through the C ABI) against the oracle (fp64 autograd
+restatement of the reference graph, oracle/tf1_graph.py) on the same seeded inputs.
+
+Tolerances: single step fp32 vs fp64 oracle at fixed theta:
+loss rel <= 1e-5, |g-g_ref|_inf/|g_ref|_inf <= 1e-4, lossVec rel <= 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf1_graph as og
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-5
+GRAD_RTOL = 1e-4
+LVEC_RTOL = 1e-4
+
+
+def synth(seed, d_in, dim, widths, integNum, n_k, nB, bDof, source=False, integW=False, detJvec=False):
+    rng = np.random.default_rng(seed)
+    n = n_k * integNum
+    d = dict(
+        Input=rng.uniform(-1, 1, (n, d_in)).astype(np.float32),
+        gcoef=rng.standard_normal((n, dim)).astype(np.float32),
+        source=rng.standard_normal((n, 1)).astype(np.float32) if source else None,
+        N1=rng.uniform(0, 1, integNum).astype(np.float32),
+        dNt1=rng.standard_normal(integNum).astype(np.float32),
+        integW=rng.uniform(0.5, 1.0, (1, integNum)).astype(np.float32) if integW else None,
+        detJ=(rng.uniform(0.1, 0.2, (n_k, 1)).astype(np.float32) if detJvec else np.float32(0.137)),
+        biInput=rng.uniform(-1, 1, (nB, d_in)).astype(np.float32),
+        biLabel=rng.standard_normal((nB, 1)).astype(np.float32),
+        w=np.array([3.0, 2.0, 5.0]),
+    )
+    d['N'] = np.tile(d['N1'], n_k).reshape(n, 1)
+    d['dNt'] = np.tile(d['dNt1'], n_k).reshape(n, 1)
+    return d
+
+
+def make_engine(d_in, dim, widths, integNum, source, integW):
+    from varnet_amd.engine import VNEngine
+    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW)
+
+
+def oracle_eval(flat, d, d_in, dim, widths, integNum, n_k, bDof, source, integW, detJvec):
+    kw = dict(Input=d['Input'].astype(np.float64), gcoef=d['gcoef'].astype(np.float64),
+              source=None if d['source'] is None else d['source'].astype(np.float64),
+              N=d['N'].astype(np.float64), dNt=d['dNt'].astype(np.float64),
+              integW=None if d['integW'] is None else d['integW'].astype(np.float64),
+              intShape=[n_k, integNum],
+              detJ=(d['detJ'].astype(np.float64) if detJvec else float(d['detJ'])), detJvec=detJvec,
+              biInput=d['biInput'].astype(np.float64), biLabel=d['biLabel'].astype(np.float64),
+              bDof=bDof, biDimVal=2.0, w=d['w'], dim=dim, time_dependent=True,
+              is_source=source, integWflag=integW)
+    return og.loss_and_grad(flat.astype(np.float64), d_in, widths, torch.float64, **kw)
+
+
+CASES = [
+    # d_in dim widths            integNum n_k  nB  bDof source integW detJvec
+    (2, 1, [20, 20, 20],         16,      40,  50, 30,  False, False, False),
+    (3, 2, [50, 50, 50, 50, 50], 64,      9,   77, 40,  False, False, False),
+    (3, 2, [10, 20],             64,      5,   33, 33,  True,  False, False),
+    (3, 1, [10, 20, 30],         16,      21,  19, 7,   False, False, False),   # MOR-style extra input
+    (2, 1, [7],                  36,      11,  40, 13,  True,  True,  True),
+    (3, 2, [64, 64, 64],         216,     3,   5,  2,   False, True,  False),
+    (3, 2, [50, 50, 50, 50, 50], 64,      300, 1000, 600, False, False, False),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_loss_and_grad_parity(case):
+    d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec = case
+    d = synth(1, d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec)
+    eng = make_engine(d_in, dim, widths, integNum, source, integW)
+    eng.init_params(seed=3)
+    flat = eng.get_params()
+    # perturb biases so they are exercised
+    flat = flat + 0.05 * np.random.default_rng(5).standard_normal(flat.size).astype(np.float32)
+    eng.set_params(flat)
+    eng.set_fe_table(d['N1'], d['dNt1'], d['integW'])
+    eng.set_interior(0, d['Input'], d['gcoef'], d['source'], n_k=n_k, detJ=d['detJ'])
+    eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+    eng.set_weights(d['w'])
+
+    ref, gref = oracle_eval(flat, d, d_in, dim, widths, integNum, n_k, bDof, source, integW, detJvec)
+
+    out, lv = eng.eval_loss(0, lossVec=True)
+    for got, key in zip(out, ['loss', 'BCloss', 'ICloss', 'varLoss']):
+        assert abs(got - ref[key]) <= LOSS_RTOL * 4 * abs(ref[key]) + 1e-7, (key, got, ref[key])
+    lv = lv.cpu().numpy()
+    lref = ref['lossVec'].reshape(-1)
+    assert np.max(np.abs(lv - lref)) <= LVEC_RTOL * np.max(np.abs(lref))
+
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy()
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * 4 * abs(ref['loss'])
+    err = np.max(np.abs(g[:eng.P] - gref)) / np.max(np.abs(gref))
+    assert err <= GRAD_RTOL, err
+    eng.close()
+
+
+def test_forward_and_residual_parity():
+    d_in, dim, widths = 3, 2, [10, 20, 30]
+    rng = np.random.default_rng(0)
+    n = 1000
+    X = rng.uniform(-1, 1, (n, d_in))
+    diff = rng.uniform(0.1, 1, (n, 1)); vel = rng.standard_normal((n, dim))
+    src = rng.standard_normal((n, 1)); ddx = rng.standard_normal((n, dim))
+    eng = make_engine(d_in, dim, widths, 64, False, False)
+    eng.init_params(seed=11)
+    flat = eng.get_params().astype(np.float64)
+    uref, rref = og.residual(flat, d_in, widths, torch.float64, X, diff, vel, src, ddx, dim, True)
+    u32 = eng.forward(X.astype(np.float32)).cpu().numpy()
+    assert np.max(np.abs(u32 - uref[:, 0])) < 2e-6 * max(1, np.max(np.abs(uref)))
+    u64 = eng.forward_f64(X).cpu().numpy()
+    assert np.max(np.abs(u64 - uref[:, 0])) < 1e-13
+    u, r = eng.residual(X, diff, vel, src, ddx, fp64=True)
+    assert np.max(np.abs(r.cpu().numpy() - rref[:, 0])) < 1e-11 * max(1, np.max(np.abs(rref)))
+    assert np.max(np.abs(u.cpu().numpy() - uref[:, 0])) < 1e-13
+    u, r = eng.residual(X.astype(np.float32), diff, vel, src, ddx, fp64=False)
+    assert np.max(np.abs(r.cpu().numpy() - rref[:, 0])) < 5e-5 * max(1, np.max(np.abs(rref)))
+    eng.close()
+
+
+def test_adam_trajectory_parity():
+    """200 TF-1 Adam steps from identical init: relative loss deviation <= 1e-2."""
+    d_in, dim, widths, integNum, n_k, nB, bDof = 2, 1, [20, 20], 16, 64, 60, 40
+    d = synth(2, d_in, dim, widths, integNum, n_k, nB, bDof)
+    eng = make_engine(d_in, dim, widths, integNum, False, False)
+    eng.init_params(seed=1)
+    flat = eng.get_params()
+    eng.set_fe_table(d['N1'], d['dNt1'], None)
+    eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=n_k, detJ=d['detJ'])
+    eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+    eng.set_weights(d['w'])
+    steps = 200
+    losses = torch.zeros(steps, device='cuda')
+    for i in range(steps):
+        eng.train_step(0, losses[i:i + 1])
+    torch.cuda.synchronize()
+    got = losses.cpu().numpy()
+    assert eng.step == steps
+
+    adam = og.TF1Adam(flat.size, lr=1e-3, dtype=np.float64)
+    th = flat.astype(np.float64)
+    ref = []
+    for i in range(steps):
+        r, g = oracle_eval(th, d, d_in, dim, widths, integNum, n_k, bDof, False, False, False)
+        ref.append(r['loss'])
+        th = adam.step(th, g)
+    ref = np.array(ref)
+    assert got[-1] < got[0]
+    assert np.max(np.abs(got - ref) / np.abs(ref)) <= 1e-2
+    # state export/import round trip
+    st = eng.export_state()
+    p1 = eng.get_params()
+    eng.init_params(seed=9)
+    eng.import_state(st)
+    assert np.array_equal(eng.get_params(), p1) and eng.step == steps
+    eng.close()

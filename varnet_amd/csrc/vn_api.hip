@@ -1,0 +1,544 @@
+// C-ABI host layer of libvarnet_hip.so (see include/varnet_hip.h for the contract and the
+// reference call sites each entry point replaces).
+#include "vn_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) return fail(VN_EHIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+  } while (0)
+
+struct Batch {
+  const float* Input = nullptr;
+  const float* gcoef = nullptr;
+  const float* source = nullptr;
+  const float* detJv = nullptr;
+  const float* Nrow = nullptr;
+  const float* dNtrow = nullptr;
+  long n_k = 0;
+  double detJ = 0.0;
+  bool set = false;
+};
+
+constexpr int PROF_CAP = 4096;
+
+}  // namespace
+
+struct vn_engine {
+  vn_config cfg{};
+  VnNet net{};
+  hipStream_t stream = nullptr;
+  int ncu = 256;
+
+  float *theta = nullptr, *m = nullptr, *v = nullptr;
+  double* theta64 = nullptr;
+  float* gradbuf_int = nullptr;
+  float* gradbuf = nullptr;
+  float* lossbuf = nullptr;       // [4] for vn_eval_loss
+  float* partial = nullptr;       // [bwd_grid, P]
+  int bwd_grid = 0, fwd_grid = 0;
+
+  float *feN = nullptr, *fedNt = nullptr, *feW = nullptr;
+  bool has_fe = false, has_feW = false;
+
+  std::vector<Batch> batches;
+  const float *biInput = nullptr, *biLabel = nullptr;
+  long nB = 0, bDof = 0;
+  double biDimVal = 1.0;
+  double w[3] = {1.0, 1.0, 1.0};
+
+  float *u = nullptr, *ud = nullptr, *ubar = nullptr, *udbar = nullptr;
+  long work_rows = 0;
+  float *ub = nullptr, *ubar_b = nullptr;
+  long work_b = 0;
+  float* losspart = nullptr;
+  long losspart_cap = 0;
+
+  int64_t step = 0;
+
+  // profiling of the dominant kernel
+  bool prof_on = false;
+  int prof_n = 0;
+  std::vector<hipEvent_t> ev0, ev1;
+  const char* prof_name = "vn_generic_bwd_kernel";
+};
+
+namespace {
+
+int build_net(const vn_config& c, VnNet& net) {
+  if (c.n_layers < 1 || c.n_layers > VN_MAX_LAYERS)
+    return fail(VN_EINVAL, "n_layers=%d outside [1,%d]", c.n_layers, VN_MAX_LAYERS);
+  if (c.d_in < 1 || c.d_in > VN_MAX_DIN) return fail(VN_EINVAL, "d_in=%d outside [1,%d]", c.d_in, VN_MAX_DIN);
+  if (c.dim < 1 || c.dim > c.d_in) return fail(VN_EINVAL, "dim=%d must be in [1,d_in]", c.dim);
+  if (c.integ_num < 1) return fail(VN_EINVAL, "integ_num must be positive");
+  if (c.activation != VN_ACT_SIGMOID) return fail(VN_EUNSUPPORTED, "only the sigmoid activation is implemented");
+  if (c.optimizer != VN_OPT_ADAM) return fail(VN_EUNSUPPORTED, "only the Adam optimizer is implemented");
+  if (c.lr < 0.0) return fail(VN_EINVAL, "learning rate must be positive!");  // TFModel.py:130
+  memset(&net, 0, sizeof net);
+  net.d_in = c.d_in;
+  net.dim = c.dim;
+  net.L = c.n_layers;
+  net.H[0] = c.d_in;
+  int off = 0, hmax = 0;
+  for (int l = 1; l <= net.L + 1; ++l) {
+    const int h = (l <= net.L) ? c.widths[l - 1] : 1;
+    if (h < 1 || h > VN_MAX_WIDTH) return fail(VN_EINVAL, "layer width %d outside [1,%d]", h, VN_MAX_WIDTH);
+    net.H[l] = h;
+    net.woff[l] = off;
+    off += net.H[l - 1] * h;
+    net.boff[l] = off;
+    off += h;
+    if (l <= net.L && h > hmax) hmax = h;
+  }
+  net.P = off;
+  net.hmax = hmax;
+  return VN_OK;
+}
+
+int ensure(float** p, long* cap, long need) {
+  if (need <= *cap) return VN_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  HIPCHK(hipMalloc((void**)p, (size_t)need * sizeof(float)));
+  *cap = need;
+  return VN_OK;
+}
+
+uint64_t splitmix64(uint64_t& s) {
+  s += 0x9E3779B97F4A7C15ull;
+  uint64_t z = s;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+int refresh_theta64(vn_engine* h) {
+  // fp32 parameters widened on the host side of the stream: tiny (P <= ~2e4), off the hot path
+  std::vector<float> t(h->net.P);
+  HIPCHK(hipMemcpyAsync(t.data(), h->theta, t.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<double> d(t.begin(), t.end());
+  if (!h->theta64) HIPCHK(hipMalloc((void**)&h->theta64, d.size() * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(h->theta64, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VN_OK;
+}
+
+int check_batch(vn_engine* h, int32_t batch) {
+  if (batch < 0 || batch >= (int)h->batches.size() || !h->batches[batch].set)
+    return fail(VN_ESTATE, "batch %d has no interior data (call vn_set_interior first)", batch);
+  if (!h->has_fe && !(h->batches[batch].Nrow && h->batches[batch].dNtrow))
+    return fail(VN_ESTATE, "FE tables missing (call vn_set_fe_table first)");
+  return VN_OK;
+}
+
+// forward + weak-form epilogue; with_seeds = also produce backward seeds.
+int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* lossVec, float* lossdst) {
+  const long nT = b.n_k * h->cfg.integ_num;
+  VnRows s0{}, s1{};
+  s0.X = b.Input; s0.G = b.gcoef; s0.u = h->u; s0.ud = h->ud; s0.n = nT;
+  s1.X = h->biInput; s1.G = nullptr; s1.u = h->ub; s1.ud = nullptr; s1.n = h->nB;
+  HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));
+
+  const long nthreads = b.n_k > h->nB ? b.n_k : h->nB;
+  const int grid = (int)((nthreads + 255) / 256);
+  if (int rc = ensure(&h->losspart, &h->losspart_cap, (long)grid * 3)) return rc;
+  VnSeedArgs a{};
+  a.u = h->u; a.ud = h->ud; a.source = h->cfg.has_source ? b.source : nullptr;
+  a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
+  a.Nrow = b.Nrow; a.dNtrow = b.dNtrow;
+  a.detJv = b.detJv; a.detJ = (float)b.detJ;
+  a.n_k = b.n_k; a.integ_num = h->cfg.integ_num; a.time_dependent = h->cfg.time_dependent;
+  a.ubar = with_seeds ? h->ubar : nullptr; a.udbar = with_seeds ? h->udbar : nullptr;
+  a.lossVec = lossVec;
+  a.ub = h->ub; a.label = h->biLabel; a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;
+  a.ubar_b = with_seeds ? h->ubar_b : nullptr;
+  a.w0 = (float)h->w[0]; a.w1 = (float)h->w[1]; a.w2 = (float)h->w[2];
+  a.part = h->losspart;
+  HIPCHK(vn_seed_launch(a, grid, h->stream));
+  if (lossdst) {
+    HIPCHK(vn_reduce_launch(nullptr, 0, 0, h->losspart, grid, h->bDof, h->nB, a.w0, a.w1, a.w2, lossdst, h->stream));
+  }
+  return VN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vn_last_error(void) { return g_err.c_str(); }
+int vn_abi_version(void) { return 1; }
+
+int vn_create(const vn_config* cfg, vn_engine** out) {
+  if (!cfg || !out) return fail(VN_EINVAL, "null argument");
+  *out = nullptr;
+  VnNet net;
+  if (int rc = build_net(*cfg, net)) return rc;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(VN_EHIP, "no HIP device available (%s): the VarNet engine has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(VN_EINVAL, "requested processor %d is unavailable!", cfg->device);
+  HIPCHK(hipSetDevice(cfg->device));
+  if (vn_generic_bwd_lds_bytes(net) > 160 * 1024)
+    return fail(VN_EUNSUPPORTED, "network needs %zu B of LDS per tile (> 160 KiB): reduce depth/width",
+                vn_generic_bwd_lds_bytes(net));
+  vn_engine* h = new vn_engine();
+  h->cfg = *cfg;
+  if (h->cfg.lr == 0.0) h->cfg.lr = 1e-3;
+  if (h->cfg.beta1 == 0.0) h->cfg.beta1 = 0.9;
+  if (h->cfg.beta2 == 0.0) h->cfg.beta2 = 0.999;
+  if (h->cfg.eps == 0.0) h->cfg.eps = 1e-8;
+  h->net = net;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->ncu = prop.multiProcessorCount;
+  const size_t P = net.P;
+  const size_t fwd_lds = vn_generic_fwd_lds_bytes(net), bwd_lds = vn_generic_bwd_lds_bytes(net);
+  int fpc = (int)((160 * 1024) / fwd_lds); if (fpc > 4) fpc = 4; if (fpc < 1) fpc = 1;
+  int bpc = (int)((160 * 1024) / bwd_lds); if (bpc > 2) bpc = 2; if (bpc < 1) bpc = 1;
+  h->fwd_grid = h->ncu * fpc;
+  h->bwd_grid = h->ncu * bpc;
+  hipError_t a = hipSuccess;
+  if (a == hipSuccess) a = hipMalloc((void**)&h->theta, P * sizeof(float));
+  if (a == hipSuccess) a = hipMalloc((void**)&h->m, P * sizeof(float));
+  if (a == hipSuccess) a = hipMalloc((void**)&h->v, P * sizeof(float));
+  if (a == hipSuccess) a = hipMalloc((void**)&h->gradbuf_int, (P + 4) * sizeof(float));
+  if (a == hipSuccess) a = hipMalloc((void**)&h->lossbuf, 4 * sizeof(float));
+  if (a == hipSuccess) a = hipMalloc((void**)&h->partial, (size_t)h->bwd_grid * P * sizeof(float));
+  if (a == hipSuccess) a = hipMalloc((void**)&h->feN, cfg->integ_num * sizeof(float));
+  if (a == hipSuccess) a = hipMalloc((void**)&h->fedNt, cfg->integ_num * sizeof(float));
+  if (a == hipSuccess) a = hipMalloc((void**)&h->feW, cfg->integ_num * sizeof(float));
+  if (a == hipSuccess) a = hipMemset(h->theta, 0, P * sizeof(float));
+  if (a == hipSuccess) a = hipMemset(h->m, 0, P * sizeof(float));
+  if (a == hipSuccess) a = hipMemset(h->v, 0, P * sizeof(float));
+  if (a == hipSuccess) a = hipMemset(h->gradbuf_int, 0, (P + 4) * sizeof(float));
+  if (a != hipSuccess) {
+    vn_destroy(h);
+    return fail(VN_ENOMEM, "device allocation failed: %s", hipGetErrorString(a));
+  }
+  h->gradbuf = h->gradbuf_int;
+  h->ev0.resize(PROF_CAP, nullptr);
+  h->ev1.resize(PROF_CAP, nullptr);
+  *out = h;
+  return VN_OK;
+}
+
+int vn_destroy(vn_engine* h) {
+  if (!h) return VN_OK;
+  (void)hipSetDevice(h->cfg.device);
+  void* ptrs[] = {h->theta, h->m, h->v, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
+                  h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
+  for (auto e : h->ev1) if (e) (void)hipEventDestroy(e);
+  delete h;
+  return VN_OK;
+}
+
+int vn_set_stream(vn_engine* h, void* s) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  h->stream = (hipStream_t)s;
+  return VN_OK;
+}
+
+int vn_param_count(const vn_engine* h, int64_t* n) {
+  if (!h || !n) return fail(VN_EINVAL, "null argument");
+  *n = h->net.P;
+  return VN_OK;
+}
+
+int vn_params_init(vn_engine* h, uint64_t seed) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const VnNet& net = h->net;
+  std::vector<float> t(net.P, 0.f);
+  uint64_t s = seed;
+  for (int l = 1; l <= net.L + 1; ++l) {
+    const int fi = net.H[l - 1], fo = net.H[l];
+    const double lim = std::sqrt(6.0 / (double)(fi + fo));          // keras glorot_uniform
+    for (int i = 0; i < fi * fo; ++i) {
+      const double u01 = (double)(splitmix64(s) >> 11) * (1.0 / 9007199254740992.0);
+      t[net.woff[l] + i] = (float)((2.0 * u01 - 1.0) * lim);
+    }
+  }
+  HIPCHK(hipMemcpyAsync(h->theta, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->m, 0, t.size() * sizeof(float), h->stream));
+  HIPCHK(hipMemsetAsync(h->v, 0, t.size() * sizeof(float), h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->step = 0;
+  return VN_OK;
+}
+
+int vn_params_get(vn_engine* h, float* host, int64_t n) {
+  if (!h || !host) return fail(VN_EINVAL, "null argument");
+  if (n != h->net.P) return fail(VN_EINVAL, "expected %d parameters, got %lld", h->net.P, (long long)n);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemcpyAsync(host, h->theta, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VN_OK;
+}
+
+int vn_params_set(vn_engine* h, const float* host, int64_t n) {
+  if (!h || !host) return fail(VN_EINVAL, "null argument");
+  if (n != h->net.P) return fail(VN_EINVAL, "expected %d parameters, got %lld", h->net.P, (long long)n);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemcpyAsync(h->theta, host, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VN_OK;
+}
+
+int vn_state_size(const vn_engine* h, int64_t* bytes) {
+  if (!h || !bytes) return fail(VN_EINVAL, "null argument");
+  *bytes = (int64_t)sizeof(int64_t) + 3ll * h->net.P * (int64_t)sizeof(float);
+  return VN_OK;
+}
+
+int vn_state_export(vn_engine* h, void* host, int64_t bytes) {
+  int64_t need = 0;
+  if (!h || !host) return fail(VN_EINVAL, "null argument");
+  vn_state_size(h, &need);
+  if (bytes != need) return fail(VN_EINVAL, "state buffer must be %lld bytes", (long long)need);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  char* p = (char*)host;
+  memcpy(p, &h->step, sizeof(int64_t));
+  p += sizeof(int64_t);
+  const size_t nb = (size_t)h->net.P * sizeof(float);
+  HIPCHK(hipMemcpyAsync(p, h->theta, nb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(p + nb, h->m, nb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(p + 2 * nb, h->v, nb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VN_OK;
+}
+
+int vn_state_import(vn_engine* h, const void* host, int64_t bytes) {
+  int64_t need = 0;
+  if (!h || !host) return fail(VN_EINVAL, "null argument");
+  vn_state_size(h, &need);
+  if (bytes != need) return fail(VN_EINVAL, "state buffer must be %lld bytes", (long long)need);
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const char* p = (const char*)host;
+  memcpy(&h->step, p, sizeof(int64_t));
+  p += sizeof(int64_t);
+  const size_t nb = (size_t)h->net.P * sizeof(float);
+  HIPCHK(hipMemcpyAsync(h->theta, p, nb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->m, p + nb, nb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->v, p + 2 * nb, nb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return VN_OK;
+}
+
+int vn_set_fe_table(vn_engine* h, const float* N, const float* dNt, const float* integW) {
+  if (!h || !N || !dNt) return fail(VN_EINVAL, "null argument");
+  if (h->cfg.has_integw && !integW) return fail(VN_EINVAL, "config has integW but none was given");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t nb = (size_t)h->cfg.integ_num * sizeof(float);
+  HIPCHK(hipMemcpyAsync(h->feN, N, nb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->fedNt, dNt, nb, hipMemcpyHostToDevice, h->stream));
+  if (integW) HIPCHK(hipMemcpyAsync(h->feW, integW, nb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));   // host buffers may be released on return
+  h->has_fe = true;
+  h->has_feW = integW != nullptr;
+  return VN_OK;
+}
+
+int vn_set_interior(vn_engine* h, int32_t batch, const float* Input, const float* gcoef, const float* source,
+                    int64_t n_k, const float* detJ_dev, double detJ, const float* N_rows, const float* dNt_rows) {
+  if (!h || !Input || !gcoef) return fail(VN_EINVAL, "null argument");
+  if (batch < 0 || batch > 65535) return fail(VN_EINVAL, "batch index %d out of range", batch);
+  if (n_k < 0) return fail(VN_EINVAL, "negative number of test functions");
+  if (h->cfg.has_source && !source) return fail(VN_EINVAL, "config has a source term but source is NULL");
+  if ((N_rows == nullptr) != (dNt_rows == nullptr)) return fail(VN_EINVAL, "N_rows and dNt_rows must be given together");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if ((int)h->batches.size() <= batch) h->batches.resize(batch + 1);
+  Batch& b = h->batches[batch];
+  b.Input = Input; b.gcoef = gcoef; b.source = source; b.detJv = detJ_dev; b.detJ = detJ;
+  b.Nrow = N_rows; b.dNtrow = dNt_rows; b.n_k = n_k; b.set = true;
+  const long nT = n_k * h->cfg.integ_num;
+  if (nT > h->work_rows) {
+    long c0 = h->work_rows, c1 = h->work_rows, c2 = h->work_rows, c3 = h->work_rows;
+    if (int rc = ensure(&h->u, &c0, nT)) return rc;
+    if (int rc = ensure(&h->ud, &c1, nT)) return rc;
+    if (int rc = ensure(&h->ubar, &c2, nT)) return rc;
+    if (int rc = ensure(&h->udbar, &c3, nT)) return rc;
+    h->work_rows = nT;
+  }
+  return VN_OK;
+}
+
+int vn_set_bic(vn_engine* h, const float* biInput, const float* biLabel, int64_t nB, int64_t bDof, double biDimVal) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  if (nB < 0 || bDof < 0 || bDof > nB) return fail(VN_EINVAL, "need 0 <= bDof <= nB");
+  if (nB > 0 && (!biInput || !biLabel)) return fail(VN_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  h->biInput = biInput; h->biLabel = biLabel; h->nB = nB; h->bDof = bDof; h->biDimVal = biDimVal;
+  if (nB > h->work_b) {
+    long c0 = h->work_b, c1 = h->work_b;
+    if (int rc = ensure(&h->ub, &c0, nB)) return rc;
+    if (int rc = ensure(&h->ubar_b, &c1, nB)) return rc;
+    h->work_b = nB;
+  }
+  return VN_OK;
+}
+
+int vn_set_weights(vn_engine* h, const double w[3]) {
+  if (!h || !w) return fail(VN_EINVAL, "null argument");
+  h->w[0] = w[0]; h->w[1] = w[1]; h->w[2] = w[2];
+  return VN_OK;
+}
+
+int vn_bind_grad_buffer(vn_engine* h, float* dev) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  h->gradbuf = dev ? dev : h->gradbuf_int;
+  return VN_OK;
+}
+
+int vn_grad(vn_engine* h, int32_t batch) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  if (int rc = check_batch(h, batch)) return rc;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const Batch& b = h->batches[batch];
+  if (int rc = run_forward_and_seed(h, b, true, nullptr, nullptr)) return rc;
+  const long nT = b.n_k * h->cfg.integ_num;
+  VnRows s0{}, s1{};
+  s0.X = b.Input; s0.G = b.gcoef; s0.ubar = h->ubar; s0.udbar = h->udbar; s0.n = nT;
+  s1.X = h->biInput; s1.G = nullptr; s1.ubar = h->ubar_b; s1.udbar = nullptr; s1.n = h->nB;
+  const bool rec = h->prof_on && h->prof_n < PROF_CAP;
+  if (rec) {
+    if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
+    HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
+  }
+  HIPCHK(vn_generic_backward(h->net, h->theta, s0, s1, h->partial, h->bwd_grid, h->stream));
+  if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
+  const long nthreads = b.n_k > h->nB ? b.n_k : h->nB;
+  const int lgrid = (int)((nthreads + 255) / 256);
+  HIPCHK(vn_reduce_launch(h->partial, h->bwd_grid, h->net.P, h->losspart, lgrid, h->bDof, h->nB, (float)h->w[0],
+                          (float)h->w[1], (float)h->w[2], h->gradbuf, h->stream));
+  return VN_OK;
+}
+
+int vn_apply(vn_engine* h) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  h->step += 1;
+  const double t = (double)h->step;
+  const double lr_t = h->cfg.lr * std::sqrt(1.0 - std::pow(h->cfg.beta2, t)) / (1.0 - std::pow(h->cfg.beta1, t));
+  HIPCHK(vn_adam_launch(h->theta, h->m, h->v, h->gradbuf, h->net.P, (float)lr_t, (float)h->cfg.beta1,
+                        (float)h->cfg.beta2, (float)h->cfg.eps, h->stream));
+  return VN_OK;
+}
+
+int vn_train_step(vn_engine* h, int32_t batch, float* loss_out_dev) {
+  if (int rc = vn_grad(h, batch)) return rc;
+  if (loss_out_dev)
+    HIPCHK(hipMemcpyAsync(loss_out_dev, h->gradbuf + h->net.P, sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  return vn_apply(h);
+}
+
+int vn_eval_loss(vn_engine* h, int32_t batch, double out[4], float* lossVec_dev) {
+  if (!h || !out) return fail(VN_EINVAL, "null argument");
+  if (int rc = check_batch(h, batch)) return rc;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (int rc = run_forward_and_seed(h, h->batches[batch], false, lossVec_dev, h->lossbuf)) return rc;
+  float t[4];
+  HIPCHK(hipMemcpyAsync(t, h->lossbuf, sizeof t, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 4; ++i) out[i] = (double)t[i];
+  return VN_OK;
+}
+
+int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
+  if (!h || (n > 0 && (!X || !u))) return fail(VN_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  VnRows s0{}, s1{};
+  s0.X = X; s0.G = nullptr; s0.u = u; s0.ud = nullptr; s0.n = n;
+  HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));
+  return VN_OK;
+}
+
+int vn_forward_f64(vn_engine* h, const double* X, int64_t n, double* u) {
+  if (!h || (n > 0 && (!X || !u))) return fail(VN_EINVAL, "null argument");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (int rc = refresh_theta64(h)) return rc;
+  HIPCHK(vn_pointwise_forward_f64(h->net, h->theta64, X, n, u, h->stream));
+  return VN_OK;
+}
+
+int vn_residual(vn_engine* h, const float* X, const float* diff, const float* vel, const float* src,
+                const float* ddx, int64_t n, float* u, float* res) {
+  if (!h || (n > 0 && (!X || !diff || !vel || !res))) return fail(VN_EINVAL, "null argument");
+  if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "residual supports dim <= 3");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(vn_pointwise_residual_f32(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res,
+                                   h->stream));
+  return VN_OK;
+}
+
+int vn_residual_f64(vn_engine* h, const double* X, const double* diff, const double* vel, const double* src,
+                    const double* ddx, int64_t n, double* u, double* res) {
+  if (!h || (n > 0 && (!X || !diff || !vel || !res))) return fail(VN_EINVAL, "null argument");
+  if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "residual supports dim <= 3");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  if (int rc = refresh_theta64(h)) return rc;
+  HIPCHK(vn_pointwise_residual_f64(h->net, h->theta64, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res,
+                                   h->stream));
+  return VN_OK;
+}
+
+int vn_get_step(const vn_engine* h, int64_t* step) {
+  if (!h || !step) return fail(VN_EINVAL, "null argument");
+  *step = h->step;
+  return VN_OK;
+}
+
+int vn_profile_begin(vn_engine* h) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  h->prof_on = true;
+  h->prof_n = 0;
+  return VN_OK;
+}
+
+int vn_profile_end(vn_engine* h, double* mean_ms, int64_t* launches, char* name, int32_t name_len) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (int i = 0; i < h->prof_n; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]));
+    tot += ms;
+  }
+  if (mean_ms) *mean_ms = h->prof_n ? tot / h->prof_n : 0.0;
+  if (launches) *launches = h->prof_n;
+  if (name && name_len > 0) {
+    strncpy(name, h->prof_name, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  h->prof_on = false;
+  return VN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Internal declarations shared by the kernel translation units and the C-ABI host layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/varnet_hip.h"
+
+// Network description passed by value to every kernel.  Layer index l = 1..L are the hidden
+// (sigmoid) layers, l = L+1 is the linear output layer; H[0] = d_in, H[L+1] = 1.
+struct VnNet {
+  int d_in, dim, L, P, hmax;
+  int H[VN_MAX_LAYERS + 2];
+  int woff[VN_MAX_LAYERS + 2];   // offset of W_l (row-major [H[l-1], H[l]]) in the flat vector
+  int boff[VN_MAX_LAYERS + 2];   // offset of b_l
+};
+
+// One contiguous set of rows (points) with optional tangent direction and backward seeds.
+struct VnRows {
+  const float* X;      // [n, d_in]
+  const float* G;      // [n, dim] tangent direction (gcoef) or nullptr (zero tangent)
+  const float* ubar;   // [n] d loss / d u      (backward only)
+  const float* udbar;  // [n] d loss / d udot   (backward only; nullptr = 0)
+  float* u;            // [n] out (forward only)
+  float* ud;           // [n] out (forward only; may be nullptr)
+  long n;
+};
+
+// Weak-form epilogue arguments (TFModel.py:643-668 restated on device).
+struct VnSeedArgs {
+  // interior
+  const float* u; const float* ud;          // [nT]
+  const float* source;                      // [nT] or nullptr
+  const float* feN; const float* fedNt; const float* feW;   // [integ_num] tables (feW may be nullptr)
+  const float* Nrow; const float* dNtrow;   // [nT] per-row overrides or nullptr
+  const float* detJv; float detJ;           // per-test-function [n_k] or scalar
+  long n_k; int integ_num; int time_dependent;
+  float* ubar; float* udbar;                // [nT] out (may be nullptr: loss only)
+  float* lossVec;                           // [n_k] out or nullptr
+  // boundary / initial
+  const float* ub; const float* label;      // [nB]
+  long nB, bDof; float biDimVal;
+  float* ubar_b;                            // [nB] out (may be nullptr)
+  float w0, w1, w2;
+  float* part;                              // [gridDim.x * 3] block partials (var, bc, ic)
+};
+
+// ---- generic (any width <= 64, any integ_num) kernels: vn_generic.hip -------------------
+size_t vn_generic_fwd_lds_bytes(const VnNet& net);
+size_t vn_generic_bwd_lds_bytes(const VnNet& net);
+hipError_t vn_generic_forward(const VnNet& net, const float* theta, VnRows seg0, VnRows seg1,
+                              int grid, hipStream_t s);
+hipError_t vn_generic_backward(const VnNet& net, const float* theta, VnRows seg0, VnRows seg1,
+                               float* partial, int grid, hipStream_t s);
+hipError_t vn_seed_launch(const VnSeedArgs& a, int grid, hipStream_t s);
+// grad[p] = sum_g partial[g*P+p]; tail[0..3] = loss, BC, IC, var from the seed partials.
+hipError_t vn_reduce_launch(const float* partial, int nparts, int P, const float* losspart,
+                            int nlossparts, long bDof, long nB, float w0, float w1, float w2,
+                            float* gradbuf, hipStream_t s);
+hipError_t vn_adam_launch(float* theta, float* m, float* v, const float* grad, int P, float lr_t,
+                          float b1, float b2, float eps, hipStream_t s);
+
+// ---- simple per-point evaluation kernels (float / double): vn_pointwise.hip --------------
+hipError_t vn_pointwise_forward_f32(const VnNet& net, const float* theta, const float* X, long n,
+                                    float* u, hipStream_t s);
+hipError_t vn_pointwise_forward_f64(const VnNet& net, const double* theta, const double* X,
+                                    long n, double* u, hipStream_t s);
+hipError_t vn_pointwise_residual_f32(const VnNet& net, const float* theta, const float* X,
+                                     const float* diff, const float* vel, const float* src,
+                                     const float* ddx, int time_dependent, long n, float* u,
+                                     float* res, hipStream_t s);
+hipError_t vn_pointwise_residual_f64(const VnNet& net, const double* theta, const double* X,
+                                     const double* diff, const double* vel, const double* src,
+                                     const double* ddx, int time_dependent, long n, double* u,
+                                     double* res, hipStream_t s);

@@ -1,0 +1,321 @@
+"""
+ctypes binding of libvarnet_hip.so (include/varnet_hip.h) -- the object that takes the place
+of the reference's `TFNN` (/root/reference/TFModel.py:54-436) behind `VarNet`.
+
+PyTorch is used only as plumbing: device memory (tensors whose `data_ptr()` is handed to the
+C ABI), the current HIP stream, and `torch.distributed` for the tower gradient SUM
+(TFModel.py:342-377).  There is no CPU fallback: constructing an engine without the library or
+without a GPU raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvarnet_hip.so')
+
+VN_MAX_LAYERS = 6
+VN_MAX_WIDTH = 64
+VN_MAX_DIN = 8
+VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED = 0, 1, 2
+
+
+class VnConfig(C.Structure):
+    _fields_ = [('dim', C.c_int32), ('d_in', C.c_int32), ('n_layers', C.c_int32),
+                ('widths', C.c_int32 * VN_MAX_LAYERS), ('activation', C.c_int32),
+                ('integ_num', C.c_int32), ('time_dependent', C.c_int32),
+                ('has_source', C.c_int32), ('has_integw', C.c_int32), ('device', C.c_int32),
+                ('optimizer', C.c_int32), ('kernel', C.c_int32),
+                ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
+                ('eps', C.c_double)]
+
+
+_lib = None
+
+_SIGS = {
+    'vn_last_error': (C.c_char_p, []),
+    'vn_abi_version': (C.c_int, []),
+    'vn_create': (C.c_int, [C.POINTER(VnConfig), C.POINTER(C.c_void_p)]),
+    'vn_destroy': (C.c_int, [C.c_void_p]),
+    'vn_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'vn_param_count': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'vn_params_init': (C.c_int, [C.c_void_p, C.c_uint64]),
+    'vn_params_get': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'vn_params_set': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'vn_state_size': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'vn_state_export': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'vn_state_import': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    'vn_set_fe_table': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'vn_set_interior': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    'vn_set_bic': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double]),
+    'vn_set_weights': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    'vn_bind_grad_buffer': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'vn_grad': (C.c_int, [C.c_void_p, C.c_int32]),
+    'vn_apply': (C.c_int, [C.c_void_p]),
+    'vn_train_step': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    'vn_eval_loss': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
+    'vn_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'vn_forward_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'vn_residual': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
+    'vn_residual_f64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
+    'vn_get_step': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'vn_profile_begin': (C.c_int, [C.c_void_p]),
+    'vn_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                 C.c_char_p, C.c_int32]),
+}
+
+ABI_SYMBOLS = tuple(_SIGS.keys())
+
+
+def load_library(path=None):
+    """dlopen libvarnet_hip.so and attach the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(there is no CPU fallback for the VarNet engine)' % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class VNError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    """Device/host address of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    return t.data_ptr()
+
+
+class VNEngine:
+    """
+    One engine per GPU / process.  Mirrors what `VarNet` needs from `TFNN`:
+    parameters + optimiser state, loss / gradient / update on registered batches, model and
+    residual evaluation.
+    """
+
+    def __init__(self, dim, inpDim, layerWidth, timeDependent, integNum, isSource=False,
+                 integWflag=False, learning_rate=0.001, device=0, activationFun='sigmoid',
+                 optimizer_name='adam', kernel=VN_KERNEL_AUTO):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise VNError('no GPU visible: the VarNet HIP engine has no CPU fallback')
+        act = activationFun[0] if isinstance(activationFun, (list, tuple)) else activationFun
+        if isinstance(activationFun, (list, tuple)) and any(a != act for a in activationFun):
+            raise ValueError('mixed activation functions are not supported')
+        if act != 'sigmoid':
+            raise ValueError('only the sigmoid activation is implemented')
+        if optimizer_name.lower() not in ('adam',):
+            raise ValueError('unknown optimizer requested!')           # TFModel.py:133-134
+        if learning_rate < 0.0:
+            raise ValueError('learning rate must be positive!')        # TFModel.py:130
+        if len(layerWidth) > VN_MAX_LAYERS or max(layerWidth) > VN_MAX_WIDTH:
+            raise ValueError('network exceeds engine limits (%d layers x %d)' % (VN_MAX_LAYERS, VN_MAX_WIDTH))
+        cfg = VnConfig()
+        cfg.dim, cfg.d_in, cfg.n_layers = dim, inpDim, len(layerWidth)
+        for i, wd in enumerate(layerWidth):
+            cfg.widths[i] = int(wd)
+        cfg.activation = 0
+        cfg.integ_num = int(integNum)
+        cfg.time_dependent = int(bool(timeDependent))
+        cfg.has_source = int(bool(isSource))
+        cfg.has_integw = int(bool(integWflag))
+        cfg.device = int(device)
+        cfg.optimizer = 0
+        cfg.kernel = kernel
+        cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = learning_rate, 0.9, 0.999, 1e-8
+        self.cfg = cfg
+        self.device = torch.device('cuda', device)
+        self.dim, self.inpDim, self.layerWidth = dim, inpDim, list(layerWidth)
+        self.integNum = int(integNum)
+        self.h = C.c_void_p()
+        self._ck(self.lib.vn_create(C.byref(cfg), C.byref(self.h)))
+        n = C.c_int64()
+        self._ck(self.lib.vn_param_count(self.h, C.byref(n)))
+        self.P = n.value
+        self._keep = {}            # python references to registered device tensors
+        self.gradbuf = None
+        self.use_current_stream()
+
+    # -- plumbing ------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc != 0:
+            raise VNError('varnet_hip error %d: %s' % (rc, self.lib.vn_last_error().decode()))
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.vn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_current_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        self._ck(self.lib.vn_set_stream(self.h, C.c_void_p(s)))
+
+    def dev(self, a, dtype=None):
+        """numpy / tensor -> contiguous device tensor (fp32 by default: TFModel.py:531,602-619)."""
+        torch = self.torch
+        dtype = dtype or torch.float32
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=self.device).contiguous()
+
+    # -- parameters ----------------------------------------------------------------------
+    def init_params(self, seed=0):
+        self._ck(self.lib.vn_params_init(self.h, C.c_uint64(seed)))
+
+    def get_params(self):
+        out = np.empty(self.P, dtype=np.float32)
+        self._ck(self.lib.vn_params_get(self.h, out.ctypes.data, self.P))
+        return out
+
+    def set_params(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        self._ck(self.lib.vn_params_set(self.h, flat.ctypes.data, flat.size))
+
+    def export_state(self):
+        n = C.c_int64()
+        self._ck(self.lib.vn_state_size(self.h, C.byref(n)))
+        buf = np.empty(n.value, dtype=np.uint8)
+        self._ck(self.lib.vn_state_export(self.h, buf.ctypes.data, n.value))
+        return buf
+
+    def import_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._ck(self.lib.vn_state_import(self.h, buf.ctypes.data, buf.size))
+
+    @property
+    def step(self):
+        s = C.c_int64()
+        self._ck(self.lib.vn_get_step(self.h, C.byref(s)))
+        return s.value
+
+    # -- data registration ---------------------------------------------------------------
+    def set_fe_table(self, N, dNt, integW=None):
+        N = np.ascontiguousarray(np.reshape(N, -1), dtype=np.float32)
+        dNt = np.ascontiguousarray(np.reshape(dNt, -1), dtype=np.float32)
+        W = None if integW is None else np.ascontiguousarray(np.reshape(integW, -1), dtype=np.float32)
+        assert N.size == self.integNum and dNt.size == self.integNum
+        self._ck(self.lib.vn_set_fe_table(self.h, N.ctypes.data, dNt.ctypes.data, _ptr(W)))
+
+    def set_interior(self, batch, Input, gcoef, source=None, n_k=None, detJ=1.0, N_rows=None,
+                     dNt_rows=None):
+        Input = self.dev(Input)
+        gcoef = self.dev(gcoef)
+        source = None if source is None else self.dev(np.reshape(source, -1) if isinstance(source, np.ndarray) else source.reshape(-1))
+        nT = Input.shape[0]
+        if n_k is None:
+            n_k = nT // self.integNum
+        assert n_k * self.integNum == nT, 'rows must be whole test functions'
+        assert Input.shape[1] == self.inpDim and gcoef.shape == (nT, self.dim)
+        detJv = None
+        if np.size(detJ) > 1:
+            detJv = self.dev(np.reshape(detJ, -1))
+            assert detJv.numel() == n_k
+            detJ_s = 0.0
+        else:
+            detJ_s = float(np.reshape(detJ, -1)[0]) if not np.isscalar(detJ) else float(detJ)
+        Nr = None if N_rows is None else self.dev(np.reshape(N_rows, -1))
+        dNr = None if dNt_rows is None else self.dev(np.reshape(dNt_rows, -1))
+        self._keep[('int', batch)] = (Input, gcoef, source, detJv, Nr, dNr)
+        self._ck(self.lib.vn_set_interior(self.h, batch, _ptr(Input), _ptr(gcoef), _ptr(source), n_k,
+                                          _ptr(detJv), detJ_s, _ptr(Nr), _ptr(dNr)))
+
+    def set_bic(self, biInput, biLabel, bDof, biDimVal):
+        if biInput is None or len(biInput) == 0:
+            self._keep['bic'] = None
+            self._ck(self.lib.vn_set_bic(self.h, None, None, 0, 0, float(biDimVal)))
+            return
+        biInput = self.dev(biInput)
+        biLabel = self.dev(np.reshape(biLabel, -1) if isinstance(biLabel, np.ndarray) else biLabel.reshape(-1))
+        self._keep['bic'] = (biInput, biLabel)
+        self._ck(self.lib.vn_set_bic(self.h, _ptr(biInput), _ptr(biLabel), biInput.shape[0], int(bDof),
+                                     float(biDimVal)))
+
+    def set_weights(self, w):
+        arr = (C.c_double * 3)(*[float(x) for x in w])
+        self._ck(self.lib.vn_set_weights(self.h, arr))
+
+    # -- compute -------------------------------------------------------------------------
+    def bind_grad_buffer(self):
+        """Torch-owned [P+4] gradient buffer so torch.distributed can all-reduce it."""
+        if self.gradbuf is None:
+            self.gradbuf = self.torch.zeros(self.P + 4, dtype=self.torch.float32, device=self.device)
+            self._ck(self.lib.vn_bind_grad_buffer(self.h, _ptr(self.gradbuf)))
+        return self.gradbuf
+
+    def grad(self, batch=0):
+        self._ck(self.lib.vn_grad(self.h, batch))
+
+    def apply(self):
+        self._ck(self.lib.vn_apply(self.h))
+
+    def train_step(self, batch=0, loss_out=None):
+        self._ck(self.lib.vn_train_step(self.h, batch, _ptr(loss_out)))
+
+    def eval_loss(self, batch=0, lossVec=False):
+        out = (C.c_double * 4)()
+        lv = None
+        if lossVec:
+            n_k = self._keep[('int', batch)][0].shape[0] // self.integNum
+            lv = self.torch.empty(n_k, dtype=self.torch.float32, device=self.device)
+        self._ck(self.lib.vn_eval_loss(self.h, batch, out, _ptr(lv)))
+        return list(out), lv
+
+    def forward(self, X):
+        X = self.dev(X)
+        u = self.torch.empty(X.shape[0], dtype=self.torch.float32, device=self.device)
+        self._ck(self.lib.vn_forward(self.h, _ptr(X), X.shape[0], _ptr(u)))
+        return u
+
+    def forward_f64(self, X):
+        t = self.torch
+        X = self.dev(X, t.float64)
+        u = t.empty(X.shape[0], dtype=t.float64, device=self.device)
+        self._ck(self.lib.vn_forward_f64(self.h, _ptr(X), X.shape[0], _ptr(u)))
+        return u
+
+    def residual(self, X, diff, vel, source=None, diff_dx=None, fp64=False):
+        t = self.torch
+        dt = t.float64 if fp64 else t.float32
+        X = self.dev(X, dt)
+        n = X.shape[0]
+        diff = self.dev(np.reshape(diff, -1), dt)
+        vel = self.dev(np.reshape(vel, (n, self.dim)), dt)
+        source = None if source is None else self.dev(np.reshape(source, -1), dt)
+        diff_dx = None if diff_dx is None else self.dev(np.reshape(diff_dx, (n, self.dim)), dt)
+        u = t.empty(n, dtype=dt, device=self.device)
+        r = t.empty(n, dtype=dt, device=self.device)
+        fn = self.lib.vn_residual_f64 if fp64 else self.lib.vn_residual
+        self._ck(fn(self.h, _ptr(X), _ptr(diff), _ptr(vel), _ptr(source), _ptr(diff_dx), n, _ptr(u), _ptr(r)))
+        return u, r
+
+    # -- profiling -----------------------------------------------------------------------
+    def profile_begin(self):
+        self._ck(self.lib.vn_profile_begin(self.h))
+
+    def profile_end(self):
+        ms, n = C.c_double(), C.c_int64()
+        name = C.create_string_buffer(128)
+        self._ck(self.lib.vn_profile_end(self.h, C.byref(ms), C.byref(n), name, 128))
+        return ms.value, n.value, name.value.decode()
