@@ -60,7 +60,7 @@ CASES = [
     # d_in dim widths            integNum n_k  nB  bDof source integW detJvec
     (2, 1, [20, 20, 20],         16,      40,  50, 30,  False, False, False),
     (3, 2, [50, 50, 50, 50, 50], 64,      9,   77, 40,  False, False, False),
-    (3, 2, [10, 20],             64,      5,   33, 33,  True,  False, False),
+    (3, 2, [10, 20],             64,      5,   33, 20,  True,  False, False),
     (3, 1, [10, 20, 30],         16,      21,  19, 7,   False, False, False),   # MOR-style extra input
     (2, 1, [7],                  36,      11,  40, 13,  True,  True,  True),
     (3, 2, [64, 64, 64],         216,     3,   5,  2,   False, True,  False),
