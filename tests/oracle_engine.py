@@ -1,0 +1,124 @@
+"""
+TEST-ONLY stand-in for varnet_amd.engine.VNEngine that computes with the oracle
+(oracle/tangent_ref.py + oracle/tf1_graph.py) on the CPU.  It lets the host logic of
+`VarNet` (data assembly, batching, tower sharding, weight rules, the training loop and the
+gradient all-reduce) run in the CPU test tier, including world_size-2 gloo runs.  It is never
+importable from the product package.
+"""
+import numpy as np
+import torch
+
+from oracle import tf1_graph as og
+from oracle import tangent_ref as tr
+
+
+class OracleEngine:
+    def __init__(self, dim, inpDim, layerWidth, timeDependent, integNum, isSource=False,
+                 integWflag=False, learning_rate=0.001, device=0, activationFun='sigmoid',
+                 optimizer_name='adam', kernel=0, dtype=np.float64):
+        self.torch = torch
+        self.device = torch.device('cpu')
+        self.dim, self.inpDim, self.layerWidth = dim, inpDim, list(layerWidth)
+        self.td, self.integNum = bool(timeDependent), int(integNum)
+        self.isSource, self.integWflag = bool(isSource), bool(integWflag)
+        self.P = og.param_count(inpDim, layerWidth)
+        self.dtype = dtype
+        self.lr = learning_rate
+        self.theta = np.zeros(self.P, dtype=dtype)
+        self.adam = og.TF1Adam(self.P, lr=learning_rate, dtype=dtype)
+        self.batches, self.bic = {}, None
+        self.w = np.ones(3)
+        self.gradbuf = None
+        self.fe = None
+
+    def dev(self, a, dtype=None):
+        if isinstance(a, torch.Tensor):
+            return a.to(torch.float64).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64)
+
+    def init_params(self, seed=0):
+        self.theta = og.glorot_init(self.inpDim, self.layerWidth, seed).astype(self.dtype)
+        self.adam = og.TF1Adam(self.P, lr=self.lr, dtype=self.dtype)
+
+    def get_params(self):
+        return self.theta.astype(np.float32)
+
+    def set_params(self, flat):
+        self.theta = np.asarray(flat).astype(self.dtype)
+
+    def export_state(self):
+        return np.concatenate([[self.adam.t], self.theta, self.adam.m, self.adam.v]).astype(np.float64).view(np.uint8)
+
+    def import_state(self, buf):
+        a = np.asarray(buf, dtype=np.uint8).view(np.float64)
+        P = self.P
+        self.adam.t = int(a[0])
+        self.theta, self.adam.m, self.adam.v = a[1:1 + P].copy(), a[1 + P:1 + 2 * P].copy(), a[1 + 2 * P:].copy()
+
+    @property
+    def step(self):
+        return self.adam.t
+
+    def set_fe_table(self, N, dNt, integW=None):
+        self.fe = (np.reshape(N, -1).astype(self.dtype), np.reshape(dNt, -1).astype(self.dtype),
+                   None if integW is None else np.reshape(integW, -1).astype(self.dtype))
+
+    def set_interior(self, batch, Input, gcoef, source=None, n_k=None, detJ=1.0, N_rows=None, dNt_rows=None):
+        self.batches[batch] = (Input.numpy().copy(), gcoef.numpy().copy(),
+                               None if source is None else source.numpy().copy(), int(n_k), detJ)
+
+    def set_bic(self, biInput, biLabel, bDof, biDimVal):
+        self.bic = (biInput.numpy().copy(), biLabel.numpy().copy(), int(bDof), float(biDimVal))
+
+    def set_weights(self, w):
+        self.w = np.array(w, dtype=float)
+
+    def bind_grad_buffer(self):
+        if self.gradbuf is None:
+            self.gradbuf = torch.zeros(self.P + 4, dtype=torch.float64)
+        return self.gradbuf
+
+    def _eval(self, batch):
+        Input, gcoef, src, n_k, detJ = self.batches[batch]
+        biInput, biLabel, bDof, biDimVal = self.bic
+        N, dNt, W = self.fe
+        q = self.integNum
+        return tr.loss_and_grad(self.theta.astype(np.float64), self.inpDim, self.layerWidth, self.dim,
+                                Input, gcoef, src if self.isSource else None, np.tile(N, n_k), np.tile(dNt, n_k),
+                                W if self.integWflag else None, n_k, q, detJ, biInput, biLabel, bDof, biDimVal,
+                                self.w, self.td)
+
+    def grad(self, batch=0):
+        res, g = self._eval(batch)
+        gb = self.bind_grad_buffer()
+        gb[:self.P] = torch.as_tensor(g)
+        gb[self.P:] = torch.tensor([res['loss'], res['BCloss'], res['ICloss'], res['varLoss']])
+
+    def apply(self):
+        self.theta = self.adam.step(self.theta, self.gradbuf[:self.P].numpy())
+
+    def train_step(self, batch=0, loss_out=None):
+        self.grad(batch)
+        if loss_out is not None:
+            loss_out[0] = self.gradbuf[self.P]
+        self.apply()
+
+    def eval_loss(self, batch=0, lossVec=False):
+        res, _ = self._eval(batch)
+        lv = torch.as_tensor(res['lossVec']) if lossVec else None
+        return [res['loss'], res['BCloss'], res['ICloss'], res['varLoss']], lv
+
+    def forward(self, X):
+        X = X.numpy() if isinstance(X, torch.Tensor) else np.asarray(X)
+        return torch.as_tensor(og.forward(self.theta, self.inpDim, self.layerWidth, torch.float64, X)[:, 0])
+
+    def residual(self, X, diff, vel, source=None, diff_dx=None, fp64=False):
+        n = np.shape(X)[0]
+        src = np.zeros((n, 1)) if source is None else np.reshape(source, (n, 1))
+        ddx = np.zeros((n, self.dim)) if diff_dx is None else np.reshape(diff_dx, (n, self.dim))
+        u, r = og.residual(self.theta, self.inpDim, self.layerWidth, torch.float64, np.asarray(X),
+                           np.reshape(diff, (n, 1)), np.reshape(vel, (n, self.dim)), src, ddx, self.dim, self.td)
+        return torch.as_tensor(u[:, 0]), torch.as_tensor(r[:, 0])
+
+    def close(self):
+        pass

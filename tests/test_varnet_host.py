@@ -1,0 +1,220 @@
+"""
+CPU tests of the host logic of `VarNet` with the oracle-backed test engine
+(tests/oracle_engine.py): data assembly known answers recorded in SURVEY.md 8(c) from the
+reference's own code, the analytic-solution known answer, batching / sharding rules, the
+training loop, checkpoints.
+"""
+import os
+import numpy as np
+import pytest
+
+from varnet_amd.domain import Domain1D, PolygonDomain2D
+from varnet_amd.adpde import ADPDE
+from varnet_amd.mor import MOR
+from varnet_amd import varnet as vmod
+from varnet_amd.varnet import VarNet
+from tests.oracle_engine import OracleEngine
+
+pi = np.pi
+
+
+@pytest.fixture(autouse=True)
+def cpu_engine(monkeypatch):
+    def make(self, processors):
+        fd = self.fixData
+        return OracleEngine(self.dim, self.inpDim, self.layerWidth, self.PDE.timeDependent, fd.integNum,
+                            isSource=self.lossOpt['isSource'], integWflag=self.lossOpt['integWflag'],
+                            learning_rate=self.learning_rate)
+    monkeypatch.setattr(VarNet, '_make_engine', make)
+
+
+def cExact(x, t, trunc=800, u=1.0, D=0.1 / pi, deriv=False):
+    """Fourier-series solution of the 1D+t problem (Operator_1Dt.py:78-108); with deriv=True also
+    its analytic x-derivative."""
+    p = np.arange(0, trunc + 1.0).reshape(1, trunc + 1)
+    c0 = 16 * pi ** 2 * D ** 3 * u * np.exp(u / D / 2 * (x - u * t / 2))
+    e1 = np.exp(-D * p ** 2 * pi ** 2 * t)
+    e2 = np.exp(-D * (2 * p + 1) ** 2 * pi ** 2 * t / 4)
+    c1d = u ** 4 + 8 * (u * pi * D) ** 2 * (p ** 2 + 1) + 16 * (pi * D) ** 4 * (p ** 2 - 1) ** 2
+    c2d = u ** 4 + (u * pi * D) ** 2 * (8 * p ** 2 + 8 * p + 10) + (pi * D) ** 4 * (4 * p ** 2 + 4 * p - 3) ** 2
+    sh, ch = np.sinh(u / D / 2), np.cosh(u / D / 2)
+    S = sh * np.sum((-1) ** p * 2 * p * np.sin(p * pi * x) * e1 / c1d, axis=-1, keepdims=True) + \
+        ch * np.sum((-1) ** p * (2 * p + 1) * np.cos((p + 0.5) * pi * x) * e2 / c2d, axis=-1, keepdims=True)
+    c = c0 * S
+    ind0 = t == 0
+    c[ind0] = -np.sin(pi * x[ind0])
+    if not deriv:
+        return c
+    Sx = sh * np.sum((-1) ** p * 2 * p * p * pi * np.cos(p * pi * x) * e1 / c1d, axis=-1, keepdims=True) - \
+        ch * np.sum((-1) ** p * (2 * p + 1) * (p + 0.5) * pi * np.sin((p + 0.5) * pi * x) * e2 / c2d,
+                    axis=-1, keepdims=True)
+    return c, c0 * (u / D / 2 * S + Sx)
+
+
+def op1dt(layerWidth=[20], discNum=20, tDiscNum=300, cEx=None):
+    pde = ADPDE(Domain1D(), diff=0.1 / pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                IC=lambda x: -np.sin(pi * x), cEx=cEx)
+    return VarNet(pde, layerWidth=layerWidth, discNum=discNum, bDiscNum=None, tDiscNum=tDiscNum)
+
+
+def op2dt(discNum=[80, 40], bDiscNum=40, tDiscNum=75, layerWidth=[10, 20]):
+    verts = np.array([[0.0, -0.5], [0.0, -0.2], [0.0, 0.2], [0.0, 0.5], [2.0, 0.5], [2.0, -0.5]])
+    BC = [[], [0.0, 1.0, 1.0], [], [], [], []]
+    pde = ADPDE(PolygonDomain2D(verts), diff=1e-3, vel=[1., 0.], tInterval=[0, 1.5], BCs=BC, IC=0.0)
+    return VarNet(pde, layerWidth=layerWidth, discNum=discNum, bDiscNum=bDiscNum, tDiscNum=tDiscNum)
+
+
+def test_survey_known_answers_1dt():
+    """Values the survey recorded by running the reference's own FIXData / trainingPoints on the
+    Operator_1Dt settings."""
+    vn = op1dt()
+    fd = vn.fixData
+    assert (fd.nt, fd.nT, fd.integNum) == (6000, 96000, 16)
+    np.testing.assert_allclose(fd.detJ, 1.5873015873e-4, rtol=1e-10)
+    assert list(fd.biDof) == [300, 300, 20] and fd.bDofsum == 600
+    assert fd.biDimVal == 2.0
+    np.testing.assert_allclose(fd.hVec.reshape(-1), [0.0952381, 0.00666667], rtol=1e-6)
+    Input, _, biInput, biDof = vn.trainingPoints()
+    assert Input.shape == (96000, 2) and biInput.shape == (620, 2)
+    np.testing.assert_allclose(Input[0], [-0.88463573, 0.0080755], atol=5e-9)
+    np.testing.assert_allclose([Input[:, 1].min(), Input[:, 1].max()], [0.00141, 2.00526], atol=5e-6)
+    assert vn.lossOpt == {'integWflag': False, 'isSource': False}
+    assert vn.inpDim == 2
+
+
+def test_survey_known_answers_2dt():
+    vn = op2dt()
+    fd = vn.fixData
+    assert (fd.nt, fd.nT, fd.integNum) == (240000, 15360000, 64)
+    np.testing.assert_allclose(fd.detJ, 1.50557e-6, rtol=1e-5)
+    assert list(fd.biDof) == [900, 1200, 900, 6000, 3000, 6000, 3200]
+
+
+def test_training_point_layout_small_2dt():
+    vn = op2dt(discNum=[4, 3], bDiscNum=3, tDiscNum=4)
+    fd = vn.fixData
+    Input, _, biInput, biDof = vn.trainingPoints()
+    q = fd.integNum
+    mesh = vn.PDE.domain.getMesh([4, 3], 3)
+    ht, t = vn.timeDisc()
+    # row r = k*q + p; test functions space-major, time-minor
+    for k in (0, 5, fd.nt - 1):
+        xk = mesh.coordinates[k // 4]
+        tk = t[k % 4, 0]
+        for p in (0, 7, q - 1):
+            exp = np.concatenate([xk + mesh.he * fd.delta[:2, p], [tk + ht * fd.delta[2, p]]])
+            np.testing.assert_allclose(Input[k * q + p], exp, rtol=1e-13)
+    assert biInput.shape[0] == sum(biDof)
+    lab = vn.biTrainData(biInput, biDof)
+    # the only non-zero Dirichlet data is c=1 on edge 1 (x=0,|y|<0.2)
+    o = biDof[0]
+    assert np.all(lab[o:o + biDof[1]] == 1.0) and np.all(lab[:o] == 0.0) and np.all(lab[o + biDof[1]:] == 0.0)
+
+
+def test_exact_solution_weak_residual_is_small():
+    """SURVEY 8c known answer: assembled with the tables, the weak residual of the analytic 1D+t
+    solution is ~0 (varLoss ~5e-3) against ~71 for the frozen initial condition."""
+    vn = op1dt()
+    fd = vn.fixData
+    Input, _, _, _ = vn.trainingPoints()
+    nt, q = fd.nt, fd.integNum
+    x, t = Input[:, 0:1], Input[:, 1:2]
+    D, u = 0.1 / pi, 1.0
+    N, dNx, dNt = fd.N, fd.dNx[:, 0], fd.dNt
+
+    def var_loss(c, cx):
+        gcoef = (D * np.tile(dNx, nt) + u * np.tile(N, nt))
+        int1 = cx[:, 0] * gcoef - c[:, 0] * np.tile(dNt, nt)
+        R = int1.reshape(nt, q).sum(axis=1)
+        return fd.detJ * np.sum(R ** 2), np.abs(R).max()
+
+    c, cx = cExact(x, t, deriv=True)
+    v_exact, rmax = var_loss(c, cx)
+    c0 = -np.sin(pi * x)
+    v_ic, _ = var_loss(c0, -pi * np.cos(pi * x))
+    assert v_exact < 2e-2 and rmax < 1.0
+    assert 60 < v_ic < 80
+
+
+def test_batching_and_weights_rule():
+    vn = op1dt(discNum=5, tDiscNum=6)
+    td = vn._build_tdata(batchNum=4)
+    assert td.batchLen == int(np.ceil(30 / 4)) and td.batchNum == 4
+    blocks = [td.block(b) for b in range(4)]
+    assert blocks == [(0, 8), (8, 16), (16, 24), (24, 30)]
+    td2 = vn._build_tdata(batchLen=7)
+    assert td2.batchNum == int(np.ceil(30 / 7)) and td2.block(td2.batchNum - 1)[1] == 30
+    with pytest.raises(ValueError):
+        vn._build_tdata(batchNum=2, batchLen=3)
+
+
+def test_train_loop_decreases_loss_and_checkpoints(tmp_path):
+    vn = op1dt(layerWidth=[8, 8], discNum=6, tDiscNum=8, cEx=cExact)
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=40, saveFreq=20, verbose=False)
+    assert len(res.loss) == 40 and res.loss[-1] < res.loss[0]
+    np.testing.assert_allclose(res.loss[0], 1e6, rtol=1e-6)       # initial weighted loss normalised to 1e6
+    assert os.path.exists(os.path.join(str(tmp_path), 'caseData.txt'))
+    assert os.path.exists(os.path.join(str(tmp_path), 'trainData.vn'))
+    p = vn.engine.get_params().copy()
+    vn.engine.init_params(seed=5)
+    n = vn.loadModel()
+    assert n in (20, 40)
+    c = vn.evaluate()
+    assert c.shape == (vn.fixData.uniform_input.shape[0], 1)
+    r, rv, err, ca = vn.residual()
+    assert np.isfinite(r) and np.isfinite(err) and rv.shape == c.shape
+    out = vn.saveNNparam()
+    assert out['W0'].shape == (2, 8) and out['W2'].shape == (8, 1)
+
+
+def test_minibatch_epoch_equals_manual_steps(tmp_path):
+    """batchNum=3: BC/IC weights divided by batchNum (VarNetUtility.py:900-901), one Adam step per
+    mini-batch, epoch loss = sum of pre-update batch losses (VarNetUtility.py:1043-1045)."""
+    vn = op1dt(layerWidth=[6], discNum=5, tDiscNum=6)
+    res = vn.train(str(tmp_path), weight=[1., 1., 1.], epochNum=2, saveFreq=100, verbose=False, batchNum=3)
+    assert vn.engine.step == 6
+    tw = res.trainWeight
+    np.testing.assert_allclose(vn.engine.w, [tw[0] / 3, tw[1] / 3, tw[2]])
+
+
+def test_mor_pipeline(tmp_path):
+    def diffFun(x, t=0, D=0.01):
+        return D * np.ones([np.shape(x)[0], 1])
+
+    def disc(discNum=3):
+        return np.array([0.003 * (11 ** (n / (discNum - 1))) for n in range(discNum)])[np.newaxis].T
+
+    mor = MOR(diffFun, ['D'], [[0.003, 0.033]])
+    pde = ADPDE(Domain1D(), diff=diffFun, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                IC=lambda x: -np.sin(pi * x), MORvar=mor)
+    vn = VarNet(pde, layerWidth=[5, 5], discNum=5, bDiscNum=None, tDiscNum=6, MORdiscScheme=disc)
+    assert vn.inpDim == 3 and vn.fixData.MORbatchNum == 3
+    td = vn._build_tdata()
+    for b, kappa in enumerate(disc()[:, 0]):
+        Inp = td.mor[b]['Input'].numpy()
+        np.testing.assert_allclose(Inp[:, 2], kappa)
+        # gcoef = kappa*dNx + v*N
+        g = td.mor[b]['gcoef'].numpy().reshape(vn.fixData.nt, vn.fixData.integNum)
+        np.testing.assert_allclose(g[3], kappa * vn.fixData.dNx[:, 0] + vn.fixData.N, rtol=1e-12)
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=3, saveFreq=100, verbose=False)
+    assert vn.engine.step == 9 and np.isfinite(res.loss[-1])
+    c = vn.evaluate(x=np.array([[0.1], [0.2]]), t=np.array([[0.5], [0.6]]), batch=1)
+    c2 = vn.evaluate(x=np.array([[0.1], [0.2]]), t=np.array([[0.5], [0.6]]), MORarg=np.array([[disc()[1, 0]]]))
+    np.testing.assert_allclose(c, c2)
+
+
+def test_constructor_errors():
+    pde = ADPDE(Domain1D(), diff=0.1, vel=1.0, tInterval=[0, 1.0], IC=0.0)
+    with pytest.raises(ValueError):
+        VarNet(pde, layerWidth=[5], discNum=[3, 3], tDiscNum=4)
+    with pytest.raises(ValueError):
+        VarNet(pde, layerWidth=[5], discNum=3, bDiscNum=None)            # tDiscNum missing
+    with pytest.raises(ValueError):
+        VarNet(pde, layerWidth=5, discNum=3, bDiscNum=None, tDiscNum=4)
+    with pytest.raises(NotImplementedError):
+        VarNet(pde, layerWidth=[5], modelId='RNN', discNum=3, bDiscNum=None, tDiscNum=4)
+    vn = VarNet(pde, layerWidth=[5], discNum=3, bDiscNum=None, tDiscNum=4)
+    with pytest.raises(ValueError):
+        vn.train(None, epochNum=1)
+    with pytest.raises(ValueError):
+        vn.train('/tmp/x', weight=[1., 1.], epochNum=1)

@@ -1,0 +1,124 @@
+"""
+Hot-path subset of the reference's `UF` helper bag (/root/reference/UtilityFunc.py), restated:
+only what the VarNet training path reaches (isnone/isempty/vstack/hstack/pairMats/l2Err/
+polyArea/buildDict/reorderList/mergeDict).  Same names and argument meaning so that user
+scripts written against the reference keep working.
+"""
+import numbers
+import numpy as np
+
+
+class UF:
+    # -- emptiness / None tests (UtilityFunc.py:101-138) ---------------------------------
+    def isnumber(self, x):
+        if isinstance(x, (list, tuple, np.ndarray)):
+            return all(isinstance(v, numbers.Number) for v in np.asarray(x, dtype=object).reshape(-1))
+        return isinstance(x, numbers.Number)
+
+    def isempty(self, x):
+        if isinstance(x, (list, dict)):
+            return len(x) == 0
+        return np.size(x) == 0
+
+    def unpackList(self, x):
+        if not isinstance(x, list):
+            raise ValueError('Input argument must be a list!')
+        out = []
+        for item in x:
+            if isinstance(item, list):
+                out.extend(self.unpackList(item))
+            elif not self.isempty(item):
+                out.append(item)
+        return out
+
+    def isnone(self, x):
+        """True if x is None or any element of x is None (empty containers are not None)."""
+        if x is None:
+            return True
+        if self.isempty(x):
+            return False
+        if isinstance(x, list):
+            for item in self.unpackList(x):
+                if isinstance(item, np.ndarray):
+                    if item.dtype == object and any(v is None for v in item.reshape(-1)):
+                        return True
+                elif item is None:
+                    return True
+            return False
+        if isinstance(x, np.ndarray):
+            return x.dtype == object and any(v is None for v in x.reshape(-1))
+        return False
+
+    # -- stacking that tolerates empty operands (UtilityFunc.py:159-184) -------------------
+    def vstack(self, tup):
+        keep = [t for t in tup if not self.isempty(t)]
+        return np.vstack(keep) if keep else []
+
+    def hstack(self, tup):
+        keep = [t for t in tup if not self.isempty(t)]
+        return np.hstack(keep) if keep else []
+
+    # -- cartesian pairing (UtilityFunc.py:301-339) ----------------------------------------
+    def pairMats(self, mat1, mat2, reverse=False):
+        """
+        Rows of the result are all (row of mat1, row of mat2) pairs, mat1 index slowest.
+        With reverse=True the roles are swapped but the column order [mat1 | mat2] is kept.
+        """
+        if self.isempty(mat1):
+            return mat2
+        if self.isempty(mat2):
+            return mat1
+        if reverse:
+            mat1, mat2 = mat2, mat1
+        mat1 = np.asarray(mat1)
+        mat2 = np.asarray(mat2)
+        n1, n2 = mat1.shape[0], mat2.shape[0]
+        A = np.repeat(mat1, n2, axis=0)
+        B = np.tile(mat2, (n1, 1))
+        return np.hstack([A, B]) if not reverse else np.hstack([B, A])
+
+    # -- small helpers -------------------------------------------------------------------
+    def reorderList(self, x, ind):
+        ind = np.reshape(np.asarray(ind), -1)
+        return [x[int(i)] for i in ind]
+
+    def buildDict(self, keys, values):
+        if len(keys) != len(values):
+            raise ValueError('length of the keys and values must match!')
+        return {k: v for k, v in zip(keys, values)}
+
+    def mergeDict(self, dictList):
+        if not isinstance(dictList, list):
+            raise ValueError('input must be a list of dictionaries!')
+        out = {}
+        for d in dictList:
+            out.update(d)
+        return out
+
+    def l2Err(self, xTrue, xApp):
+        """Normalised l2 error ||xTrue-xApp|| / ||xTrue|| (UtilityFunc.py:485-499)."""
+        xTrue = np.reshape(np.asarray(xTrue, dtype=float), -1)
+        xApp = np.reshape(np.asarray(xApp, dtype=float), -1)
+        if xTrue.size != xApp.size:
+            raise ValueError('\'xTrue\' and \'xApp\' must have the same shape!')
+        return np.linalg.norm(xTrue - xApp) / np.linalg.norm(xTrue)
+
+    def polyArea(self, x, y=None):
+        """Shoelace area (UtilityFunc.py:541-563)."""
+        if y is None:
+            x = np.asarray(x)
+            if x.ndim != 2 or x.shape[1] != 2:
+                raise ValueError('input must be 2d!')
+            x, y = x[:, 1], x[:, 0]
+        else:
+            x = np.reshape(x, -1)
+            y = np.reshape(y, -1)
+            if len(x) != len(y):
+                raise ValueError('\'x\' and \'y\' must be the same length!')
+        return 0.5 * np.abs(np.dot(x, np.roll(y, 1)) - np.dot(y, np.roll(x, 1)))
+
+    def nodeNum(self, x, val):
+        """Index of the entry of x closest to each value in val."""
+        x = np.reshape(np.asarray(x, dtype=float), -1)
+        val = np.reshape(np.asarray(val, dtype=float), -1)
+        return np.array([int(np.argmin(np.abs(x - v))) for v in val])

@@ -1,0 +1,834 @@
+"""
+`VarNet` -- trainer / data assembly for the variational (weak-form) loss, with the reference's
+constructor and `train / evaluate / residual / loadModel` surface
+(/root/reference/VarNet.py:67-203, 1197-1692), re-designed around a GPU-resident engine:
+
+  reference (TF1)                                   here (MI355X)
+  ------------------------------------------------  ------------------------------------------
+  nT-row fp64 NumPy arrays re-fed host->device on   built once on the host in fp64 (same
+  EVERY step through sess.run(feed_dict)            arithmetic, so the fp32 values the device
+  (VarNetUtility.py:840-854, 1044)                  sees are identical), uploaded once, resident
+  N / dNt tiled to nT rows (FiniteElement.py:426)   period-integNum tables inside the engine
+  towers in one process, grads summed on a          one process per GPU, contiguous test-function
+  controller (TFModel.py:342-377)                   shard per rank, SUM all-reduce of the flat
+                                                    gradient over RCCL (torch.distributed)
+  loss read back every step (VarNetUtility.py:1044) accumulated on device, read once per epoch
+
+Out of scope here: modelId='RNN', smpScheme='optimal', updateWeights, plots.
+"""
+import math
+import os
+import pickle
+import time
+import warnings
+
+import numpy as np
+
+from .finite_element import FE
+from .utility import UF
+
+uf = UF()
+shape = np.shape
+size = np.size
+
+
+# ======================================================================================
+class FIXData:
+    """
+    Static discretisation data (/root/reference/VarNetUtility.py:204-463).  Differences from
+    the reference: `N`, `dNx`, `dNt` are the period-`integNum` tables ([integNum], [integNum,dim],
+    [integNum]) instead of nT-row tilings -- `rows()` materialises the tiled form on demand.
+    """
+
+    def __init__(self, vn, integPnum=2):
+        dim = vn.dim
+        PDE = vn.PDE
+        domain = PDE.domain
+        MORvar = PDE.MORvar
+        timeDependent = PDE.timeDependent
+        if timeDependent:
+            feDim = dim + 1
+            tDiscNum = vn.tDiscNum
+            ht, t_coord = vn.timeDisc()
+        else:
+            feDim = dim
+            tDiscNum = 1
+            t_coord = []
+        mesh = domain.getMesh(vn.discNum, vn.bDiscNum)
+        dof = mesh.dof
+        he = np.reshape(mesh.he, [dim, 1])
+        hVec = np.vstack([he, ht]) if timeDependent else he
+        uniform_biInput, biDof = vn.biTrainPoints(mesh, t_coord)
+        nt = dof * tDiscNum
+        biDimVal = domain.measure                                   # VarNetUtility.py:293
+
+        lossVecflag = True
+        if nt > 1e6:                                                # VarNetUtility.py:300-303
+            lossVecflag = False
+            mesh = domain.getMesh(discNum=100, bDiscNum=50)
+            if timeDependent:
+                _, t_coord = vn.timeDisc(tdof=100)
+        coord = mesh.coordinates
+        uniform_input = uf.pairMats(coord, t_coord) if timeDependent else coord
+        if nt > 1e6:
+            uniform_biInput, _ = vn.biTrainPoints(mesh, t_coord)
+
+        if MORvar is not None:
+            discArg = MORvar.discretizeArg(vn.MORdiscScheme)
+            argInd = MORvar.argIndex(discArg)
+            batchNum = len(argInd)
+            if batchNum > 16:
+                lossVecflag = False
+        else:
+            discArg, argInd, batchNum = None, None, 1
+
+        self.dim, self.feDim, self.timeDependent = dim, feDim, timeDependent
+        self.integPnum = integPnum
+        self.dof, self.bdof = dof, mesh.bdof
+        self.biDof0, self.nt0 = biDof, nt
+        self.hVec, self.biDimVal = hVec, biDimVal
+        self.detJvec = False
+        self.lossVecflag = lossVecflag
+        self.uniform_input, self.uniform_biInput = uniform_input, uniform_biInput
+        self.MORbatchNum, self.MORargInd, self.MORdiscArg = batchNum, argInd, discArg
+        self.cEx = self.uniform_inpData = self.d_diff = None
+        self.integNum = self.biDof = self.bDofsum = self.nt = self.nT = None
+        self.delta = self.integW = self.detJ = self.N = self.dNx = self.dNt = None
+
+    def setInputData(self, vn):
+        """Exact solution, PDE fields and grad(kappa) on `uniform_input` (VarNetUtility.py:364-411)."""
+        dim, PDE = self.dim, vn.PDE
+        ui = self.uniform_input
+        Coord = ui[:, :dim]
+        targ = [ui[:, dim:dim + 1]] if self.timeDependent else []
+        self.cEx = PDE.cEx(Coord, *targ) if PDE.cEx is not None else None
+        self.uniform_inpData = vn.PDEinpData(ui) if PDE.MORvar is None else [None] * 3
+        self.d_diff = PDE.d_diffFun(Coord, *targ)
+
+    def setFEdata(self):
+        """FE tables of the initial uniform sampling (VarNetUtility.py:415-462)."""
+        biDof = self.biDof0
+        self.bDofsum = int(np.sum(biDof[:-1])) if self.timeDependent else int(np.sum(biDof))
+        fe = FE(self.feDim, self.integPnum)
+        integNum, detJ, delta, integW, N, dN = fe.basisTable(self.hVec)
+        self.integNum, self.biDof = integNum, biDof
+        self.nt, self.nT = self.nt0, self.nt0 * integNum
+        self.delta, self.integW, self.detJ = delta, integW, detJ
+        self.N = N
+        self.dNx = dN[:, 0:self.dim]
+        self.dNt = dN[:, self.dim] if self.timeDependent else np.zeros(integNum)
+
+    def rows(self, nt=None):
+        """Tiled [nT,1], [nT,dim], [nT,1] forms of N, dNx, dNt (what the reference stores)."""
+        nt = self.nt if nt is None else nt
+        return (np.tile(self.N.reshape(-1, 1), (nt, 1)), np.tile(self.dNx, (nt, 1)),
+                np.tile(self.dNt.reshape(-1, 1), (nt, 1)))
+
+
+# ======================================================================================
+class TrainResult:
+    """Text log + loss / residual / error histories (lean restatement of
+    /root/reference/VarNetUtility.py:1149-1631; plots are out of scope)."""
+
+    def __init__(self, folderpath, cExFlg=False, verbose=True, saveFreq=100):
+        self.folderpath = folderpath
+        self.cExFlg, self.verbose, self.saveFreq = cExFlg, verbose, saveFreq
+        self.loss, self.minLoss, self.lossComp = [], [], []
+        self.residual, self.error, self.inpIter = [], [], []
+        self.epochTime = 0.0
+        self.trainWeight = None
+        if folderpath is not None:
+            os.makedirs(folderpath, exist_ok=True)
+
+    def writeCase(self, string, mode='a'):
+        if self.folderpath is None:
+            return
+        with open(os.path.join(self.folderpath, 'caseData.txt'), mode) as f:
+            f.write(string)
+
+    writeComment = writeCase
+
+    def initializeCase(self, vn, argDict):
+        fd = vn.fixData
+        s = 'VarNet (MI355X engine) case\n'
+        s += 'dim=%d feDim=%d inpDim=%d layerWidth=%s\n' % (vn.dim, fd.feDim, vn.inpDim, vn.layerWidth)
+        s += 'discNum=%s bDiscNum=%s tDiscNum=%s integPnum=%d\n' % (vn.discNum, vn.bDiscNum, vn.tDiscNum, fd.integPnum)
+        s += 'nt=%d nT=%d integNum=%d biDof=%s detJ=%.10e\n' % (fd.nt, fd.nT, fd.integNum, list(fd.biDof), fd.detJ)
+        s += 'train arguments: %s\n\n' % {k: v for k, v in argDict.items() if k not in ('self',)}
+        self.writeCase(s, mode='w')
+
+    def iterOutput(self, epoch, current_loss, min_loss, epoch_time, resVal, err, lossComp, lossVec):
+        self.loss.append(current_loss)
+        self.epochTime = epoch_time
+        if epoch % self.saveFreq != 0:
+            return
+        self.minLoss.append(min_loss)
+        if resVal is not None:
+            self.residual.append(resVal)
+        if err is not None:
+            self.error.append(err)
+        if lossComp is not None:
+            self.lossComp.append(np.reshape(lossComp, -1))
+        s = 'epoch %d: loss %.6e (best %.6e)' % (epoch, current_loss, min_loss)
+        if resVal is not None:
+            s += ' residual %.4e' % resVal
+        if err is not None:
+            s += ' error %.4e' % err
+        s += ' average iteration time: %2.5fs\n' % (epoch_time / epoch)
+        if self.verbose:
+            print(s, end='')
+        self.writeCase(s)
+        self.saveData()
+
+    def saveData(self):
+        if self.folderpath is None:
+            return
+        data = dict(loss=self.loss, minLoss=self.minLoss, lossComp=self.lossComp, residual=self.residual,
+                    error=self.error, inpIter=self.inpIter, trainWeight=self.trainWeight)
+        with open(os.path.join(self.folderpath, 'trainData.vn'), 'wb') as f:
+            pickle.dump(data, f)
+
+    def loadData(self):
+        with open(os.path.join(self.folderpath, 'trainData.vn'), 'rb') as f:
+            data = pickle.load(f)
+        for k, v in data.items():
+            setattr(self, k, v)
+
+
+# ======================================================================================
+class ManageTrainData:
+    """
+    Device-resident training set, sharded and batched the way the reference's feed dicts are
+    (/root/reference/VarNetUtility.py:563-1017): whole test functions only, mini-batch x tower
+    blocks of `batchLen = ceil(nt/batchNum/puNum)` consecutive test functions, BC/IC set
+    replicated with its weights divided by batchNum*puNum.
+    """
+
+    def __init__(self, vn, mor_data, batchNum=None, batchLen=None):
+        if batchNum is not None and batchLen is not None:
+            raise ValueError('Only one of batch number or length properties must be provided!')
+        self.vn = vn
+        self.mor = mor_data                      # list (per MOR batch) of dicts of device tensors
+        fd = vn.fixData
+        self.nt, self.integNum = fd.nt, fd.integNum
+        puNum = vn.world
+        if batchNum is None and batchLen is None:
+            batchNum = 1
+        if batchNum is None:
+            batchLen = min(int(batchLen), self.nt)
+            batchNum = int(np.ceil(self.nt / batchLen / puNum))
+        else:
+            batchNum = int(batchNum)
+            batchLen = int(np.ceil(self.nt / batchNum / puNum))
+        self.batchNum, self.batchLen, self.puNum = batchNum, batchLen, puNum
+        self.batchInd = np.arange(self.nt)
+        self.shuffled = False
+        self._register()
+
+    def block(self, bi):
+        """[n0,n1) test-function range of this rank's tower in mini-batch bi."""
+        j = bi * self.puNum + self.vn.rank
+        n0 = min(j * self.batchLen, self.nt)
+        return n0, min(n0 + self.batchLen, self.nt)
+
+    def engine_batch(self, mor_b, bi):
+        return mor_b * self.batchNum + bi
+
+    def _register(self):
+        eng, q = self.vn.engine, self.integNum
+        torch = eng.torch
+        fd = self.vn.fixData
+        self._held = {}
+        for mb, d in enumerate(self.mor):
+            for bi in range(self.batchNum):
+                n0, n1 = self.block(bi)
+                if self.shuffled:
+                    tf = torch.as_tensor(self.batchInd[n0:n1], device=eng.device, dtype=torch.long)
+                    rows = (tf[:, None] * q + torch.arange(q, device=eng.device)[None, :]).reshape(-1)
+                    Inp = d['Input'].index_select(0, rows)
+                    gc = d['gcoef'].index_select(0, rows)
+                    src = None if d['source'] is None else d['source'].index_select(0, rows)
+                else:
+                    Inp = d['Input'][n0 * q:n1 * q]
+                    gc = d['gcoef'][n0 * q:n1 * q]
+                    src = None if d['source'] is None else d['source'][n0 * q:n1 * q]
+                eng.set_interior(self.engine_batch(mb, bi), Inp, gc, src, n_k=n1 - n0, detJ=fd.detJ)
+
+    def shuffleTrainData(self):
+        """Permute the test-function order (VarNetUtility.py:957-1017); every rank draws the
+        same permutation (seeded generator shared at construction)."""
+        self.vn._rng.shuffle(self.batchInd)
+        self.shuffled = True
+        self._register()
+
+    def select_mor(self, mb):
+        d = self.mor[mb]
+        fd = self.vn.fixData
+        self.vn.engine.set_bic(d['biInput'], d['biLabel'], fd.bDofsum, fd.biDimVal)
+
+
+# ======================================================================================
+class VarNet:
+    def __init__(self, PDE, layerWidth=[20], modelId='MLP', activationFun=None, discNum=20,
+                 bDiscNum=[], tDiscNum=[], MORdiscScheme=None, processors=None, controller=None,
+                 integPnum=2, optimizer='adam', learning_rate=0.001):
+        dim = PDE.dim
+        timeDependent = PDE.timeDependent
+        MORvar = PDE.MORvar
+        # argument checks: /root/reference/VarNet.py:147-171
+        if size(discNum) != 1 and size(discNum) != dim:
+            raise ValueError('dimension of the number of discretizations does not match dimension of the domain!')
+        elif size(discNum) == 1:
+            discNum = [int(np.reshape(discNum, -1)[0])] * dim
+        if size(bDiscNum) != 1:
+            raise ValueError('density of boundary discretizations must be a scalar!')
+        if modelId == 'RNN':
+            raise NotImplementedError('modelId=\'RNN\' is unfinished in the reference (TFModel.py:225,763) '
+                                      'and out of scope here')
+        if modelId != 'MLP':
+            raise ValueError('unknown modelId!')
+        if timeDependent and uf.isempty(tDiscNum):
+            raise ValueError('time discretization number must be provided for time-dependent PDEs!')
+        if activationFun is None:
+            activationFun = 'sigmoid'
+        if not isinstance(layerWidth, list):
+            raise ValueError('layer widths should be given in a list!')
+        if MORvar is not None and MORdiscScheme is None:
+            raise ValueError('\'MORdiscScheme\' must be given for MOR!')
+        if learning_rate < 0.0:
+            raise ValueError('learning rate must be positive!')
+        if optimizer.lower() == 'rms':
+            optimizer = 'rmsprop'
+        if optimizer.lower() not in ('adam', 'rmsprop'):
+            raise ValueError('unknown optimizer requested!')
+        if optimizer.lower() == 'rmsprop':
+            raise NotImplementedError('RMSProp is not implemented (Adam is what the operators use)')
+
+        inpDim = dim + (1 if timeDependent else 0)
+        if MORvar is not None:
+            inpDim += int(np.sum(MORvar.varNum))
+        lossOpt = {'integWflag': integPnum != 2}
+        lossOpt['isSource'] = not (hasattr(PDE, 'source') and PDE.source == 0.0)   # VarNet.py:184
+
+        self.dim, self.discNum, self.bDiscNum, self.tDiscNum = dim, discNum, bDiscNum, tDiscNum
+        self.MORdiscScheme = MORdiscScheme
+        self.modelId, self.PDE = modelId, PDE
+        self.layerWidth, self.inpDim, self.lossOpt = list(layerWidth), inpDim, lossOpt
+        self.activationFun, self.optimizer, self.learning_rate = activationFun, optimizer, learning_rate
+        self.processors, self.controller = processors, controller
+
+        self.fixData = FIXData(self, integPnum)
+        self.fixData.setInputData(self)
+        self.fixData.setFEdata()
+
+        # distributed context: one process per GPU; world_size plays the reference's puNum
+        self.rank, self.world, self.dist = 0, 1, None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+        except ImportError:
+            pass
+        self._rng = np.random.default_rng(12345)
+        self.engine = self._make_engine(processors)
+        self.engine.init_params(seed=0)
+        fd = self.fixData
+        self.engine.set_fe_table(fd.N, fd.dNt, None if fd.integW is None else fd.integW)
+        self.tfData = self.engine       # name kept for scripts that poke at `VarNet.tfData`
+
+    # -- engine ----------------------------------------------------------------------------
+    def _make_engine(self, processors):
+        from .engine import VNEngine
+        device = 0
+        if isinstance(processors, (list, tuple)):
+            if len(processors) > 1:
+                raise ValueError('one process drives one GPU: launch one rank per GPU with torchrun')
+            processors = processors[0]
+        if isinstance(processors, str):
+            kind, _, idx = processors.partition(':')
+            if kind.upper() != 'GPU':
+                raise ValueError('requested processor %s is unavailable!' % processors)
+            device = int(idx or 0)
+        elif 'LOCAL_RANK' in os.environ:
+            device = int(os.environ['LOCAL_RANK'])
+        fd = self.fixData
+        return VNEngine(self.dim, self.inpDim, self.layerWidth, self.PDE.timeDependent, fd.integNum,
+                        isSource=self.lossOpt['isSource'], integWflag=self.lossOpt['integWflag'],
+                        learning_rate=self.learning_rate, device=device, activationFun=self.activationFun,
+                        optimizer_name=self.optimizer)
+
+    # -- discretisation ----------------------------------------------------------------------
+    def timeDisc(self, tdof=None, rfrac=0, sortflg=True, discTol=None):
+        """t nodes linspace(t0+ht, T, tdof), ht=(T-t0)/tdof (VarNet.py:297-338)."""
+        PDE = self.PDE
+        if not PDE.timeDependent:
+            raise Exception('The problem is time-independent!')
+        rfrac = min(max(rfrac, 0), 1)
+        if tdof is None:
+            tdof = self.tDiscNum
+        tlim = PDE.tInterval
+        ht = (tlim[1] - tlim[0]) / tdof
+        tol = ht if discTol is None else float(np.reshape(discTol, -1)[0])
+        dof1 = math.floor(tdof * rfrac)
+        t1 = np.random.uniform(tlim[0] + tol, tlim[1], dof1)
+        t2 = np.linspace(tlim[0] + tol, tlim[1], tdof - dof1)
+        t = np.hstack([t1, t2]) if dof1 else t2
+        if rfrac > 0 and sortflg:
+            t = np.sort(t)
+        return ht, np.reshape(t, [tdof, 1])
+
+    def trainingPoints(self, smpScheme='uniform', frac=0.5, addTrainPts=True, suppFactor=1.0):
+        """
+        Quadrature-point coordinates of every test function (VarNet.py:504-600):
+        Input[k*integNum+p, d] = x_k[d] + he[d]*delta[d,p],  Input[., dim] = t_k + ht*delta[-1,p];
+        test functions ordered space-major, time-minor.
+        """
+        if smpScheme == 'optimal':
+            raise NotImplementedError('smpScheme=\'optimal\' (residual-driven resampling) is a later-round item')
+        rfrac = frac if smpScheme == 'random' else 0.
+        dim, PDE, fd = self.dim, self.PDE, self.fixData
+        domain = PDE.domain
+        dof, nt, nT, delta = fd.dof, fd.nt, fd.nT, fd.delta
+        if PDE.timeDependent:
+            tDiscNum = self.tDiscNum
+            ht, t_coord = self.timeDisc(rfrac=rfrac)
+        else:
+            tDiscNum, t_coord = 1, []
+        mesh = domain.getMesh(self.discNum, self.bDiscNum, rfrac=rfrac)
+        if smpScheme == 'random' and mesh.dof < dof:
+            coord = mesh.coordinates
+            while coord.shape[0] < dof:
+                coord = uf.vstack([coord, domain.getMesh(self.discNum, self.bDiscNum, rfrac=1.).coordinates])
+            mesh.dof, mesh.coordinates = dof, coord[:dof, :]
+        he = np.reshape(mesh.he, -1)
+        coord = mesh.coordinates
+        Coord = np.empty([nT, dim])
+        for d in range(dim):
+            c = np.repeat(coord[:, d], tDiscNum).reshape(nt, 1) + he[d] * delta[d, :]
+            Coord[:, d] = c.reshape(nT)
+        if PDE.timeDependent:
+            tC = np.tile(t_coord, [dof, 1]) + ht * delta[-1, :]
+            Input = np.concatenate([Coord, tC.reshape(nT, 1)], axis=1)
+        else:
+            Input = Coord
+        biInput, biDof = self.biTrainPoints(mesh, t_coord)
+        return Input, [], biInput, biDof
+
+    def biTrainPoints(self, mesh, t_coord):
+        """Dirichlet-edge x time points, then IC points [x,0] (VarNet.py:604-645)."""
+        PDE = self.PDE
+        bInput, biDof = [], []
+        for bInd in range(PDE.domain.bIndNum):
+            if PDE.BCtype[bInd] == 'Dirichlet':
+                b = uf.pairMats(mesh.bCoordinates[bInd], t_coord)
+                biDof.append(len(b))
+                bInput.append(b)
+        bInput = uf.vstack(bInput)
+        iInput = []
+        if PDE.timeDependent:
+            iInput = np.concatenate([mesh.coordinates, np.zeros([mesh.dof, 1])], axis=1)
+            biDof.append(mesh.dof)
+        return uf.vstack([bInput, iInput]), biDof
+
+    def biTrainData(self, biInput, biDof, biArg=[]):
+        """Labels g/beta on Dirichlet edges, IC(x) on the initial slice (VarNet.py:649-722)."""
+        dim, PDE = self.dim, self.PDE
+        td = PDE.timeDependent
+        nb = PDE.domain.bIndNum
+        if uf.isempty(biArg):
+            biArg = [{} for _ in range(nb)] + ([{}] if td else [])
+        labels, indp, j = [], 0, 0
+        ind = 0
+        for bInd in range(nb):
+            if PDE.BCtype[bInd] != 'Dirichlet':
+                continue
+            ind = indp + biDof[j]
+            j += 1
+            beta, g = PDE.BCs[bInd][1], PDE.BCs[bInd][2]
+            targ = [biInput[indp:ind, dim][np.newaxis].T] if td else []
+            arg = biArg[bInd] if biArg[bInd] is not None else {}
+            labels.append(g(biInput[indp:ind, :dim], *targ, **arg) / beta)
+            indp = ind
+        out = uf.vstack(labels)
+        if td:
+            arg = biArg[-1] if biArg[-1] is not None else {}
+            out = uf.vstack([out, PDE.IC(biInput[ind:, :dim], **arg)])
+        return out
+
+    def PDEinpData(self, Input, inpArg=[]):
+        """kappa, v, s at the rows of Input (VarNet.py:726-774)."""
+        dim, PDE = self.dim, self.PDE
+        if uf.isempty(inpArg):
+            diffArg, velArg, sourceArg = {}, {}, {}
+        else:
+            diffArg, velArg, sourceArg = [a if a is not None else {} for a in inpArg]
+        targ = [Input[:, dim][np.newaxis].T] if PDE.timeDependent else []
+        X = Input[:, 0:dim]
+        return (PDE.diffFun(X, *targ, **diffArg), PDE.velFun(X, *targ, **velArg),
+                PDE.sourceFun(X, *targ, **sourceArg))
+
+    def MORargExtract(self, batch, MORdiscArg):
+        """Keyword arguments of every parametric callable for MOR batch `batch`, and the extra
+        network inputs, in the reference's order (VarNet.py:901-1049): BC functions, IC, diff,
+        vel, source."""
+        PDE = self.PDE
+        fi = PDE.MORfunInd
+        names = PDE.MORvar.ArgNames
+        argInd = self.fixData.MORargInd
+        nb = PDE.domain.bIndNum
+        inpNN = []
+
+        def kw(find):
+            vals = MORdiscArg[find][int(argInd[batch, find]), :]
+            inpNN.extend(vals)
+            return uf.buildDict(names[find], vals)
+
+        biArg = [{} for _ in range(nb)] + ([{}] if PDE.timeDependent else [])
+        if fi['biData']:
+            for bInd in range(nb):
+                if PDE.BCtype[bInd] == 'Dirichlet' and fi['BCs'][bInd] is not None:
+                    biArg[bInd] = kw(fi['BCs'][bInd])
+            if fi['IC'] is not None:
+                biArg[-1] = kw(fi['IC'])
+        inpArg = [{}, {}, {}]
+        if fi['inpData']:
+            for j, key in enumerate(('diff', 'vel', 'source')):
+                if fi[key] is not None:
+                    inpArg[j] = kw(fi[key])
+        return biArg, inpArg, np.reshape(np.asarray(inpNN, dtype=float), [1, len(inpNN)])
+
+    # -- device-resident data -----------------------------------------------------------------
+    def _assemble(self, Input, biInput, biDof, batch, MORdiscArg):
+        """Host fp64 assembly of one MOR batch -> dict of device tensors (VarNet.py:778-857)."""
+        fd, eng = self.fixData, self.engine
+        if MORdiscArg is None:
+            biArg, inpArg, MORinp = [], [], None
+        else:
+            biArg, inpArg, MORinp = self.MORargExtract(batch, MORdiscArg)
+        biLabel = self.biTrainData(biInput, biDof, biArg)
+        diff, vel, src = self.PDEinpData(Input, inpArg)
+        nt, q, dim = fd.nt, fd.integNum, self.dim
+        # gcoef = kappa*dNx + v*N  (VarNet.py:837) with the period tables broadcast over test functions
+        gcoef = (diff.reshape(nt, q, 1) * fd.dNx[None, :, :] +
+                 vel.reshape(nt, q, dim) * fd.N[None, :, None]).reshape(nt * q, dim)
+        if MORinp is not None:
+            Input = np.hstack([Input, np.tile(MORinp, [Input.shape[0], 1])])
+            biInput = np.hstack([biInput, np.tile(MORinp, [biInput.shape[0], 1])])
+        return dict(Input=eng.dev(Input), gcoef=eng.dev(gcoef),
+                    source=eng.dev(src.reshape(-1)) if self.lossOpt['isSource'] else None,
+                    biInput=eng.dev(biInput), biLabel=eng.dev(biLabel.reshape(-1)))
+
+    def _build_tdata(self, batchNum=None, batchLen=None, smpScheme='uniform', frac=0.5):
+        fd = self.fixData
+        Input, _, biInput, biDof = self.trainingPoints(smpScheme, frac)
+        MORdiscArg = fd.MORdiscArg
+        mor = [self._assemble(Input, biInput, biDof, b, MORdiscArg) for b in range(fd.MORbatchNum)]
+        return ManageTrainData(self, mor, batchNum, batchLen)
+
+    # -- loss components / weights ----------------------------------------------------------------
+    def _allreduce(self, t):
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def splitLoss(self, tData, W=None):
+        """BC, IC and variational loss summed over MOR batches (VarNet.py:1053-1090)."""
+        if W is None:
+            W = np.eye(3)
+        eng, fd = self.engine, self.fixData
+        torch = eng.torch
+        comp = np.zeros([3, 1])
+        lossVec = [] if fd.lossVecflag else None
+        for mb in range(fd.MORbatchNum):
+            tData.select_mor(mb)
+            var = 0.0
+            lv_b = []
+            for bi in range(tData.batchNum):
+                out, lv = eng.eval_loss(tData.engine_batch(mb, bi), lossVec=fd.lossVecflag and self.world == 1)
+                bc, ic = out[1], out[2]
+                var += out[3]
+                if lv is not None:
+                    lv_b.append(lv.cpu().numpy().reshape(-1, 1))
+            if self.world > 1:
+                t = torch.tensor([var], dtype=torch.float64, device=eng.device)
+                self._allreduce(t)
+                var = float(t.item())
+            comp += np.array([[bc, ic, var]]).T
+            if lossVec is not None and lv_b:
+                lossVec.append(np.vstack(lv_b))
+        return np.matmul(W, comp), tData, lossVec
+
+    def trainWeight(self, weight, tData, normalizeW=False, useOriginalW=False, lossTot=1.e6):
+        """Initial penalty weights (VarNet.py:1094-1146): default branch scales `weight` so the
+        weighted initial loss is 1e6."""
+        td = self.PDE.timeDependent
+        lossVal, tData, _ = self.splitLoss(tData)
+        lossVal = np.reshape(lossVal, 3)
+        lossTmp = lossVal if td else np.array([lossVal[0], lossVal[2]])
+        if useOriginalW:
+            trainW = np.array(weight, dtype=float)
+        elif normalizeW:
+            nw = len(weight)
+            W = np.tile(weight, [nw, 1]) / np.reshape(weight, [nw, 1])
+            W = np.sum(W, axis=1, keepdims=True) * np.reshape(lossTmp, [nw, 1])
+            trainW = np.reshape(lossTot / W, nw)
+        else:
+            trainW = lossTot / np.sum(np.array(weight) * np.array(lossTmp)) * np.array(weight, dtype=float)
+        if not td:
+            trainW = np.array([trainW[0], 0., trainW[1]])
+        s = 'Training weight information:\n'
+        s += '\tboundary condition loss value: %.4e\n\tinitial condition loss value: %.4e\n' % (lossVal[0], lossVal[1])
+        s += '\tintegral loss value: %.4e\n\trequested weight on each term: %s\n' % (lossVal[2], str(weight))
+        s += '\tcorresponding training weights: %s\n\n' % np.array2string(np.array(trainW), precision=4)
+        if self.trainRes.verbose and self.rank == 0:
+            print(s)
+        self.trainRes.writeCase(s)
+        return np.array(trainW, dtype=float), tData, lossVal
+
+    # -- training -------------------------------------------------------------------------------------
+    def optimIter(self, tData, mb, loss_acc):
+        """One pass over the mini-batches of MOR batch mb (VarNetUtility.py:1021-1047):
+        gradient, tower SUM (all-reduce), TF-1 Adam; the pre-update loss is added to the
+        device scalar `loss_acc`."""
+        eng = self.engine
+        P = eng.P
+        gb = eng.bind_grad_buffer()
+        for bi in range(tData.batchNum):
+            eng.grad(tData.engine_batch(mb, bi))
+            self._allreduce(gb)
+            eng.apply()
+            loss_acc += gb[P]
+
+    def train(self, folderpath, weight=None, smpScheme='uniform', epochNum=500000, tol=1.e-1,
+              verbose=True, saveFreq=100, pltReplace=True, saveMORdata=False, frac=None,
+              addTrainPts=True, suppFactor=1.0, multiTrainUpd=False, trainUpdelay=2e4, tolUpd=0.01,
+              reinitrain=True, updateWeights=False, normalizeW=False, adjustWeight=False,
+              useOriginalW=False, batchNum=None, batchLen=None, shuffleData=False, shuffleFreq=1):
+        """Training loop of /root/reference/VarNet.py:1197-1421 (uniform / random sampling)."""
+        if uf.isnone(folderpath) or uf.isempty(folderpath):
+            raise ValueError('a folder path must be provided to backup the trained model!')
+        self.folderpath = folderpath
+        td = self.PDE.timeDependent
+        if weight is None:
+            weight = [1., 1., 1.] if td else [1., 1.]
+        elif td and len(weight) != 3:
+            raise ValueError('weight dimension does not match!')
+        elif not td and len(weight) != 2:
+            raise ValueError('weight dimension does not match!')
+        if smpScheme not in ('uniform', 'random', 'optimal'):
+            raise ValueError('sampling scheme is not valid!')
+        if smpScheme == 'optimal':
+            raise NotImplementedError('smpScheme=\'optimal\' is a later-round item')
+        if updateWeights:
+            raise NotImplementedError('updateWeights=True is broken in the reference (VarNet.py:1373)')
+        self.smpScheme = smpScheme
+        if frac is None:
+            frac = 0.50 if addTrainPts else 0.25
+        if batchNum is None and batchLen is None and shuffleData:
+            warnings.warn('shuffling data is possible for batch-optimization, setting \'shuffleData\' to False!')
+            shuffleData = False
+        argDict = {k: v for k, v in locals().items() if k != 'self'}
+
+        eng, fd = self.engine, self.fixData
+        torch = eng.torch
+        tData = self._build_tdata(batchNum, batchLen)
+        trainRes = TrainResult(folderpath if self.rank == 0 else None, fd.cEx is not None, verbose, saveFreq)
+        trainRes.initializeCase(self, argDict)
+        self.trainRes = trainRes
+
+        eng.set_weights([1.0, 1.0, 1.0])
+        trainW, tData, lossVal = self.trainWeight(weight, tData, normalizeW, useOriginalW)
+        trainRes.trainWeight = trainW.copy()
+        w_eff = trainW.copy()
+        w_eff[:-1] = w_eff[:-1] / tData.batchNum / tData.puNum        # VarNetUtility.py:900-901
+        eng.set_weights(w_eff)
+        trainRes.lossComp.append(lossVal)
+        self.tData = tData
+
+        min_loss = float('inf')
+        epoch_time = 0.0
+        resVal = err = lossComp = lossVec = None
+        loss_acc = torch.zeros((), dtype=torch.float32, device=eng.device)
+        for epoch in range(1, epochNum + 1):
+            t0 = time.perf_counter()
+            loss_acc.zero_()
+            for mb in range(fd.MORbatchNum):
+                tData.select_mor(mb)
+                self.optimIter(tData, mb, loss_acc)
+            current_loss = float(loss_acc.item())                   # one host sync per epoch
+            epoch_time += time.perf_counter() - t0
+
+            if shuffleData and epoch % shuffleFreq == 0:
+                tData.shuffleTrainData()
+
+            if epoch % saveFreq == 0:
+                if min_loss > current_loss:
+                    min_loss = current_loss
+                    self.saveModel(epoch)
+                resVal, _, err, _ = self.residual()
+                eng.set_weights([1.0, 1.0, 1.0])
+                lossComp, _, lossVec = self.splitLoss(tData)
+                eng.set_weights(w_eff)
+            trainRes.iterOutput(epoch, current_loss, min_loss, epoch_time, resVal, err, lossComp, lossVec)
+
+            if current_loss < tol:
+                trainRes.writeCase('Training completed!')
+                if verbose and self.rank == 0:
+                    print('Training completed!')
+                break
+        return trainRes
+
+    # -- checkpoints ----------------------------------------------------------------------------------
+    def saveModel(self, epoch):
+        """`saver.save(sess, 'best_model', global_step=epoch)` with max_to_keep=2
+        (TFModel.py:307, VarNet.py:1359-1362) -> best_model-<epoch>.npz."""
+        if self.rank != 0:
+            return
+        path = os.path.join(self.folderpath, 'best_model-%d.npz' % epoch)
+        np.savez(path, state=self.engine.export_state(), layerWidth=np.array(self.layerWidth),
+                 inpDim=self.inpDim, epoch=epoch)
+        kept = getattr(self, '_ckpts', [])
+        kept.append(path)
+        while len(kept) > 2:
+            old = kept.pop(0)
+            if os.path.exists(old):
+                os.remove(old)
+        self._ckpts = kept
+
+    def loadModel(self, iterNum=None, folderpath=None):
+        """Restore the newest (or requested) best_model checkpoint (VarNet.py:1426-1506)."""
+        if folderpath is None:
+            if not hasattr(self, 'folderpath'):
+                raise ValueError('\'folderpath\' must be provided!')
+            folderpath = self.folderpath
+        else:
+            self.folderpath = folderpath
+            self.trainRes = TrainResult(folderpath)
+            if os.path.exists(os.path.join(folderpath, 'trainData.vn')):
+                self.trainRes.loadData()
+        if iterNum is None:
+            nums = []
+            for f in os.listdir(folderpath):
+                if f.startswith('best_model-') and f.endswith('.npz'):
+                    nums.append(int(f[len('best_model-'):-4]))
+            nums.sort(reverse=True)
+        else:
+            nums = [iterNum]
+        for n in nums:
+            path = os.path.join(folderpath, 'best_model-%d.npz' % n)
+            if os.path.isfile(path):
+                z = np.load(path)
+                if list(z['layerWidth']) != self.layerWidth or int(z['inpDim']) != self.inpDim:
+                    raise ValueError('checkpoint does not match the network architecture!')
+                self.engine.import_state(z['state'])
+                return n
+        raise ValueError('no restorable checkpoint data found!')
+
+    def saveNNparam(self, path=None):
+        """Export the trained kernels / biases (VarNet.py:2179-2260) as an .npz of per-layer arrays."""
+        flat = self.engine.get_params()
+        out, off, fan = {}, 0, self.inpDim
+        for l, h in enumerate(self.layerWidth + [1]):
+            out['W%d' % l] = flat[off:off + fan * h].reshape(fan, h)
+            off += fan * h
+            out['b%d' % l] = flat[off:off + h]
+            off += h
+            fan = h
+        if path is not None:
+            np.savez(path, **out)
+        return out
+
+    # -- evaluation -------------------------------------------------------------------------------------
+    def _mor_columns(self, batch, n):
+        fd = self.fixData
+        if self.PDE.MORvar is None:
+            return None, [], []
+        biArg, inpArg, MORinp = self.MORargExtract(batch, fd.MORdiscArg)
+        return np.tile(MORinp, [n, 1]), biArg, inpArg
+
+    def evaluate(self, x=None, t=None, batch=None, MORarg=None):
+        """NN approximation of the PDE solution at (x,t[,mu]) (VarNet.py:1510-1595) -> [n,1]."""
+        dim, PDE, fd = self.dim, self.PDE, self.fixData
+        td = PDE.timeDependent
+        MORvar = PDE.MORvar
+        if x is None:
+            if (td and t is None) or not td:
+                Input = fd.uniform_input
+                dof = Input.shape[0]
+            else:
+                dof = fd.dof
+                x = fd.uniform_input[:dof, :dim]                     # as the reference (VarNet.py:1545)
+        elif shape(x)[1] != dim:
+            raise ValueError('spatial coordinates dimension does not match domain!')
+        else:
+            dof = shape(x)[0]
+        if td and t is not None and not (size(t) == 1 or shape(t)[0] == dof):
+            raise ValueError('temporal discretrization does not match spatial discretization!')
+        if td and t is not None and size(t) == 1:
+            t = float(np.reshape(t, -1)[0]) * np.ones([dof, 1])
+        if MORvar is not None and batch is None and MORarg is None:
+            raise ValueError('batch number or argument values must be given for MOR!')
+        if MORvar is not None and batch is None and shape(MORarg)[1] != self.inpDim - fd.feDim:
+            raise ValueError('MOR argument dimension does not match the NN input size!')
+        if MORvar is not None and batch is not None and batch > fd.MORbatchNum - 1:
+            raise ValueError('requested batch number is higher than total available batches!')
+        if x is not None:
+            Input = np.concatenate([x, t], axis=1) if (td and t is not None) else x
+        if MORvar is not None:
+            if batch is None:
+                MORarg = np.asarray(MORarg, dtype=float)
+                if MORarg.shape[0] == 1:
+                    MORarg = np.tile(MORarg, [dof, 1])
+                Input = np.hstack([Input, MORarg])
+            else:
+                cols, _, _ = self._mor_columns(batch, Input.shape[0])
+                Input = np.hstack([Input, cols])
+        return self.engine.forward(Input).cpu().numpy().astype(np.float64).reshape(-1, 1)
+
+    def residual(self, Input=None, tDiscIND=None, batch=None, fp64=False):
+        """
+        Strong PDE residual norm on `uniform_input` (or `Input`) and, when an exact solution is
+        known, the normalised l2 error (VarNet.py:1599-1692):
+            res = sqrt(sum(resVec^2) * prod(hVec)), err = l2Err(cEx, cApp), averaged over MOR batches.
+        Returns (res, resVec, err, cApp).
+        """
+        dim, PDE, fd = self.dim, self.PDE, self.fixData
+        td = PDE.timeDependent
+        elemSize = np.prod(fd.hVec)
+        nb = fd.MORbatchNum
+        if batch is not None:
+            if batch > nb - 1:
+                raise ValueError('requested batch number is higher than total available batches!')
+            batchRange, nb = range(batch, batch + 1), 1
+        else:
+            batchRange = range(nb)
+        noInput = Input is None
+        cEx = None
+        if noInput:
+            Input, cEx = fd.uniform_input, fd.cEx
+        elif PDE.cEx is not None:
+            cEx = PDE.cEx(Input[:, :dim], Input[:, dim:dim + 1]) if td else PDE.cEx(Input[:, :dim])
+        targ = [Input[:, dim:dim + 1]] if td else []
+        diff_dx = fd.d_diff if noInput else PDE.d_diffFun(Input[:, :dim], *targ)
+        res, err = 0., (0. if PDE.cEx is not None else None)
+        resVec = cApp = None
+        for b in batchRange:
+            if PDE.MORvar is None:
+                if noInput and fd.uniform_inpData[0] is not None:
+                    diff, vel, src = fd.uniform_inpData
+                else:
+                    diff, vel, src = self.PDEinpData(Input)
+                Inp = Input
+            else:
+                cols, _, inpArg = self._mor_columns(b, Input.shape[0])
+                diff, vel, src = self.PDEinpData(Input, inpArg)
+                Inp = np.hstack([Input, cols])
+            u, r = self.engine.residual(Inp, diff, vel, src, diff_dx, fp64=fp64)
+            cApp = u.cpu().numpy().astype(np.float64).reshape(-1, 1)
+            resVec = r.cpu().numpy().astype(np.float64).reshape(-1, 1)
+            if PDE.cEx is not None:
+                err += uf.l2Err(cEx, cApp)
+            res += np.sqrt(np.sum(resVec ** 2) * elemSize)
+        res = res / nb
+        if PDE.cEx is not None:
+            err = err / nb
+        return res, resVec, err, cApp
