@@ -1,0 +1,67 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/varnet_hip.h declares;
+without a GPU the engine fails loudly instead of falling back (no compute calls here)."""
+import ctypes as C
+import os
+import re
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'varnet_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(vn_[a-z0-9_]+)\s*\(', txt)))
+
+
+def _lib():
+    from varnet_amd import engine
+    if not os.path.exists(engine.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return engine, engine.load_library()
+
+
+def test_header_symbols_exported():
+    engine, lib = _lib()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), 'missing export ' + n
+    assert set(names) == set(engine.ABI_SYMBOLS), set(names) ^ set(engine.ABI_SYMBOLS)
+    assert lib.vn_abi_version() == 1
+
+
+def test_no_silent_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    engine, lib = _lib()
+    cfg = engine.VnConfig()
+    cfg.dim, cfg.d_in, cfg.n_layers, cfg.integ_num = 1, 2, 1, 16
+    cfg.widths[0] = 5
+    h = C.c_void_p()
+    rc = lib.vn_create(C.byref(cfg), C.byref(h))
+    assert rc != 0 and b'no CPU fallback' in lib.vn_last_error()
+    with pytest.raises(Exception):
+        engine.VNEngine(1, 2, [5], True, 16)
+
+
+def test_argument_validation_without_gpu():
+    engine, lib = _lib()
+    cfg = engine.VnConfig()
+    cfg.dim, cfg.d_in, cfg.n_layers, cfg.integ_num = 1, 2, 9, 16     # too many layers
+    h = C.c_void_p()
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) == 1
+    cfg.n_layers = 1
+    cfg.widths[0] = 500                                               # too wide
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) == 1
+    assert lib.vn_create(None, C.byref(h)) == 1
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'varnet_amd')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
