@@ -38,9 +38,9 @@ def synth(seed, d_in, dim, widths, integNum, n_k, nB, bDof, source=False, integW
     return d
 
 
-def make_engine(d_in, dim, widths, integNum, source, integW):
+def make_engine(d_in, dim, widths, integNum, source, integW, kernel=0):
     from varnet_amd.engine import VNEngine
-    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW)
+    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel)
 
 
 def oracle_eval(flat, d, d_in, dim, widths, integNum, n_k, bDof, source, integW, detJvec):
@@ -65,14 +65,18 @@ CASES = [
     (2, 1, [7],                  36,      11,  40, 13,  True,  True,  True),
     (3, 2, [64, 64, 64],         216,     3,   5,  2,   False, True,  False),
     (3, 2, [50, 50, 50, 50, 50], 64,      300, 1000, 600, False, False, False),
+    (2, 1, [50, 50, 50, 50],     16,      801, 450, 400, True,  False, True),     # config-2 shaped
+    (3, 2, [20, 20, 20],         64,      33,  70,  30,  True,  False, False),
+    (3, 2, [32, 17],             32,      50,  10,  4,   False, True,  True),
 ]
 
 
+@pytest.mark.parametrize('kernel', [1, 0], ids=['generic', 'auto'])
 @pytest.mark.parametrize('case', CASES)
-def test_loss_and_grad_parity(case):
+def test_loss_and_grad_parity(case, kernel):
     d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec = case
     d = synth(1, d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec)
-    eng = make_engine(d_in, dim, widths, integNum, source, integW)
+    eng = make_engine(d_in, dim, widths, integNum, source, integW, kernel)
     eng.init_params(seed=3)
     flat = eng.get_params()
     # perturb biases so they are exercised
@@ -125,11 +129,12 @@ def test_forward_and_residual_parity():
     eng.close()
 
 
-def test_adam_trajectory_parity():
+@pytest.mark.parametrize('kernel', [1, 0], ids=['generic', 'auto'])
+def test_adam_trajectory_parity(kernel):
     """200 TF-1 Adam steps from identical init: relative loss deviation <= 1e-2."""
     d_in, dim, widths, integNum, n_k, nB, bDof = 2, 1, [20, 20], 16, 64, 60, 40
     d = synth(2, d_in, dim, widths, integNum, n_k, nB, bDof)
-    eng = make_engine(d_in, dim, widths, integNum, False, False)
+    eng = make_engine(d_in, dim, widths, integNum, False, False, kernel)
     eng.init_params(seed=1)
     flat = eng.get_params()
     eng.set_fe_table(d['N1'], d['dNt1'], None)

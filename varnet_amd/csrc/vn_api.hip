@@ -77,6 +77,8 @@ struct vn_engine {
   long losspart_cap = 0;
 
   int64_t step = 0;
+  bool use_fused = false;
+  float* fused_losspart = nullptr;   // [ncu*3]
 
   // profiling of the dominant kernel
   bool prof_on = false;
@@ -240,6 +242,18 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
     return fail(VN_ENOMEM, "device allocation failed: %s", hipGetErrorString(a));
   }
   h->gradbuf = h->gradbuf_int;
+  if (cfg->kernel == VN_KERNEL_FUSED && !vn_fused_supported(net, cfg->integ_num)) {
+    vn_destroy(h);
+    return fail(VN_EUNSUPPORTED, "fused kernel unsupported for this network / integ_num");
+  }
+  h->use_fused = cfg->kernel != VN_KERNEL_GENERIC && vn_fused_supported(net, cfg->integ_num);
+  if (h->use_fused) {
+    if (hipMalloc((void**)&h->fused_losspart, (size_t)h->ncu * 3 * sizeof(float)) != hipSuccess) {
+      vn_destroy(h);
+      return fail(VN_ENOMEM, "device allocation failed");
+    }
+    h->prof_name = "vn_fused_kernel";
+  }
   h->ev0.resize(PROF_CAP, nullptr);
   h->ev1.resize(PROF_CAP, nullptr);
   *out = h;
@@ -250,7 +264,7 @@ int vn_destroy(vn_engine* h) {
   if (!h) return VN_OK;
   (void)hipSetDevice(h->cfg.device);
   void* ptrs[] = {h->theta, h->m, h->v, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
-                  h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart};
+                  h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
@@ -421,6 +435,29 @@ int vn_grad(vn_engine* h, int32_t batch) {
   if (int rc = check_batch(h, batch)) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   const Batch& b = h->batches[batch];
+  if (h->use_fused && !b.Nrow) {
+    VnFusedArgs a{};
+    a.net = h->net; a.theta = h->theta;
+    a.X = b.Input; a.G = b.gcoef; a.src = h->cfg.has_source ? b.source : nullptr;
+    a.nT = b.n_k * h->cfg.integ_num; a.n_k = b.n_k; a.integ_num = h->cfg.integ_num;
+    a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
+    a.detJv = b.detJv; a.detJ = (float)b.detJ; a.time_dependent = h->cfg.time_dependent;
+    a.lossVec = nullptr;
+    a.Xb = h->biInput; a.label = h->biLabel; a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;
+    a.w0 = (float)h->w[0]; a.w1 = (float)h->w[1]; a.w2 = (float)h->w[2];
+    a.partial = h->partial; a.losspart = h->fused_losspart;
+    const int grid = h->ncu;
+    const bool rec = h->prof_on && h->prof_n < PROF_CAP;
+    if (rec) {
+      if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
+      HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
+    }
+    HIPCHK(vn_fused_launch(a, grid, h->stream));
+    if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
+    HIPCHK(vn_reduce_launch(h->partial, grid, h->net.P, h->fused_losspart, grid, h->bDof, h->nB, a.w0, a.w1, a.w2,
+                            h->gradbuf, h->stream));
+    return VN_OK;
+  }
   if (int rc = run_forward_and_seed(h, b, true, nullptr, nullptr)) return rc;
   const long nT = b.n_k * h->cfg.integ_num;
   VnRows s0{}, s1{};

@@ -1,0 +1,530 @@
+// Fused gfx950 kernel for the VarNet variational-loss training step: forward (value + one
+// directional tangent), weak-form epilogue (R_k, lossVec, seeds) and the complete reverse pass
+// to parameter gradients in ONE persistent launch, for hidden widths <= 2*KS.
+//
+// Design (DESIGN.md "fused kernel"):
+//   * one workgroup (4 waves, 1 wave / SIMD, up to 512 VGPRs) per CU, looping over 128-point
+//     tiles; each wave owns 32 points;
+//   * every layer is D[feature x point] = W^T . A with v_mfma_f32_32x32x2_f32; the accumulator
+//     tile of layer l IS the B operand of layer l+1 (column = lane&31 = point, rows in the
+//     16 registers x 2 lane halves), so activations never leave registers: feature f lives in
+//     k-step ks = f/2, lane half g = f%2, at accumulator row pos(ks,g);
+//   * activations (a_l, zdot_l) of all layers stay in registers for the reverse pass;
+//   * weights sit in LDS once per workgroup as [in-feature][out-position] images (stride 65,
+//     conflict-free for both the forward and the transposed backward fragment reads);
+//   * weight gradients contract over points, which needs the operands transposed: each wave
+//     bounces 32x64 tiles through a private LDS buffer (ds_write_b32 / ds_read_b128) and
+//     accumulates G[in][out] (+ bias row through a constant-one input row) with MFMA, then adds
+//     the tile into the workgroup's LDS gradient image (ds_add_f32), which is the flat parameter
+//     layout; one partial per workgroup goes to HBM at the end.
+//
+// Math: oracle/tangent_ref.py; reference graph TFModel.py:536, 643-668, 709.
+#include "vn_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// vector view of LDS words that are also written as scalars: exempt from type-based alias analysis
+typedef f32x4 f32x4a __attribute__((may_alias));
+
+namespace {
+
+constexpr int NTHREADS = 256;
+constexpr int TILE = 128;     // points per workgroup tile (4 waves x 32)
+constexpr int WS = 65;        // weight image row stride (floats)
+constexpr int TS = 36;        // transposition buffer row stride (floats): 16-B aligned rows
+constexpr int TROWS = 64;
+constexpr int KS0 = 4;        // input layer k-steps (d_in <= 8)
+
+__host__ __device__ constexpr int al4(int x) { return (x + 3) & ~3; }
+// accumulator row of feature (ks, g)
+__host__ __device__ constexpr int vpos(int ks, int g) {
+  return 32 * (ks >> 4) + 8 * ((ks & 15) >> 2) + 4 * g + (ks & 3);
+}
+// k-step owning accumulator row `pos`
+__host__ __device__ constexpr int vks(int pos) {
+  return 16 * (pos >> 5) + 4 * ((pos & 31) >> 3) + (pos & 3);
+}
+__host__ __device__ constexpr int vfeat(int pos) { return 2 * vks(pos) + (((pos & 31) >> 2) & 1); }
+// first accumulator row not used by KS k-steps: carries the constant-one "bias" input
+__host__ __device__ constexpr int vones(int KS) {
+  for (int p = 0; p < 64; ++p)
+    if (vks(p) >= KS) return p;
+  return -1;
+}
+__host__ __device__ constexpr int mtiles(int KS) { return KS > 16 ? 2 : 1; }
+
+template <int L, int KS>
+struct Lay {
+  static constexpr int HP = 2 * KS;
+  static constexpr int HPWS = al4(HP * WS);
+  static constexpr int W1_OFF = 0;                          // [8][WS]
+  static constexpr int WH_OFF = al4(8 * WS);                // [L-1][HP][WS]
+  static constexpr int BI_OFF = WH_OFF + (L - 1) * HPWS;    // [L][64] biases in (mt, g, i) order
+  static constexpr int WO_OFF = BI_OFF + L * 64;            // [2*KS] output weights by feature
+  static constexpr int MISC_OFF = WO_OFF + al4(2 * KS);     // sInt[128] | sR[128]
+  static constexpr int T_OFF = MISC_OFF + 256;              // [4 waves][TROWS][TS]
+  static constexpr int G_OFF = T_OFF + 4 * TROWS * TS;      // [P] gradient image (flat layout)
+};
+
+__device__ __forceinline__ float fsigmoid(float z) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Lanes of one wave exchange data through the wave's private LDS buffer.  The hardware executes a
+// wave's LDS instructions in order, but the compiler reasons per thread: without a fence it may
+// forward or reorder a lane's loads across ANOTHER lane's stores.  Wavefront-scope fences + the
+// wave barrier pin the program order of the LDS traffic (no s_barrier is emitted).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct LaneC {
+  int g, c;
+  int offF[2];     // forward A-fragment lane offset inside a weight image
+  int offB[2];     // backward (transposed) A-fragment lane offset
+  int twr;         // transposition write offset (floats, inside the wave's buffer)
+  int trd[2];      // transposition read offsets per 32-row tile
+  int fcol[2];     // out-feature owned by this lane for column tile nt (or >= 1<<20 if none)
+};
+
+// One weight-gradient contraction for a layer:
+//   G[in pos][out pos] += sum_pts Aside[in][pt] * Bside[out][pt]   (value half, then tangent half)
+// av/azd: A-side registers per k-step (a, zdot) in accumulator layout; RAWA: inputs (tangent = azd
+// as is) instead of a*(1-a)*zd.  bv/bt: B-side registers (zbar, zdbar).
+template <int KSA, int KSB, bool RAWA>
+__device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float (&azd)[KSA],
+                                            const float (&bv)[KSB], const float (&bt)[KSB], float* Tw,
+                                            const LaneC& lc, float* Gl, int Hin, int Hout) {
+  constexpr int ONES = vones(KSA);
+  constexpr int MTA = (mtiles(KSA) > (ONES >> 5) + 1) ? mtiles(KSA) : (ONES >> 5) + 1;
+  constexpr int NTB = mtiles(KSB);
+  f32x16 wacc[MTA][NTB];
+#pragma unroll
+  for (int m = 0; m < MTA; ++m)
+#pragma unroll
+    for (int n = 0; n < NTB; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wacc[m][n][i] = 0.f;
+
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    // ---- A side -> LDS (transposed image: row = feature position, column = point) ----
+#pragma unroll
+    for (int ks = 0; ks < KSA; ++ks) {
+      float v;
+      if (half == 0) v = av[ks];
+      else v = RAWA ? azd[ks] : av[ks] * (1.f - av[ks]) * azd[ks];
+      Tw[lc.twr + vpos(ks, 0) * TS] = v;
+    }
+    if (lc.g == 0) Tw[ONES * TS + lc.c] = (half == 0) ? 1.f : 0.f;
+    wave_lds_sync();
+    float areg[MTA][16];
+#pragma unroll
+    for (int m = 0; m < MTA; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 t = *reinterpret_cast<const f32x4a*>(&Tw[lc.trd[m] + 4 * j]);
+        areg[m][4 * j + 0] = t[0]; areg[m][4 * j + 1] = t[1];
+        areg[m][4 * j + 2] = t[2]; areg[m][4 * j + 3] = t[3];
+      }
+    // ---- B side -> LDS (same buffer; LDS ops of one wave execute in order) ----
+    wave_lds_sync();
+#pragma unroll
+    for (int ks = 0; ks < KSB; ++ks) Tw[lc.twr + vpos(ks, 0) * TS] = (half == 0) ? bv[ks] : bt[ks];
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 b[NTB];
+#pragma unroll
+      for (int n = 0; n < NTB; ++n) b[n] = *reinterpret_cast<const f32x4a*>(&Tw[lc.trd[n] + 4 * j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int m = 0; m < MTA; ++m)
+#pragma unroll
+          for (int n = 0; n < NTB; ++n) wacc[m][n] = mfma32(areg[m][4 * j + e], b[n][e], wacc[m][n]);
+    }
+    wave_lds_sync();
+  }
+  // ---- add the tile into the workgroup's gradient image (flat [Hin+1][Hout] block) ----
+#pragma unroll
+  for (int m = 0; m < MTA; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ks = 16 * m + i;                       // k-step of this accumulator row
+      constexpr int ones_m = ONES >> 5;
+      constexpr int ones_i = 4 * ((ONES & 31) >> 3) + (ONES & 3);
+      constexpr int ones_g = ((ONES & 31) >> 2) & 1;
+      int frow = -1;
+      if (ks < KSA) {
+        const int f = 2 * ks + lc.g;
+        if (f < Hin) frow = f;
+      } else if (m == ones_m && i == ones_i) {
+        if (lc.g == ones_g) frow = Hin;                // bias row
+      } else {
+        continue;
+      }
+#pragma unroll
+      for (int n = 0; n < NTB; ++n) {
+        if (frow >= 0 && lc.fcol[n] < Hout) atomicAdd(&Gl[frow * Hout + lc.fcol[n]], wacc[m][n][i]);
+      }
+    }
+}
+
+struct VnFusedArgsD {
+  VnNet net;
+  const float* theta;
+  const float* X; const float* G; const float* src;
+  long nT, n_k; int integ_num;
+  const float* feN; const float* fedNt; const float* feW;
+  const float* detJv; float detJ; int time_dependent;
+  float* lossVec;
+  const float* Xb; const float* label; long nB, bDof; float biDimVal;
+  float w0, w1, w2;
+  float* partial;
+  float* losspart;
+};
+
+template <int L, int KS>
+__global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
+  using LY = Lay<L, KS>;
+  constexpr int MT = mtiles(KS);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const VnNet& net = A.net;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = net.P;
+  float* W1 = lds + LY::W1_OFF;
+  float* WH = lds + LY::WH_OFF;
+  float* BI = lds + LY::BI_OFF;
+  float* WO = lds + LY::WO_OFF;
+  float* sInt = lds + LY::MISC_OFF;
+  float* sR = sInt + TILE;
+  float* Tw = lds + LY::T_OFF + wave * TROWS * TS;
+  float* Gacc = lds + LY::G_OFF;
+
+  // ------------------------------------------------------------------ prologue: LDS images
+  {
+    const int d_in = net.d_in, H1 = net.H[1];
+    for (int i = tid; i < 8 * WS; i += NTHREADS) {
+      const int k = i / WS, pos = i % WS;
+      const int f = vfeat(pos & 63);
+      W1[i] = (k < d_in && pos < 64 && f < H1) ? A.theta[net.woff[1] + k * H1 + f] : 0.f;
+    }
+#pragma unroll
+    for (int l = 2; l <= L; ++l) {
+      const int Hin = net.H[l - 1], Hout = net.H[l];
+      float* Wl = WH + (l - 2) * LY::HPWS;
+      for (int i = tid; i < LY::HP * WS; i += NTHREADS) {
+        const int k = i / WS, pos = i % WS;
+        const int f = vfeat(pos & 63);
+        Wl[i] = (k < Hin && pos < 64 && f < Hout) ? A.theta[net.woff[l] + k * Hout + f] : 0.f;
+      }
+    }
+    for (int i = tid; i < L * 64; i += NTHREADS) {
+      const int l = i / 64 + 1, idx = i % 64;
+      const int mt = idx >> 5, g = (idx >> 4) & 1, r = idx & 15;
+      const int f = 2 * (16 * mt + r) + g;
+      BI[i] = (16 * mt + r < KS && f < net.H[l]) ? A.theta[net.boff[l] + f] : 0.f;
+    }
+    for (int i = tid; i < 2 * KS; i += NTHREADS) WO[i] = (i < net.H[L]) ? A.theta[net.woff[L + 1] + i] : 0.f;
+    for (int i = tid; i < P; i += NTHREADS) Gacc[i] = 0.f;
+    for (int i = tid; i < 4 * TROWS * TS; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
+  }
+  __syncthreads();
+
+  LaneC lc;
+  lc.g = lane >> 5;
+  lc.c = lane & 31;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    lc.offF[m] = lc.g * WS + 32 * m + lc.c;
+    int fin = vfeat(32 * m + lc.c);
+    if (fin >= LY::HP) fin = 0;
+    lc.offB[m] = fin * WS + 4 * lc.g;
+    lc.trd[m] = (32 * m + lc.c) * TS + 16 * lc.g;
+    const int fo = vfeat(32 * m + lc.c);
+    lc.fcol[m] = (vks(32 * m + lc.c) < KS) ? fo : (1 << 20);
+  }
+  lc.twr = 4 * lc.g * TS + lc.c;
+
+  const float bo = A.theta[net.boff[L + 1]];
+  const int q = A.integ_num;
+  const int TT = TILE / q;                                   // test functions per tile
+  const long ntiles_i = (A.nT + TILE - 1) / TILE;
+  const long ntiles = ntiles_i + (A.nB + TILE - 1) / TILE;
+  float loss_var = 0.f, loss_bc = 0.f, loss_ic = 0.f;
+  const long nI = A.nB - A.bDof;
+  const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
+  const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool interior = tile < ntiles_i;
+    const long r0 = (interior ? tile : tile - ntiles_i) * TILE;
+    const long nrows = interior ? A.nT : A.nB;
+    const int pt = wave * 32 + lc.c;                         // point inside the tile
+    const long row = r0 + pt;
+    const bool valid = row < nrows;
+
+    // ---------------------------------------------------------------- inputs
+    float xin[KS0], gin[KS0];
+    {
+      const float* Xp = interior ? A.X : A.Xb;
+#pragma unroll
+      for (int s = 0; s < KS0; ++s) {
+        const int f = 2 * s + lc.g;
+        xin[s] = (valid && f < net.d_in) ? Xp[row * net.d_in + f] : 0.f;
+        gin[s] = (valid && interior && f < net.dim) ? A.G[row * net.dim + f] : 0.f;
+      }
+    }
+
+    float a[L][KS], zd[L][KS];                               // stored activations (registers)
+
+    // ---------------------------------------------------------------- forward
+    {
+      f32x16 accv[MT], acct[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 b = *reinterpret_cast<const f32x4a*>(&BI[m * 32 + lc.g * 16 + 4 * j]);
+          accv[m][4 * j + 0] = b[0]; accv[m][4 * j + 1] = b[1];
+          accv[m][4 * j + 2] = b[2]; accv[m][4 * j + 3] = b[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acct[m][i] = 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < KS0; ++s) {
+        if (2 * s < net.d_in) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float wf = W1[2 * s * WS + lc.offF[m]];
+            accv[m] = mfma32(wf, xin[s], accv[m]);
+            acct[m] = mfma32(wf, gin[s], acct[m]);
+          }
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a[0][ks] = fsigmoid(accv[ks >> 4][ks & 15]);
+        zd[0][ks] = acct[ks >> 4][ks & 15];
+      }
+    }
+#pragma unroll
+    for (int l = 2; l <= L; ++l) {
+      const float* Wl = WH + (l - 2) * LY::HPWS;
+      f32x16 accv[MT], acct[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 b = *reinterpret_cast<const f32x4a*>(&BI[(l - 1) * 64 + m * 32 + lc.g * 16 + 4 * j]);
+          accv[m][4 * j + 0] = b[0]; accv[m][4 * j + 1] = b[1];
+          accv[m][4 * j + 2] = b[2]; accv[m][4 * j + 3] = b[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acct[m][i] = 0.f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float av = a[l - 2][ks];
+        const float ad = av * (1.f - av) * zd[l - 2][ks];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float wf = Wl[2 * ks * WS + lc.offF[m]];
+          accv[m] = mfma32(wf, av, accv[m]);
+          acct[m] = mfma32(wf, ad, acct[m]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a[l - 1][ks] = fsigmoid(accv[ks >> 4][ks & 15]);
+        zd[l - 1][ks] = acct[ks >> 4][ks & 15];
+      }
+    }
+    // output layer (VALU): u, udot; both lane halves end with the full sums
+    float u = 0.f, ud = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float wv = WO[2 * ks + lc.g];
+      const float av = a[L - 1][ks];
+      u += wv * av;
+      ud += wv * (av * (1.f - av) * zd[L - 1][ks]);
+    }
+    u += __shfl_xor(u, 32, 64);
+    ud += __shfl_xor(ud, 32, 64);
+    u += bo;
+
+    // ---------------------------------------------------------------- weak-form epilogue
+    float ubar = 0.f, udbar = 0.f;
+    if (interior) {
+      const int pq = pt % q;
+      const float dnt = A.time_dependent ? A.fedNt[pq] : 0.f;
+      const float wq = A.feW ? A.feW[pq] : 1.f;
+      float t = ud - dnt * u;                                           // TFModel.py:653-655
+      if (A.src) t -= (valid ? A.src[row] : 0.f) * A.feN[pq];           // :657
+      t *= wq;                                                          // :660
+      if (!valid) t = 0.f;
+      if (lc.g == 0) sInt[pt] = t;
+      __syncthreads();
+      if (tid < TT) {
+        float R = 0.f;
+        for (int p = 0; p < q; ++p) R += sInt[tid * q + p];             // :661
+        const long k = r0 / q + tid;
+        float s = 0.f;
+        if (k < A.n_k) {
+          const float dj = A.detJv ? A.detJv[k] : A.detJ;
+          const float lv = dj * R * R;                                  // detJ once: :571-577, :664-668
+          loss_var += lv;
+          if (A.lossVec) A.lossVec[k] = lv;
+          s = 2.f * A.w2 * dj * R;
+        }
+        sR[tid] = s;
+      }
+      __syncthreads();
+      const float s = sR[pt / q] * wq;
+      udbar = s;
+      ubar = -dnt * s;
+    } else {
+      if (valid) {
+        const float e = u - A.label[row];
+        const bool isbc = row < A.bDof;
+        if (lc.g == 0) {
+          const float e2 = A.biDimVal * e * e;                          // :643
+          if (isbc) loss_bc += e2; else loss_ic += e2;
+        }
+        ubar = (isbc ? cb : ci) * e;
+      }
+    }
+
+    // ---------------------------------------------------------------- backward
+    float zb[KS], zdb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float wv = WO[2 * ks + lc.g];
+      const float av = a[L - 1][ks];
+      const float sp = av * (1.f - av);
+      const float ab = ubar * wv, adb = udbar * wv;
+      zdb[ks] = adb * sp;
+      zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[L - 1][ks];
+    }
+    // output layer gradient: G[f][0] = sum_pt ubar*a_L + udbar*adot_L ; bias = sum ubar
+    {
+      float sv[1], st[1];
+      sv[0] = (lc.g == 0) ? ubar : 0.f;
+      st[0] = (lc.g == 0) ? udbar : 0.f;
+      wgrad_layer<KS, 1, false>(a[L - 1], zd[L - 1], sv, st, Tw, lc, Gacc + net.woff[L + 1], net.H[L], 1);
+    }
+#pragma unroll
+    for (int l = L; l >= 2; --l) {
+      wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, Tw, lc, Gacc + net.woff[l], net.H[l - 1], net.H[l]);
+      // input gradient of layer l: Abar_{l-1}[in pos][pt] = sum_out W_l[in][out] zbar_l[out][pt]
+      const float* Wl = WH + (l - 2) * LY::HPWS;
+      f32x16 accv[MT], acct[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accv[m][i] = 0.f; acct[m][i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float wf = Wl[lc.offB[m] + vpos(ks, 0)];
+          accv[m] = mfma32(wf, zb[ks], accv[m]);
+          acct[m] = mfma32(wf, zdb[ks], acct[m]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float av = a[l - 2][ks];
+        const float sp = av * (1.f - av);
+        const float ab = accv[ks >> 4][ks & 15], adb = acct[ks >> 4][ks & 15];
+        zdb[ks] = adb * sp;
+        zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[l - 2][ks];
+      }
+    }
+    wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, Tw, lc, Gacc + net.woff[1], net.d_in, net.H[1]);
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  __syncthreads();
+  float* out = A.partial + (long)blockIdx.x * P;
+  for (int i = tid; i < P; i += NTHREADS) out[i] = Gacc[i];
+  // loss partials: (var, bc, ic)
+  float v0 = loss_var, v1 = loss_bc, v2 = loss_ic;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v0 += __shfl_down(v0, o, 64);
+    v1 += __shfl_down(v1, o, 64);
+    v2 += __shfl_down(v2, o, 64);
+  }
+  __syncthreads();
+  if (lane == 0) { sInt[wave * 3 + 0] = v0; sInt[wave * 3 + 1] = v1; sInt[wave * 3 + 2] = v2; }
+  __syncthreads();
+  if (tid < 3) A.losspart[blockIdx.x * 3 + tid] = sInt[tid] + sInt[3 + tid] + sInt[6 + tid] + sInt[9 + tid];
+}
+
+template <int L, int KS>
+hipError_t launch_one(const VnFusedArgsD& a, int grid, hipStream_t s) {
+  using LY = Lay<L, KS>;
+  const size_t bytes = (size_t)(LY::G_OFF + a.net.P) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)vn_fused_kernel<L, KS>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((vn_fused_kernel<L, KS>), dim3(grid), dim3(NTHREADS), bytes, s, a);
+  return hipGetLastError();
+}
+
+template <int L, int KS>
+size_t lds_one(int P) {
+  return (size_t)(Lay<L, KS>::G_OFF + P) * sizeof(float);
+}
+
+int pick_ks(int hmax) {
+  if (hmax <= 20) return 10;
+  if (hmax <= 32) return 16;
+  if (hmax <= 50) return 25;
+  return 0;
+}
+
+}  // namespace
+
+#define VN_FUSED_CASES(X) \
+  X(1, 10) X(2, 10) X(3, 10) X(4, 10) \
+  X(2, 16) X(3, 16) X(4, 16)          \
+  X(3, 25) X(4, 25) X(5, 25)
+
+size_t vn_fused_lds_bytes(const VnNet& net) {
+  const int ks = pick_ks(net.hmax);
+#define X(LL, KK) if (net.L == LL && ks == KK) return lds_one<LL, KK>(net.P);
+  VN_FUSED_CASES(X)
+#undef X
+  return 0;
+}
+
+bool vn_fused_supported(const VnNet& net, int integ_num) {
+  if (net.d_in > 2 * KS0) return false;
+  if (integ_num < 1 || integ_num > TILE || (TILE % integ_num) != 0) return false;
+  const size_t b = vn_fused_lds_bytes(net);
+  return b != 0 && b <= 160 * 1024;
+}
+
+hipError_t vn_fused_launch(const VnFusedArgs& h, int grid, hipStream_t s) {
+  VnFusedArgsD a;
+  a.net = h.net; a.theta = h.theta; a.X = h.X; a.G = h.G; a.src = h.src; a.nT = h.nT; a.n_k = h.n_k;
+  a.integ_num = h.integ_num; a.feN = h.feN; a.fedNt = h.fedNt; a.feW = h.feW; a.detJv = h.detJv;
+  a.detJ = h.detJ; a.time_dependent = h.time_dependent; a.lossVec = h.lossVec; a.Xb = h.Xb;
+  a.label = h.label; a.nB = h.nB; a.bDof = h.bDof; a.biDimVal = h.biDimVal; a.w0 = h.w0; a.w1 = h.w1;
+  a.w2 = h.w2; a.partial = h.partial; a.losspart = h.losspart;
+  const int ks = pick_ks(h.net.hmax);
+#define X(LL, KK) if (h.net.L == LL && ks == KK) return launch_one<LL, KK>(a, grid, s);
+  VN_FUSED_CASES(X)
+#undef X
+  return hipErrorInvalidValue;
+}

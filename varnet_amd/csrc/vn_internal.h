@@ -58,6 +58,24 @@ hipError_t vn_reduce_launch(const float* partial, int nparts, int P, const float
 hipError_t vn_adam_launch(float* theta, float* m, float* v, const float* grad, int P, float lr_t,
                           float b1, float b2, float eps, hipStream_t s);
 
+// ---- fused forward+epilogue+backward kernel (vn_fused.hip) --------------------------------
+struct VnFusedArgs {
+  VnNet net;
+  const float* theta;
+  const float* X; const float* G; const float* src;   // interior rows
+  long nT, n_k; int integ_num;
+  const float* feN; const float* fedNt; const float* feW;
+  const float* detJv; float detJ; int time_dependent;
+  float* lossVec;
+  const float* Xb; const float* label; long nB, bDof; float biDimVal;   // BC/IC rows
+  float w0, w1, w2;
+  float* partial;    // [grid, P] per-workgroup gradient partials
+  float* losspart;   // [grid, 3] per-workgroup (var, bc, ic) partial sums
+};
+bool vn_fused_supported(const VnNet& net, int integ_num);
+size_t vn_fused_lds_bytes(const VnNet& net);
+hipError_t vn_fused_launch(const VnFusedArgs& a, int grid, hipStream_t s);
+
 // ---- simple per-point evaluation kernels (float / double): vn_pointwise.hip --------------
 hipError_t vn_pointwise_forward_f32(const VnNet& net, const float* theta, const float* X, long n,
                                     float* u, hipStream_t s);
