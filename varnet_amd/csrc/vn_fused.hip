@@ -63,11 +63,27 @@ struct Lay {
   static constexpr int WO_OFF = BI_OFF + L * 64;            // [2*KS] output weights by feature
   static constexpr int MISC_OFF = WO_OFF + al4(2 * KS);     // sInt[128] | sR[128]
   static constexpr int T_OFF = MISC_OFF + 256;              // [4 waves][TROWS][TS]
-  static constexpr int G_OFF = T_OFF + 4 * TROWS * TS;      // [P] gradient image (flat layout)
+  static constexpr int G_OFF = T_OFF + 4 * TROWS * TS;      // gradient image (padded blocks, below)
+  // gradient image: layer 1 block [2*KS0+1][HP], hidden blocks [HP+1][HP], output block [HP+1][1];
+  // the last row of every block is the bias gradient.  Compile-time strides keep every ds_add
+  // address an immediate offset from two per-lane registers.
+  static constexpr int G1_SZ = (2 * KS0 + 1) * HP;
+  static constexpr int GH_SZ = (HP + 1) * HP;
+  static constexpr int GO_OFF = G1_SZ + (L - 1) * GH_SZ;
+  static constexpr int G_SZ = al4(GO_OFF + HP + 1);
+  static constexpr int TOTAL = G_OFF + G_SZ;
 };
 
 __device__ __forceinline__ float fsigmoid(float z) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+
+// Identity the optimiser cannot see through.  The reverse pass recomputes sigma' = a(1-a) and
+// adot = sigma' * zdot from the stored activations; without this, GVN merges those expressions
+// with their forward-pass twins and keeps ~250 extra values alive across the whole tile (spills).
+__device__ __forceinline__ float opaque(float x) {
+  asm("" : "+v"(x));
+  return x;
 }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -91,16 +107,17 @@ struct LaneC {
   int twr;         // transposition write offset (floats, inside the wave's buffer)
   int trd[2];      // transposition read offsets per 32-row tile
   int fcol[2];     // out-feature owned by this lane for column tile nt (or >= 1<<20 if none)
+  int gbase[2];    // fcol + g*GS for the hidden/first blocks (GS = HP)
 };
 
 // One weight-gradient contraction for a layer:
 //   G[in pos][out pos] += sum_pts Aside[in][pt] * Bside[out][pt]   (value half, then tangent half)
 // av/azd: A-side registers per k-step (a, zdot) in accumulator layout; RAWA: inputs (tangent = azd
 // as is) instead of a*(1-a)*zd.  bv/bt: B-side registers (zbar, zdbar).
-template <int KSA, int KSB, bool RAWA>
+template <int KSA, int KSB, bool RAWA, int GS>
 __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float (&azd)[KSA],
                                             const float (&bv)[KSB], const float (&bt)[KSB], float* Tw,
-                                            const LaneC& lc, float* Gl, int Hin, int Hout) {
+                                            const LaneC& lc, float* Gl) {
   constexpr int ONES = vones(KSA);
   constexpr int MTA = (mtiles(KSA) > (ONES >> 5) + 1) ? mtiles(KSA) : (ONES >> 5) + 1;
   constexpr int NTB = mtiles(KSB);
@@ -119,7 +136,11 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
     for (int ks = 0; ks < KSA; ++ks) {
       float v;
       if (half == 0) v = av[ks];
-      else v = RAWA ? azd[ks] : av[ks] * (1.f - av[ks]) * azd[ks];
+      else if (RAWA) v = azd[ks];
+      else {
+        const float x = opaque(av[ks]);
+        v = x * (1.f - x) * azd[ks];
+      }
       Tw[lc.twr + vpos(ks, 0) * TS] = v;
     }
     if (lc.g == 0) Tw[ONES * TS + lc.c] = (half == 0) ? 1.f : 0.f;
@@ -152,7 +173,9 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
     }
     wave_lds_sync();
   }
-  // ---- add the tile into the workgroup's gradient image (flat [Hin+1][Hout] block) ----
+  // ---- add the tile into the workgroup's gradient image block: [2*KSA+1 rows][GS] ----
+  // row = in-feature 2*ks+g (bias: row 2*KSA), column = this lane's out-feature.  Padded cells
+  // collect harmless values that are never copied out.
 #pragma unroll
   for (int m = 0; m < MTA; ++m)
 #pragma unroll
@@ -161,18 +184,22 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
       constexpr int ones_m = ONES >> 5;
       constexpr int ones_i = 4 * ((ONES & 31) >> 3) + (ONES & 3);
       constexpr int ones_g = ((ONES & 31) >> 2) & 1;
-      int frow = -1;
       if (ks < KSA) {
-        const int f = 2 * ks + lc.g;
-        if (f < Hin) frow = f;
-      } else if (m == ones_m && i == ones_i) {
-        if (lc.g == ones_g) frow = Hin;                // bias row
-      } else {
-        continue;
-      }
 #pragma unroll
-      for (int n = 0; n < NTB; ++n) {
-        if (frow >= 0 && lc.fcol[n] < Hout) atomicAdd(&Gl[frow * Hout + lc.fcol[n]], wacc[m][n][i]);
+        for (int n = 0; n < NTB; ++n) {
+          if (lc.fcol[n] < GS) {
+            if (GS == 1) atomicAdd(&Gl[2 * ks + lc.g], wacc[m][n][i]);
+            else atomicAdd(&Gl[lc.gbase[n] + 2 * ks * GS], wacc[m][n][i]);
+          }
+        }
+      } else if (m == ones_m && i == ones_i) {
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+          if (lc.g == ones_g && lc.fcol[n] < GS) {
+            if (GS == 1) atomicAdd(&Gl[2 * KSA], wacc[m][n][i]);
+            else atomicAdd(&Gl[lc.fcol[n] + 2 * KSA * GS], wacc[m][n][i]);
+          }
+        }
       }
     }
 }
@@ -233,7 +260,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       BI[i] = (16 * mt + r < KS && f < net.H[l]) ? A.theta[net.boff[l] + f] : 0.f;
     }
     for (int i = tid; i < 2 * KS; i += NTHREADS) WO[i] = (i < net.H[L]) ? A.theta[net.woff[L + 1] + i] : 0.f;
-    for (int i = tid; i < P; i += NTHREADS) Gacc[i] = 0.f;
+    for (int i = tid; i < LY::G_SZ; i += NTHREADS) Gacc[i] = 0.f;
     for (int i = tid; i < 4 * TROWS * TS; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
   }
   __syncthreads();
@@ -250,6 +277,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
     lc.trd[m] = (32 * m + lc.c) * TS + 16 * lc.g;
     const int fo = vfeat(32 * m + lc.c);
     lc.fcol[m] = (vks(32 * m + lc.c) < KS) ? fo : (1 << 20);
+    lc.gbase[m] = lc.fcol[m] + lc.g * LY::HP;
   }
   lc.twr = 4 * lc.g * TS + lc.c;
 
@@ -264,6 +292,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
   const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // The weight images never change inside the loop, so LICM would hoist every fragment load
+    // (~450 registers) out of it and spill them; fragments are meant to be re-read from LDS.
+    asm volatile("" ::: "memory");
     const bool interior = tile < ntiles_i;
     const long r0 = (interior ? tile : tile - ntiles_i) * TILE;
     const long nrows = interior ? A.nT : A.nB;
@@ -408,7 +439,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const float wv = WO[2 * ks + lc.g];
-      const float av = a[L - 1][ks];
+      const float av = opaque(a[L - 1][ks]);
       const float sp = av * (1.f - av);
       const float ab = ubar * wv, adb = udbar * wv;
       zdb[ks] = adb * sp;
@@ -419,11 +450,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       float sv[1], st[1];
       sv[0] = (lc.g == 0) ? ubar : 0.f;
       st[0] = (lc.g == 0) ? udbar : 0.f;
-      wgrad_layer<KS, 1, false>(a[L - 1], zd[L - 1], sv, st, Tw, lc, Gacc + net.woff[L + 1], net.H[L], 1);
+      wgrad_layer<KS, 1, false, 1>(a[L - 1], zd[L - 1], sv, st, Tw, lc, Gacc + LY::GO_OFF);
     }
 #pragma unroll
     for (int l = L; l >= 2; --l) {
-      wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, Tw, lc, Gacc + net.woff[l], net.H[l - 1], net.H[l]);
+      wgrad_layer<KS, KS, false, LY::HP>(a[l - 2], zd[l - 2], zb, zdb, Tw, lc,
+                                         Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ);
       // input gradient of layer l: Abar_{l-1}[in pos][pt] = sum_out W_l[in][out] zbar_l[out][pt]
       const float* Wl = WH + (l - 2) * LY::HPWS;
       f32x16 accv[MT], acct[MT];
@@ -442,20 +474,31 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const float av = a[l - 2][ks];
+        const float av = opaque(a[l - 2][ks]);
         const float sp = av * (1.f - av);
         const float ab = accv[ks >> 4][ks & 15], adb = acct[ks >> 4][ks & 15];
         zdb[ks] = adb * sp;
         zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[l - 2][ks];
       }
     }
-    wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, Tw, lc, Gacc + net.woff[1], net.d_in, net.H[1]);
+    wgrad_layer<KS0, KS, true, LY::HP>(xin, gin, zb, zdb, Tw, lc, Gacc);
   }
 
   // ------------------------------------------------------------------ epilogue
   __syncthreads();
   float* out = A.partial + (long)blockIdx.x * P;
-  for (int i = tid; i < P; i += NTHREADS) out[i] = Gacc[i];
+  // gradient image -> flat parameter layout ([Hin+1][Hout] per layer: kernel rows then the bias row)
+#pragma unroll
+  for (int l = 1; l <= L + 1; ++l) {
+    const int Hin = net.H[l - 1], Hout = net.H[l];
+    const int gs = (l == L + 1) ? 1 : LY::HP;
+    const int brow = (l == 1) ? 2 * KS0 : LY::HP;
+    const float* Gl = Gacc + ((l == 1) ? 0 : (l == L + 1) ? LY::GO_OFF : LY::G1_SZ + (l - 2) * LY::GH_SZ);
+    for (int i = tid; i < (Hin + 1) * Hout; i += NTHREADS) {
+      const int r = i / Hout, cc = i % Hout;
+      out[net.woff[l] + i] = Gl[(r < Hin ? r : brow) * gs + cc];
+    }
+  }
   // loss partials: (var, bc, ic)
   float v0 = loss_var, v1 = loss_bc, v2 = loss_ic;
 #pragma unroll
@@ -473,7 +516,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
 template <int L, int KS>
 hipError_t launch_one(const VnFusedArgsD& a, int grid, hipStream_t s) {
   using LY = Lay<L, KS>;
-  const size_t bytes = (size_t)(LY::G_OFF + a.net.P) * sizeof(float);
+  const size_t bytes = (size_t)LY::TOTAL * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)vn_fused_kernel<L, KS>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return e;
@@ -483,7 +526,8 @@ hipError_t launch_one(const VnFusedArgsD& a, int grid, hipStream_t s) {
 
 template <int L, int KS>
 size_t lds_one(int P) {
-  return (size_t)(Lay<L, KS>::G_OFF + P) * sizeof(float);
+  (void)P;
+  return (size_t)Lay<L, KS>::TOTAL * sizeof(float);
 }
 
 int pick_ks(int hmax) {
