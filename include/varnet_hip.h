@@ -152,6 +152,10 @@ int vn_get_step(const vn_engine* h, int64_t* step);
 int vn_profile_begin(vn_engine* h);
 int vn_profile_end(vn_engine* h, double* mean_ms, int64_t* launches, char* name, int32_t name_len);
 
+/* Diagnostic builds (-DVN_STAMPS) only: per-phase s_memtime cycle sums of workgroup 0 of the last
+ * fused launch (zeros otherwise).  Never part of a timed or shipped build. */
+int vn_debug_stamps(vn_engine* h, unsigned long long out[8]);
+
 #ifdef __cplusplus
 }
 #endif

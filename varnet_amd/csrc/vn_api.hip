@@ -79,6 +79,7 @@ struct vn_engine {
   int64_t step = 0;
   bool use_fused = false;
   float* fused_losspart = nullptr;   // [ncu*3]
+  unsigned long long* stamps = nullptr;   // 8 counters, diagnostic builds
 
   // profiling of the dominant kernel
   bool prof_on = false;
@@ -253,6 +254,8 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
       return fail(VN_ENOMEM, "device allocation failed");
     }
     h->prof_name = "vn_fused_kernel";
+    if (hipMalloc((void**)&h->stamps, 8 * sizeof(unsigned long long)) == hipSuccess)
+      (void)hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   }
   h->ev0.resize(PROF_CAP, nullptr);
   h->ev1.resize(PROF_CAP, nullptr);
@@ -264,7 +267,7 @@ int vn_destroy(vn_engine* h) {
   if (!h) return VN_OK;
   (void)hipSetDevice(h->cfg.device);
   void* ptrs[] = {h->theta, h->m, h->v, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
-                  h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart};
+                  h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart, h->stamps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
@@ -445,7 +448,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
     a.lossVec = nullptr;
     a.Xb = h->biInput; a.label = h->biLabel; a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;
     a.w0 = (float)h->w[0]; a.w1 = (float)h->w[1]; a.w2 = (float)h->w[2];
-    a.partial = h->partial; a.losspart = h->fused_losspart;
+    a.partial = h->partial; a.losspart = h->fused_losspart; a.stamps = h->stamps;
     const int grid = h->ncu;
     const bool rec = h->prof_on && h->prof_n < PROF_CAP;
     if (rec) {
@@ -548,6 +551,14 @@ int vn_residual_f64(vn_engine* h, const double* X, const double* diff, const dou
 int vn_get_step(const vn_engine* h, int64_t* step) {
   if (!h || !step) return fail(VN_EINVAL, "null argument");
   *step = h->step;
+  return VN_OK;
+}
+
+int vn_debug_stamps(vn_engine* h, unsigned long long out[8]) {
+  if (!h || !out) return fail(VN_EINVAL, "null argument");
+  if (!h->stamps) { memset(out, 0, 8 * sizeof(unsigned long long)); return VN_OK; }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(out, h->stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return VN_OK;
 }
 

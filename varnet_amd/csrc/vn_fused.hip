@@ -31,7 +31,7 @@ namespace {
 constexpr int NTHREADS = 256;
 constexpr int TILE = 128;     // points per workgroup tile (4 waves x 32)
 constexpr int WS = 65;        // weight image row stride (floats)
-constexpr int TS = 36;        // transposition buffer row stride (floats): 16-B aligned rows
+constexpr int TSW = 132;      // transposition buffer row stride (floats): 128 points + 4, 16-B aligned rows
 constexpr int TROWS = 64;
 constexpr int KS0 = 4;        // input layer k-steps (d_in <= 8)
 
@@ -62,16 +62,15 @@ struct Lay {
   static constexpr int BI_OFF = WH_OFF + (L - 1) * HPWS;    // [L][64] biases in (mt, g, i) order
   static constexpr int WO_OFF = BI_OFF + L * 64;            // [2*KS] output weights by feature
   static constexpr int MISC_OFF = WO_OFF + al4(2 * KS);     // sInt[128] | sR[128]
-  static constexpr int T_OFF = MISC_OFF + 256;              // [4 waves][TROWS][TS]
-  static constexpr int G_OFF = T_OFF + 4 * TROWS * TS;      // gradient image (padded blocks, below)
-  // gradient image: layer 1 block [2*KS0+1][HP], hidden blocks [HP+1][HP], output block [HP+1][1];
-  // the last row of every block is the bias gradient.  Compile-time strides keep every ds_add
-  // address an immediate offset from two per-lane registers.
+  static constexpr int T_OFF = MISC_OFF + 256;              // TA | TB: [TROWS][TSW] each (shared by the 4 waves)
+  // gradient image (only used once, after the tile loop; aliases TA|TB): layer 1 block
+  // [2*KS0+1][HP], hidden blocks [HP+1][HP], output block [HP+1][1]; last row = bias gradient.
   static constexpr int G1_SZ = (2 * KS0 + 1) * HP;
   static constexpr int GH_SZ = (HP + 1) * HP;
   static constexpr int GO_OFF = G1_SZ + (L - 1) * GH_SZ;
   static constexpr int G_SZ = al4(GO_OFF + HP + 1);
-  static constexpr int TOTAL = G_OFF + G_SZ;
+  static constexpr int T_SZ = (2 * TROWS * TSW > G_SZ) ? 2 * TROWS * TSW : G_SZ;
+  static constexpr int TOTAL = T_OFF + T_SZ;
 };
 
 __device__ __forceinline__ float fsigmoid(float z) {
@@ -104,34 +103,41 @@ struct LaneC {
   int g, c;
   int offF[2];     // forward A-fragment lane offset inside a weight image
   int offB[2];     // backward (transposed) A-fragment lane offset
-  int twr;         // transposition write offset (floats, inside the wave's buffer)
-  int trd[2];      // transposition read offsets per 32-row tile
-  int fcol[2];     // out-feature owned by this lane for column tile nt (or >= 1<<20 if none)
-  int gbase[2];    // fcol + g*GS for the hidden/first blocks (GS = HP)
+  int twr;         // transposition write offset: (4g)*TSW + wave*32 + c
 };
 
-// One weight-gradient contraction for a layer:
+// One weight-gradient contraction for a layer, cooperative over the workgroup's 128-point tile:
 //   G[in pos][out pos] += sum_pts Aside[in][pt] * Bside[out][pt]   (value half, then tangent half)
+// Every wave writes its 32 point-columns of the transposed operands into the shared LDS images
+// TA / TB; after a barrier wave w contracts ONE 32x32 output tile (m, n) over its share of the
+// points into a persistent register accumulator (no atomics, fixed summation order).  With NT
+// output tiles, tile = w % NT and the 128 points are split over the NS = 4/NT waves per tile.
 // av/azd: A-side registers per k-step (a, zdot) in accumulator layout; RAWA: inputs (tangent = azd
 // as is) instead of a*(1-a)*zd.  bv/bt: B-side registers (zbar, zdbar).
-template <int KSA, int KSB, bool RAWA, int GS>
-__device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float (&azd)[KSA],
-                                            const float (&bv)[KSB], const float (&bt)[KSB], float* Tw,
-                                            const LaneC& lc, float* Gl) {
-  constexpr int ONES = vones(KSA);
-  constexpr int MTA = (mtiles(KSA) > (ONES >> 5) + 1) ? mtiles(KSA) : (ONES >> 5) + 1;
-  constexpr int NTB = mtiles(KSB);
-  f32x16 wacc[MTA][NTB];
-#pragma unroll
-  for (int m = 0; m < MTA; ++m)
-#pragma unroll
-    for (int n = 0; n < NTB; ++n)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) wacc[m][n][i] = 0.f;
+template <int KSA, int KSB>
+struct WG {
+  static constexpr int ONES = vones(KSA);
+  static constexpr int MTA = (mtiles(KSA) > (ONES >> 5) + 1) ? mtiles(KSA) : (ONES >> 5) + 1;
+  static constexpr int NTB = mtiles(KSB);
+  static constexpr int NT = MTA * NTB;          // 1, 2 or 4
+  static constexpr int NS = 4 / NT;             // point splits
+  static constexpr int PTS = TILE / NS;         // points contracted by one wave
+  static constexpr int ones_m = ONES >> 5;
+  static constexpr int ones_i = 4 * ((ONES & 31) >> 3) + (ONES & 3);
+  static constexpr int ones_g = ((ONES & 31) >> 2) & 1;
+};
 
+template <int KSA, int KSB, bool RAWA>
+__device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float (&azd)[KSA],
+                                            const float (&bv)[KSB], const float (&bt)[KSB], float* TA,
+                                            float* TB, const LaneC& lc, int wave, f32x16& acc) {
+  using W = WG<KSA, KSB>;
+  const int t = wave % W::NT, sidx = wave / W::NT;
+  const int m = t / W::NTB, n = t % W::NTB;
+  const int rdA = (32 * m + lc.c) * TSW + sidx * W::PTS + lc.g * (W::PTS / 2);
+  const int rdB = (32 * n + lc.c) * TSW + sidx * W::PTS + lc.g * (W::PTS / 2);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    // ---- A side -> LDS (transposed image: row = feature position, column = point) ----
 #pragma unroll
     for (int ks = 0; ks < KSA; ++ks) {
       float v;
@@ -141,68 +147,56 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
         const float x = opaque(av[ks]);
         v = x * (1.f - x) * azd[ks];
       }
-      Tw[lc.twr + vpos(ks, 0) * TS] = v;
+      TA[lc.twr + vpos(ks, 0) * TSW] = v;
     }
-    if (lc.g == 0) Tw[ONES * TS + lc.c] = (half == 0) ? 1.f : 0.f;
-    wave_lds_sync();
-    float areg[MTA][16];
+    if (lc.g == 0) TA[lc.twr + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
 #pragma unroll
-    for (int m = 0; m < MTA; ++m)
+    for (int ks = 0; ks < KSB; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 t = *reinterpret_cast<const f32x4a*>(&Tw[lc.trd[m] + 4 * j]);
-        areg[m][4 * j + 0] = t[0]; areg[m][4 * j + 1] = t[1];
-        areg[m][4 * j + 2] = t[2]; areg[m][4 * j + 3] = t[3];
-      }
-    // ---- B side -> LDS (same buffer; LDS ops of one wave execute in order) ----
-    wave_lds_sync();
+    for (int j = 0; j < W::PTS / 8; ++j) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * j]);
+      const f32x4 b4 = *reinterpret_cast<const f32x4a*>(&TB[rdB + 4 * j]);
 #pragma unroll
-    for (int ks = 0; ks < KSB; ++ks) Tw[lc.twr + vpos(ks, 0) * TS] = (half == 0) ? bv[ks] : bt[ks];
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 b[NTB];
-#pragma unroll
-      for (int n = 0; n < NTB; ++n) b[n] = *reinterpret_cast<const f32x4a*>(&Tw[lc.trd[n] + 4 * j]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int m = 0; m < MTA; ++m)
-#pragma unroll
-          for (int n = 0; n < NTB; ++n) wacc[m][n] = mfma32(areg[m][4 * j + e], b[n][e], wacc[m][n]);
+      for (int e = 0; e < 4; ++e) acc = mfma32(a4[e], b4[e], acc);
     }
-    wave_lds_sync();
+    __syncthreads();
   }
-  // ---- add the tile into the workgroup's gradient image block: [2*KSA+1 rows][GS] ----
-  // row = in-feature 2*ks+g (bias: row 2*KSA), column = this lane's out-feature.  Padded cells
-  // collect harmless values that are never copied out.
-#pragma unroll
-  for (int m = 0; m < MTA; ++m)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int ks = 16 * m + i;                       // k-step of this accumulator row
-      constexpr int ones_m = ONES >> 5;
-      constexpr int ones_i = 4 * ((ONES & 31) >> 3) + (ONES & 3);
-      constexpr int ones_g = ((ONES & 31) >> 2) & 1;
-      if (ks < KSA) {
-#pragma unroll
-        for (int n = 0; n < NTB; ++n) {
-          if (lc.fcol[n] < GS) {
-            if (GS == 1) atomicAdd(&Gl[2 * ks + lc.g], wacc[m][n][i]);
-            else atomicAdd(&Gl[lc.gbase[n] + 2 * ks * GS], wacc[m][n][i]);
-          }
-        }
-      } else if (m == ones_m && i == ones_i) {
-#pragma unroll
-        for (int n = 0; n < NTB; ++n) {
-          if (lc.g == ones_g && lc.fcol[n] < GS) {
-            if (GS == 1) atomicAdd(&Gl[2 * KSA], wacc[m][n][i]);
-            else atomicAdd(&Gl[lc.fcol[n] + 2 * KSA * GS], wacc[m][n][i]);
-          }
-        }
-      }
-    }
 }
+
+// After the tile loop: add this wave's accumulator tile of one layer into the LDS gradient image
+// block [2*KSA+1 rows][GS] (row = in-feature, last row = bias; column = out-feature).
+template <int KSA, int KSB, int GS>
+__device__ __forceinline__ void wgrad_flush(const f32x16& acc, float* Gl, const LaneC& lc, int wave) {
+  using W = WG<KSA, KSB>;
+  const int t = wave % W::NT;
+  const int m = t / W::NTB, n = t % W::NTB;
+  const int cpos = 32 * n + lc.c;
+  const bool colok = (vks(cpos) < KSB) && (vfeat(cpos) < GS);
+  const int col = vfeat(cpos);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ks = 16 * m + i;
+    int row = -1;
+    if (ks < KSA) row = 2 * ks + lc.g;
+    else if (m == W::ones_m && i == W::ones_i && lc.g == W::ones_g) row = 2 * KSA;
+    if (row >= 0 && colok) Gl[row * GS + col] += acc[i];
+  }
+}
+
+#ifdef VN_STAMPS
+#define STAMP(i)                                                          \
+  do {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    unsigned long long t_;                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    stamp_acc[i] += t_ - stamp_prev;                                      \
+    stamp_prev = t_;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 
 struct VnFusedArgsD {
   VnNet net;
@@ -216,6 +210,7 @@ struct VnFusedArgsD {
   float w0, w1, w2;
   float* partial;
   float* losspart;
+  unsigned long long* stamps;
 };
 
 template <int L, int KS>
@@ -232,8 +227,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
   float* WO = lds + LY::WO_OFF;
   float* sInt = lds + LY::MISC_OFF;
   float* sR = sInt + TILE;
-  float* Tw = lds + LY::T_OFF + wave * TROWS * TS;
-  float* Gacc = lds + LY::G_OFF;
+  float* TA = lds + LY::T_OFF;
+  float* TB = TA + TROWS * TSW;
+  float* Gacc = lds + LY::T_OFF;                 // aliases TA|TB, used after the tile loop only
 
   // ------------------------------------------------------------------ prologue: LDS images
   {
@@ -260,8 +256,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       BI[i] = (16 * mt + r < KS && f < net.H[l]) ? A.theta[net.boff[l] + f] : 0.f;
     }
     for (int i = tid; i < 2 * KS; i += NTHREADS) WO[i] = (i < net.H[L]) ? A.theta[net.woff[L + 1] + i] : 0.f;
-    for (int i = tid; i < LY::G_SZ; i += NTHREADS) Gacc[i] = 0.f;
-    for (int i = tid; i < 4 * TROWS * TS; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
+    for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
   }
   __syncthreads();
 
@@ -274,12 +269,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
     int fin = vfeat(32 * m + lc.c);
     if (fin >= LY::HP) fin = 0;
     lc.offB[m] = fin * WS + 4 * lc.g;
-    lc.trd[m] = (32 * m + lc.c) * TS + 16 * lc.g;
-    const int fo = vfeat(32 * m + lc.c);
-    lc.fcol[m] = (vks(32 * m + lc.c) < KS) ? fo : (1 << 20);
-    lc.gbase[m] = lc.fcol[m] + lc.g * LY::HP;
   }
-  lc.twr = 4 * lc.g * TS + lc.c;
+  lc.twr = 4 * lc.g * TSW + wave * 32 + lc.c;
+
+  // persistent weight-gradient accumulators: one 32x32 tile per layer per wave
+  f32x16 wacc[L + 1];
+#pragma unroll
+  for (int l = 0; l <= L; ++l)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wacc[l][i] = 0.f;
 
   const float bo = A.theta[net.boff[L + 1]];
   const int q = A.integ_num;
@@ -291,6 +289,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
   const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
   const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
 
+#ifdef VN_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // The weight images never change inside the loop, so LICM would hoist every fragment load
     // (~450 registers) out of it and spill them; fragments are meant to be re-read from LDS.
@@ -314,10 +316,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       }
     }
 
+    STAMP(0);   // inputs
     float a[L][KS], zd[L][KS];                               // stored activations (registers)
 
     // ---------------------------------------------------------------- forward
-    {
+    // layer 1 (also re-run late in the reverse pass: its activations are cheap to recompute --
+    // 2*MT MFMAs per input pair -- and not keeping them alive frees 2*KS registers)
+    auto layer1 = [&](const float (&xi)[KS0], const float (&gi)[KS0]) {
       f32x16 accv[MT], acct[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -336,8 +341,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             const float wf = W1[2 * s * WS + lc.offF[m]];
-            accv[m] = mfma32(wf, xin[s], accv[m]);
-            acct[m] = mfma32(wf, gin[s], acct[m]);
+            accv[m] = mfma32(wf, xi[s], accv[m]);
+            acct[m] = mfma32(wf, gi[s], acct[m]);
           }
         }
       }
@@ -346,7 +351,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
         a[0][ks] = fsigmoid(accv[ks >> 4][ks & 15]);
         zd[0][ks] = acct[ks >> 4][ks & 15];
       }
-    }
+    };
+    layer1(xin, gin);
 #pragma unroll
     for (int l = 2; l <= L; ++l) {
       const float* Wl = WH + (l - 2) * LY::HPWS;
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
         zd[l - 1][ks] = acct[ks >> 4][ks & 15];
       }
     }
+    STAMP(1);   // forward GEMMs
     // output layer (VALU): u, udot; both lane halves end with the full sums
     float u = 0.f, ud = 0.f;
 #pragma unroll
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       }
     }
 
+    STAMP(2);   // output + weak-form epilogue (2 barriers)
     // ---------------------------------------------------------------- backward
     float zb[KS], zdb[KS];
 #pragma unroll
@@ -450,12 +458,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       float sv[1], st[1];
       sv[0] = (lc.g == 0) ? ubar : 0.f;
       st[0] = (lc.g == 0) ? udbar : 0.f;
-      wgrad_layer<KS, 1, false, 1>(a[L - 1], zd[L - 1], sv, st, Tw, lc, Gacc + LY::GO_OFF);
+      STAMP(3);  // zbar_L
+      wgrad_layer<KS, 1, false>(a[L - 1], zd[L - 1], sv, st, TA, TB, lc, wave, wacc[L]);
+      STAMP(4);  // output-layer wgrad
     }
 #pragma unroll
     for (int l = L; l >= 2; --l) {
-      wgrad_layer<KS, KS, false, LY::HP>(a[l - 2], zd[l - 2], zb, zdb, Tw, lc,
-                                         Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ);
+      if (l == 2 && L > 2) {                                 // bring layer-1 activations back
+        float xr[KS0], gr[KS0];
+#pragma unroll
+        for (int s = 0; s < KS0; ++s) { xr[s] = opaque(xin[s]); gr[s] = opaque(gin[s]); }
+        layer1(xr, gr);
+      }
+      wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacc[l - 1]);
+      STAMP(5);  // hidden wgrad
       // input gradient of layer l: Abar_{l-1}[in pos][pt] = sum_out W_l[in][out] zbar_l[out][pt]
       const float* Wl = WH + (l - 2) * LY::HPWS;
       f32x16 accv[MT], acct[MT];
@@ -480,12 +496,30 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
         zdb[ks] = adb * sp;
         zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[l - 2][ks];
       }
+      STAMP(6);  // input-gradient GEMM + zbar
     }
-    wgrad_layer<KS0, KS, true, LY::HP>(xin, gin, zb, zdb, Tw, lc, Gacc);
+    wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc[0]);
+    STAMP(7);    // layer-1 wgrad
   }
 
   // ------------------------------------------------------------------ epilogue
+#ifdef VN_STAMPS
+  if (A.stamps && blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 8; ++i) A.stamps[i] = stamp_acc[i];
+#endif
   __syncthreads();
+  for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {                      // fixed order: bitwise reproducible sums
+    if (wave == w) {
+      wgrad_flush<KS0, KS, LY::HP>(wacc[0], Gacc, lc, wave);
+#pragma unroll
+      for (int l = 2; l <= L; ++l)
+        wgrad_flush<KS, KS, LY::HP>(wacc[l - 1], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
+      wgrad_flush<KS, 1, 1>(wacc[L], Gacc + LY::GO_OFF, lc, wave);
+    }
+    __syncthreads();
+  }
   float* out = A.partial + (long)blockIdx.x * P;
   // gradient image -> flat parameter layout ([Hin+1][Hout] per layer: kernel rows then the bias row)
 #pragma unroll
@@ -565,7 +599,7 @@ hipError_t vn_fused_launch(const VnFusedArgs& h, int grid, hipStream_t s) {
   a.integ_num = h.integ_num; a.feN = h.feN; a.fedNt = h.fedNt; a.feW = h.feW; a.detJv = h.detJv;
   a.detJ = h.detJ; a.time_dependent = h.time_dependent; a.lossVec = h.lossVec; a.Xb = h.Xb;
   a.label = h.label; a.nB = h.nB; a.bDof = h.bDof; a.biDimVal = h.biDimVal; a.w0 = h.w0; a.w1 = h.w1;
-  a.w2 = h.w2; a.partial = h.partial; a.losspart = h.losspart;
+  a.w2 = h.w2; a.partial = h.partial; a.losspart = h.losspart; a.stamps = h.stamps;
   const int ks = pick_ks(h.net.hmax);
 #define X(LL, KK) if (h.net.L == LL && ks == KK) return launch_one<LL, KK>(a, grid, s);
   VN_FUSED_CASES(X)

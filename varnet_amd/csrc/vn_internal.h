@@ -71,6 +71,7 @@ struct VnFusedArgs {
   float w0, w1, w2;
   float* partial;    // [grid, P] per-workgroup gradient partials
   float* losspart;   // [grid, 3] per-workgroup (var, bc, ic) partial sums
+  unsigned long long* stamps;   // diagnostic builds (-DVN_STAMPS) only: 8 phase cycle sums, else nullptr
 };
 bool vn_fused_supported(const VnNet& net, int integ_num);
 size_t vn_fused_lds_bytes(const VnNet& net);

@@ -60,6 +60,7 @@ _SIGS = {
     'vn_residual': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_residual_f64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_get_step': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'vn_debug_stamps': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     'vn_profile_begin': (C.c_int, [C.c_void_p]),
     'vn_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                  C.c_char_p, C.c_int32]),
@@ -309,6 +310,11 @@ class VNEngine:
         fn = self.lib.vn_residual_f64 if fp64 else self.lib.vn_residual
         self._ck(fn(self.h, _ptr(X), _ptr(diff), _ptr(vel), _ptr(source), _ptr(diff_dx), n, _ptr(u), _ptr(r)))
         return u, r
+
+    def debug_stamps(self):
+        out = (C.c_uint64 * 8)()
+        self._ck(self.lib.vn_debug_stamps(self.h, out))
+        return list(out)
 
     # -- profiling -----------------------------------------------------------------------
     def profile_begin(self):
