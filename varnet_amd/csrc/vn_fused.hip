@@ -74,6 +74,9 @@ struct Lay {
 };
 
 __device__ __forceinline__ float fsigmoid(float z) {
+#ifdef VN_EXP_NOSIG   // timing-only diagnostic
+  return z * 0.25f;
+#endif
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
 }
 
@@ -153,12 +156,22 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
     __syncthreads();
+    // operand fragments are fetched one step (4 MFMAs = 256 cycles) ahead of their use
+    f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA]);
+    f32x4 b4 = *reinterpret_cast<const f32x4a*>(&TB[rdB]);
 #pragma unroll
     for (int j = 0; j < W::PTS / 8; ++j) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * j]);
-      const f32x4 b4 = *reinterpret_cast<const f32x4a*>(&TB[rdB + 4 * j]);
+      f32x4 an = a4, bn = b4;
+      if (j + 1 < W::PTS / 8) {
+        an = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * (j + 1)]);
+        bn = *reinterpret_cast<const f32x4a*>(&TB[rdB + 4 * (j + 1)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = mfma32(a4[e], b4[e], acc);
+      __builtin_amdgcn_sched_barrier(0);
+      a4 = an;
+      b4 = bn;
     }
     __syncthreads();
   }
@@ -352,38 +365,100 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
         zd[0][ks] = acct[ks >> 4][ks & 15];
       }
     };
-    layer1(xin, gin);
+    // forward proper: pv/pt hold the raw (z, zdot) accumulators of the previous layer; its sigmoid
+    // is applied inside the next layer's k-loop, one k-step ahead of the MFMAs that consume it,
+    // so the VALU/transcendental work runs under the matrix pipe.
+    f32x16 pv[MT], ptn[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b = *reinterpret_cast<const f32x4a*>(&BI[m * 32 + lc.g * 16 + 4 * j]);
+        pv[m][4 * j + 0] = b[0]; pv[m][4 * j + 1] = b[1];
+        pv[m][4 * j + 2] = b[2]; pv[m][4 * j + 3] = b[3];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ptn[m][i] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < KS0; ++s) {
+      if (2 * s < net.d_in) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float wf = W1[2 * s * WS + lc.offF[m]];
+          pv[m] = mfma32(wf, xin[s], pv[m]);
+          ptn[m] = mfma32(wf, gin[s], ptn[m]);
+        }
+      }
+    }
 #pragma unroll
     for (int l = 2; l <= L; ++l) {
       const float* Wl = WH + (l - 2) * LY::HPWS;
-      f32x16 accv[MT], acct[MT];
+      f32x16 nv[MT], nt[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 b = *reinterpret_cast<const f32x4a*>(&BI[(l - 1) * 64 + m * 32 + lc.g * 16 + 4 * j]);
-          accv[m][4 * j + 0] = b[0]; accv[m][4 * j + 1] = b[1];
-          accv[m][4 * j + 2] = b[2]; accv[m][4 * j + 3] = b[3];
+          nv[m][4 * j + 0] = b[0]; nv[m][4 * j + 1] = b[1];
+          nv[m][4 * j + 2] = b[2]; nv[m][4 * j + 3] = b[3];
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acct[m][i] = 0.f;
+        for (int i = 0; i < 16; ++i) nt[m][i] = 0.f;
       }
+      // Software pipeline over k-steps (all indices compile-time): while the MFMAs of k-step ks run,
+      // the sigmoid of the previous layer advances by one stage for each of the next three k-steps
+      //   A(j): e = 2^(-z_j*log2e)     B(j): s = 1/(1+e)     C(j): q = s(1-s)*zdot_j
+      // so no VALU/transcendental dependency chain is longer than 3 ops inside one MFMA shadow.
+      auto zin = [&](int j) { return pv[j >> 4][j & 15]; };
+      auto zdin = [&](int j) { return ptn[j >> 4][j & 15]; };
+      auto stA = [&](int j) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * zin(j)); };
+      auto stB = [&](float e) { return __builtin_amdgcn_rcpf(1.0f + e); };
+      float wf[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = Wl[lc.offF[m]];
+      float cs = stB(stA(0));                       // sigmoid of k-step 0
+      float cq = cs * (1.f - cs) * zdin(0);
+      a[l - 2][0] = cs;
+      zd[l - 2][0] = zdin(0);
+      float s1 = (KS > 1) ? stB(stA(1)) : 0.f;      // sigmoid of k-step ks+1
+      float e2 = (KS > 2) ? stA(2) : 0.f;           // exp of k-step ks+2
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const float av = a[l - 2][ks];
-        const float ad = av * (1.f - av) * zd[l - 2][ks];
+        float wn[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float wf = Wl[2 * ks * WS + lc.offF[m]];
-          accv[m] = mfma32(wf, av, accv[m]);
-          acct[m] = mfma32(wf, ad, acct[m]);
+        for (int m = 0; m < MT; ++m) wn[m] = (ks + 1 < KS) ? Wl[2 * (ks + 1) * WS + lc.offF[m]] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        nv[0] = mfma32(wf[0], cs, nv[0]);
+        float e3 = 0.f;
+        if (ks + 3 < KS) e3 = stA(ks + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        nt[0] = mfma32(wf[0], cq, nt[0]);
+        float s2 = 0.f;
+        if (ks + 2 < KS) s2 = stB(e2);
+        __builtin_amdgcn_sched_barrier(0);
+        float q1 = 0.f;
+        if (MT == 2) nv[MT - 1] = mfma32(wf[MT - 1], cs, nv[MT - 1]);
+        if (ks + 1 < KS) {
+          const float zz = zdin(ks + 1);
+          q1 = s1 * (1.f - s1) * zz;
+          a[l - 2][ks + 1] = s1;
+          zd[l - 2][ks + 1] = zz;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MT == 2) nt[MT - 1] = mfma32(wf[MT - 1], cq, nt[MT - 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        cs = s1; cq = q1; s1 = s2; e2 = e3;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wf[m] = wn[m];
       }
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        a[l - 1][ks] = fsigmoid(accv[ks >> 4][ks & 15]);
-        zd[l - 1][ks] = acct[ks >> 4][ks & 15];
-      }
+      for (int m = 0; m < MT; ++m) { pv[m] = nv[m]; ptn[m] = nt[m]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      a[L - 1][ks] = fsigmoid(pv[ks >> 4][ks & 15]);
+      zd[L - 1][ks] = ptn[ks >> 4][ks & 15];
     }
     STAMP(1);   // forward GEMMs
     // output layer (VALU): u, udot; both lane halves end with the full sums
@@ -479,14 +554,23 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { accv[m][i] = 0.f; acct[m][i] = 0.f; }
+      float wf[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = Wl[lc.offB[m] + vpos(0, 0)];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+        float wn[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wn[m] = (ks + 1 < KS) ? Wl[lc.offB[m] + vpos(ks + 1, 0)] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const float wf = Wl[lc.offB[m] + vpos(ks, 0)];
-          accv[m] = mfma32(wf, zb[ks], accv[m]);
-          acct[m] = mfma32(wf, zdb[ks], acct[m]);
+          accv[m] = mfma32(wf[m], zb[ks], accv[m]);
+          acct[m] = mfma32(wf[m], zdb[ks], acct[m]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wf[m] = wn[m];
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
