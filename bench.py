@@ -164,6 +164,13 @@ def main():
                     + vn.layerWidth[-1])
         flop_launch = 6.0 * F_pt * rows_local + 3.0 * F_pt * nB
         achieved = flop_launch / (kms * 1e-3) / 1e12 if kms > 0 else None
+        # HBM bytes per launch come from the separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the
+        # gfx950 correction, WRITE_SIZE as is) committed under profiles/; only quoted for the exact
+        # workload and kernel they were collected on.
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
+        if args.config == 3 and world == 1 and kname == 'vn_fused_kernel' and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
         out = {
             "metric": "training-points/sec (test-funcs x quad-pts), 2D+t AD-PDE" if args.config == 3
             else "training-points/sec (test-funcs x quad-pts), 1D+t AD-PDE",
@@ -183,7 +190,7 @@ def main():
                        "optimizer": "TF1-Adam lr=1e-3", "sharding": "contiguous test-function blocks per rank, SUM all-reduce of %d floats" % (P + 4),
                        "test_functions_per_sec": fd.nt * args.steps / dt, "loss_after": loss_after},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
                          "kernel": kname, "kernel_ms": kms, "launches_timed": klaunches,
                          "algorithmic_flop_per_launch": flop_launch,
                          "note": "6*F_pt per interior point + 3*F_pt per BC/IC point, F_pt=%d; HIP events on the engine stream" % F_pt},
