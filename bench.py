@@ -110,12 +110,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # several ranks may share a GPU only in the gloo rehearsal below
     torch.cuda.set_device(local)
+    os.environ['LOCAL_RANK'] = str(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        # backend 'nccl' IS RCCL on ROCm; VN_DIST_BACKEND=gloo rehearses the N>1 path on one GPU
+        backend = os.environ.get('VN_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     vn, wname = build_problem(args.config)
     fd, eng = vn.fixData, vn.engine
