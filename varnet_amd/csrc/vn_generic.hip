@@ -376,17 +376,23 @@ __global__ __launch_bounds__(NTHREADS) void vn_seed_kernel(VnSeedArgs a) {
   }
 }
 
-// grad[p] = sum over workgroup partials in fixed order; block 0 also folds the loss partials.
+// grad[p] = sum over workgroup partials in a fixed order; block 0 also folds the loss partials.
+// A block owns 64 consecutive parameters; its 4 waves each sum every 4th partial (coalesced 256-B
+// rows), then the 4 sub-sums are added in wave order -> bitwise reproducible.
 __global__ __launch_bounds__(NTHREADS) void vn_reduce_kernel(const float* __restrict__ partial, int nparts, int P,
                                                              const float* __restrict__ losspart, int nlp,
                                                              long bDof, long nB, float w0, float w1, float w2,
                                                              float* __restrict__ gradbuf) {
-  const int p = blockIdx.x * NTHREADS + threadIdx.x;
+  __shared__ float sub[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + lane;
+  float acc = 0.f;
   if (p < P) {
-    float acc = 0.f;
-    for (int g = 0; g < nparts; ++g) acc += partial[(long)g * P + p];
-    gradbuf[p] = acc;
+    for (int g = grp; g < nparts; g += 4) acc += partial[(long)g * P + p];
   }
+  sub[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && p < P) gradbuf[p] = ((sub[0][lane] + sub[1][lane]) + sub[2][lane]) + sub[3][lane];
   if (blockIdx.x == 0 && threadIdx.x == 0 && losspart != nullptr) {
     double tot[3] = {0.0, 0.0, 0.0};
     for (int g = 0; g < nlp; ++g) {
@@ -466,7 +472,7 @@ hipError_t vn_seed_launch(const VnSeedArgs& a, int grid, hipStream_t s) {
 
 hipError_t vn_reduce_launch(const float* partial, int nparts, int P, const float* losspart, int nlossparts,
                             long bDof, long nB, float w0, float w1, float w2, float* gradbuf, hipStream_t s) {
-  const int grid = (P + NTHREADS - 1) / NTHREADS;
+  const int grid = (P + 63) / 64;
   hipLaunchKernelGGL(vn_reduce_kernel, dim3(grid > 0 ? grid : 1), dim3(NTHREADS), 0, s, partial, nparts, P,
                      losspart, nlossparts, bDof, nB, w0, w1, w2, gradbuf);
   return hipGetLastError();
