@@ -484,11 +484,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
       if (A.src) t -= (valid ? A.src[row] : 0.f) * A.feN[pq];           // :657
       t *= wq;                                                          // :660
       if (!valid) t = 0.f;
-      if (lc.g == 0) sInt[pt] = t;
+      // R_k = sum over the test function's q quadrature points: xor-shuffle tree inside the wave
+      // (segments of min(q,32) lanes), then q/32 wave partials through LDS when q > 32.
+      const int seg = q < 32 ? q : 32;
+      for (int o = 1; o < seg; o <<= 1) t += __shfl_xor(t, o, 64);
+      if (lc.g == 0 && (lc.c % seg) == 0) sInt[pt / seg] = t;       // TILE/seg partial sums
       __syncthreads();
       if (tid < TT) {
+        const int per = q / seg;                                      // partials per test function
         float R = 0.f;
-        for (int p = 0; p < q; ++p) R += sInt[tid * q + p];             // :661
+        for (int j = 0; j < per; ++j) R += sInt[tid * per + j];       // :661
         const long k = r0 / q + tid;
         float s = 0.f;
         if (k < A.n_k) {

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvarnet_hip.so')
+# VARNET_HIP_LIB selects a diagnostic build of the same ABI (tools/): never a different backend
+LIB_PATH = os.environ.get('VARNET_HIP_LIB', os.path.join(_HERE, 'libvarnet_hip.so'))
 
 VN_MAX_LAYERS = 6
 VN_MAX_WIDTH = 64
