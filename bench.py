@@ -177,7 +177,7 @@ def main():
         # workload and kernel they were collected on.
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
-        if args.config == 3 and world == 1 and kname == 'vn_fused_kernel' and os.path.exists(tfile):
+        if args.config == 3 and world == 1 and kname.startswith('vn_fused') and os.path.exists(tfile):
             traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
         out = {
             "metric": "training-points/sec (test-funcs x quad-pts), 2D+t AD-PDE" if args.config == 3

@@ -45,7 +45,8 @@ enum {
 
 enum { VN_ACT_SIGMOID = 0 };
 enum { VN_OPT_ADAM = 0 };
-enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 };
+enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 /* 4 waves, 32x32x2 */,
+       VN_KERNEL_FUSED16 = 3 /* 8 waves, 16x16x4 */ };
 
 typedef struct vn_engine vn_engine;
 

@@ -8,7 +8,7 @@ Input = torch.rand(n, d_in, device='cuda', generator=g)*2-1
 gcoef = torch.randn(n, dim, device='cuda', generator=g)
 biInput = torch.rand(nB, d_in, device='cuda', generator=g)*2-1
 biLabel = torch.randn(nB, device='cuda', generator=g)
-eng = VNEngine(dim, d_in, widths, True, integNum)
+eng = VNEngine(dim, d_in, widths, True, integNum, kernel=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 eng.init_params(0)
 rng = np.random.default_rng(0)
 eng.set_fe_table(rng.uniform(0,1,integNum), rng.standard_normal(integNum))

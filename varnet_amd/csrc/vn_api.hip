@@ -78,6 +78,7 @@ struct vn_engine {
 
   int64_t step = 0;
   bool use_fused = false;
+  bool use_fused16 = false;
   float* fused_losspart = nullptr;   // [ncu*3]
   unsigned long long* stamps = nullptr;   // 8 counters, diagnostic builds
 
@@ -247,13 +248,22 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
     vn_destroy(h);
     return fail(VN_EUNSUPPORTED, "fused kernel unsupported for this network / integ_num");
   }
-  h->use_fused = cfg->kernel != VN_KERNEL_GENERIC && vn_fused_supported(net, cfg->integ_num);
+  if (cfg->kernel == VN_KERNEL_FUSED16 && !vn_fused16_supported(net, cfg->integ_num)) {
+    vn_destroy(h);
+    return fail(VN_EUNSUPPORTED, "fused16 kernel unsupported for this network / integ_num");
+  }
+  // AUTO: the 8-wave geometry where instantiated (faster: two waves per SIMD overlap VALU/LDS work
+  // with MFMA), else the 4-wave geometry, else the generic kernels
+  h->use_fused16 = cfg->kernel == VN_KERNEL_FUSED16 ||
+                   (cfg->kernel == VN_KERNEL_AUTO && vn_fused16_supported(net, cfg->integ_num));
+  h->use_fused = h->use_fused16 ||
+                 (cfg->kernel != VN_KERNEL_GENERIC && vn_fused_supported(net, cfg->integ_num));
   if (h->use_fused) {
     if (hipMalloc((void**)&h->fused_losspart, (size_t)h->ncu * 3 * sizeof(float)) != hipSuccess) {
       vn_destroy(h);
       return fail(VN_ENOMEM, "device allocation failed");
     }
-    h->prof_name = "vn_fused_kernel";
+    h->prof_name = h->use_fused16 ? "vn_fused16_kernel" : "vn_fused_kernel";
     if (hipMalloc((void**)&h->stamps, 8 * sizeof(unsigned long long)) == hipSuccess)
       (void)hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   }
@@ -455,7 +465,8 @@ int vn_grad(vn_engine* h, int32_t batch) {
       if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
       HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
     }
-    HIPCHK(vn_fused_launch(a, grid, h->stream));
+    if (h->use_fused16) HIPCHK(vn_fused16_launch(a, grid, h->stream));
+    else HIPCHK(vn_fused_launch(a, grid, h->stream));
     if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
     HIPCHK(vn_reduce_launch(h->partial, grid, h->net.P, h->fused_losspart, grid, h->bDof, h->nB, a.w0, a.w1, a.w2,
                             h->gradbuf, h->stream));

@@ -1,0 +1,595 @@
+// Fused gfx950 kernel, 8-wave geometry: the same algorithm as vn_fused.hip (forward with one
+// tangent, weak-form epilogue, full reverse pass in one persistent launch) laid out for
+// TWO waves per SIMD so that one wave's VALU / LDS / barrier phases run under the other wave's
+// MFMAs.  (Measured on gfx950: a wave's own f32 MFMAs and its VALU work do not overlap -- kernel
+// time with one wave per SIMD is the SUM of MFMA cycles and all other issue cycles.)
+//
+// Geometry: workgroup = 8 waves (512 threads), 128-point tiles, 16 points per wave,
+// v_mfma_f32_16x16x4_f32.  Feature f lives in k-step ks = f/4, lane group g = f%4 (lane = 16g+c,
+// c = point), accumulator row pos(ks,g) = 16(ks>>2) + 4g + (ks&3).  Everything else (register
+// chaining of layers, LDS weight images with stride 65, cooperative LDS-transposed weight
+// gradients with persistent accumulators, fixed summation order) is as documented in vn_fused.hip.
+// Register budget: <= 256 VGPR+AGPR per wave (stored activations 2*KS*L = 130 at 5x50).
+#include "vn_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4a __attribute__((may_alias));
+
+namespace {
+
+constexpr int NW = 8;
+constexpr int NTHREADS = 64 * NW;
+constexpr int TILE = 128;
+constexpr int CW = 16;        // points per wave
+constexpr int WS = 65;        // weight image row stride
+constexpr int TSW = 132;      // transposition image row stride
+constexpr int TROWS = 64;
+constexpr int KS0 = 2;        // input layer k-steps (d_in <= 8)
+
+__host__ __device__ constexpr int al4(int x) { return (x + 3) & ~3; }
+__host__ __device__ constexpr int vpos(int ks, int g) { return 16 * (ks >> 2) + 4 * g + (ks & 3); }
+__host__ __device__ constexpr int vks(int pos) { return 4 * (pos >> 4) + (pos & 3); }
+__host__ __device__ constexpr int vfeat(int pos) { return 4 * vks(pos) + ((pos >> 2) & 3); }
+__host__ __device__ constexpr int vones(int KS) {
+  for (int p = 0; p < 64; ++p)
+    if (vks(p) >= KS) return p;
+  return -1;
+}
+__host__ __device__ constexpr int mtiles(int KS) { return (KS + 3) / 4; }
+
+template <int L, int KS>
+struct Lay {
+  static constexpr int HP = 4 * KS;
+  static constexpr int HPWS = al4(HP * WS);
+  static constexpr int W1_OFF = 0;                          // [8][WS]
+  static constexpr int WH_OFF = al4(8 * WS);                // [L-1][HP][WS]
+  static constexpr int BI_OFF = WH_OFF + (L - 1) * HPWS;    // [L][64] biases in (tile, g, i) order
+  static constexpr int WO_OFF = BI_OFF + L * 64;            // [4*KS]
+  static constexpr int MISC_OFF = WO_OFF + al4(4 * KS);     // sInt[128] | sR[128]
+  static constexpr int T_OFF = MISC_OFF + 256;              // TA | TB
+  static constexpr int G1_SZ = (4 * KS0 + 1) * HP;
+  static constexpr int GH_SZ = (HP + 1) * HP;
+  static constexpr int GO_OFF = G1_SZ + (L - 1) * GH_SZ;
+  static constexpr int G_SZ = al4(GO_OFF + HP + 1);
+  static constexpr int T_SZ = (2 * TROWS * TSW > G_SZ) ? 2 * TROWS * TSW : G_SZ;
+  static constexpr int TOTAL = T_OFF + T_SZ;
+};
+
+__device__ __forceinline__ float opaque(float x) {
+  asm("" : "+v"(x));
+  return x;
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct LaneC {
+  int g, c;
+  int offF;        // forward A-fragment lane offset: g*WS + c            (+ 16*m + 4*ks*WS)
+  int offB[4];     // backward A-fragment lane offset per row tile: fin*WS + 4g   (+ vpos(ks,0))
+  int twr;         // transposition write offset: 4g*TSW + wave*16 + c     (+ vpos(ks,0)*TSW)
+};
+
+template <int KSA, int KSB>
+struct WG {
+  static constexpr int ONES = vones(KSA);
+  static constexpr int MTA0 = (mtiles(KSA) > (ONES >> 4) + 1) ? mtiles(KSA) : (ONES >> 4) + 1;
+  static constexpr int MTA = MTA0 == 3 ? 4 : MTA0;             // 1, 2 or 4 row tiles
+  static constexpr int NTB0 = mtiles(KSB);
+  static constexpr int NTB = NTB0 == 3 ? 4 : NTB0;
+  static constexpr int NT = MTA * NTB;                         // output tiles (16x16): 1..16
+  static constexpr int TPW = (NT >= NW) ? NT / NW : 1;         // tiles per wave (same row tile m)
+  static constexpr int NS = (NT >= NW) ? 1 : NW / NT;          // point splits
+  static constexpr int PTS = TILE / NS;                        // points contracted by one wave
+  static constexpr int PG = PTS / 4;                           // ... by one lane group
+  static constexpr int ones_m = ONES >> 4;
+  static constexpr int ones_i = ONES & 3;
+  static constexpr int ones_g = (ONES >> 2) & 3;
+  static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8 || NT == 16, "tile count must divide the waves");
+  static_assert(NT < NW || NTB % TPW == 0, "a wave's tiles must share a row tile");
+};
+
+// Cooperative weight gradient (see vn_fused.hip): all waves publish their 16 point-columns of
+// the transposed operands, then each wave contracts its output tile(s) over its share of the
+// 128 points into persistent accumulators.
+template <int KSA, int KSB, bool RAWA, int NACC>
+__device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float (&azd)[KSA],
+                                            const float (&bv)[KSB], const float (&bt)[KSB], float* TA,
+                                            float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC]) {
+  using W = WG<KSA, KSB>;
+  static_assert(NACC == W::TPW, "accumulator count");
+  const int t0 = (W::NT >= NW) ? wave * W::TPW : wave % W::NT;
+  const int sidx = (W::NT >= NW) ? 0 : wave / W::NT;
+  const int m = t0 / W::NTB, n0 = t0 % W::NTB;
+  const int rdA = (16 * m + lc.c) * TSW + sidx * W::PTS + lc.g * W::PG;
+  const int rdB = (16 * n0 + lc.c) * TSW + sidx * W::PTS + lc.g * W::PG;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ks = 0; ks < KSA; ++ks) {
+      float v;
+      if (half == 0) v = av[ks];
+      else if (RAWA) v = azd[ks];
+      else {
+        const float x = opaque(av[ks]);
+        v = x * (1.f - x) * azd[ks];
+      }
+      TA[lc.twr + vpos(ks, 0) * TSW] = v;
+    }
+    if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSB; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
+    __syncthreads();
+    f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA]);
+    f32x4 b4[W::TPW];
+#pragma unroll
+    for (int t = 0; t < W::TPW; ++t) b4[t] = *reinterpret_cast<const f32x4a*>(&TB[rdB + 16 * t * TSW]);
+#pragma unroll
+    for (int j = 0; j < W::PG / 4; ++j) {
+      f32x4 an = a4, bn[W::TPW];
+#pragma unroll
+      for (int t = 0; t < W::TPW; ++t) bn[t] = b4[t];
+      if (j + 1 < W::PG / 4) {
+        an = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * (j + 1)]);
+#pragma unroll
+        for (int t = 0; t < W::TPW; ++t)
+          bn[t] = *reinterpret_cast<const f32x4a*>(&TB[rdB + 16 * t * TSW + 4 * (j + 1)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < W::TPW; ++t) acc[t] = mfma16(a4[e], b4[t][e], acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
+      a4 = an;
+#pragma unroll
+      for (int t = 0; t < W::TPW; ++t) b4[t] = bn[t];
+    }
+    __syncthreads();
+  }
+}
+
+template <int KSA, int KSB, int GS, int NACC>
+__device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl, const LaneC& lc, int wave) {
+  using W = WG<KSA, KSB>;
+  const int t0 = (W::NT >= NW) ? wave * W::TPW : wave % W::NT;
+  const int m = t0 / W::NTB, n0 = t0 % W::NTB;
+#pragma unroll
+  for (int t = 0; t < W::TPW; ++t) {
+    const int cpos = 16 * (n0 + t) + lc.c;
+    const bool colok = (vks(cpos) < KSB) && (vfeat(cpos) < GS);
+    const int col = vfeat(cpos);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ks = 4 * m + i;
+      int row = -1;
+      if (ks < KSA) row = 4 * ks + lc.g;
+      else if (m == W::ones_m && i == W::ones_i && lc.g == W::ones_g) row = 4 * KSA;
+      if (row >= 0 && colok) Gl[row * GS + col] += acc[t][i];
+    }
+  }
+}
+
+struct VnFusedArgsD {
+  VnNet net;
+  const float* theta;
+  const float* X; const float* G; const float* src;
+  long nT, n_k; int integ_num;
+  const float* feN; const float* fedNt; const float* feW;
+  const float* detJv; float detJ; int time_dependent;
+  float* lossVec;
+  const float* Xb; const float* label; long nB, bDof; float biDimVal;
+  float w0, w1, w2;
+  float* partial;
+  float* losspart;
+};
+
+template <int L, int KS>
+__global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A) {
+  using LY = Lay<L, KS>;
+  constexpr int MT = mtiles(KS);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const VnNet& net = A.net;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = net.P;
+  float* W1 = lds + LY::W1_OFF;
+  float* WH = lds + LY::WH_OFF;
+  float* BI = lds + LY::BI_OFF;
+  float* WO = lds + LY::WO_OFF;
+  float* sInt = lds + LY::MISC_OFF;
+  float* sR = sInt + TILE;
+  float* TA = lds + LY::T_OFF;
+  float* TB = TA + TROWS * TSW;
+  float* Gacc = lds + LY::T_OFF;
+
+  // ------------------------------------------------------------------ prologue: LDS images
+  {
+    const int d_in = net.d_in, H1 = net.H[1];
+    for (int i = tid; i < 8 * WS; i += NTHREADS) {
+      const int k = i / WS, pos = i % WS;
+      const int f = vfeat(pos & 63);
+      W1[i] = (k < d_in && pos < 64 && f < H1) ? A.theta[net.woff[1] + k * H1 + f] : 0.f;
+    }
+#pragma unroll
+    for (int l = 2; l <= L; ++l) {
+      const int Hin = net.H[l - 1], Hout = net.H[l];
+      float* Wl = WH + (l - 2) * LY::HPWS;
+      for (int i = tid; i < LY::HP * WS; i += NTHREADS) {
+        const int k = i / WS, pos = i % WS;
+        const int f = vfeat(pos & 63);
+        Wl[i] = (k < Hin && pos < 64 && f < Hout) ? A.theta[net.woff[l] + k * Hout + f] : 0.f;
+      }
+    }
+    for (int i = tid; i < L * 64; i += NTHREADS) {
+      const int l = i / 64 + 1, idx = i % 64;
+      const int mt = idx >> 4, g = (idx >> 2) & 3, r = idx & 3;       // [tile][g][i]
+      const int ks = 4 * mt + r, f = 4 * ks + g;
+      BI[i] = (ks < KS && f < net.H[l]) ? A.theta[net.boff[l] + f] : 0.f;
+    }
+    for (int i = tid; i < 4 * KS; i += NTHREADS) WO[i] = (i < net.H[L]) ? A.theta[net.woff[L + 1] + i] : 0.f;
+    for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
+  }
+  __syncthreads();
+
+  LaneC lc;
+  lc.g = lane >> 4;
+  lc.c = lane & 15;
+  lc.offF = lc.g * WS + lc.c;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    int fin = vfeat(16 * m + lc.c);
+    if (fin >= LY::HP) fin = 0;
+    lc.offB[m] = fin * WS + 4 * lc.g;
+  }
+  lc.twr = 4 * lc.g * TSW + wave * CW + lc.c;
+
+  // persistent weight-gradient accumulators
+  using W1G = WG<KS0, KS>;
+  using WHG = WG<KS, KS>;
+  using WOG = WG<KS, 1>;
+  f32x4 wacc1[W1G::TPW], wacch[L > 1 ? L - 1 : 1][WHG::TPW], wacco[WOG::TPW];
+#pragma unroll
+  for (int t = 0; t < W1G::TPW; ++t) wacc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < (L > 1 ? L - 1 : 1); ++l)
+#pragma unroll
+    for (int t = 0; t < WHG::TPW; ++t) wacch[l][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < WOG::TPW; ++t) wacco[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float bo = A.theta[net.boff[L + 1]];
+  const int q = A.integ_num;
+  const int TT = TILE / q;
+  const long ntiles_i = (A.nT + TILE - 1) / TILE;
+  const long ntiles = ntiles_i + (A.nB + TILE - 1) / TILE;
+  float loss_var = 0.f, loss_bc = 0.f, loss_ic = 0.f;
+  const long nI = A.nB - A.bDof;
+  const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
+  const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    asm volatile("" ::: "memory");                 // keep LDS fragment loads inside the loop
+    const bool interior = tile < ntiles_i;
+    const long r0 = (interior ? tile : tile - ntiles_i) * TILE;
+    const long nrows = interior ? A.nT : A.nB;
+    const int pt = wave * CW + lc.c;
+    const long row = r0 + pt;
+    const bool valid = row < nrows;
+
+    float xin[KS0], gin[KS0];
+    {
+      const float* Xp = interior ? A.X : A.Xb;
+#pragma unroll
+      for (int s = 0; s < KS0; ++s) {
+        const int f = 4 * s + lc.g;
+        xin[s] = (valid && f < net.d_in) ? Xp[row * net.d_in + f] : 0.f;
+        gin[s] = (valid && interior && f < net.dim) ? A.G[row * net.dim + f] : 0.f;
+      }
+    }
+
+    float a[L][KS], zd[L][KS];
+
+    // ---------------------------------------------------------------- layer 1 (also recomputed late)
+    auto layer1_raw = [&](const float (&xi)[KS0], const float (&gi)[KS0], f32x4 (&ov)[MT], f32x4 (&ot)[MT]) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ov[m] = *reinterpret_cast<const f32x4a*>(&BI[m * 16 + lc.g * 4]);
+        ot[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int s = 0; s < KS0; ++s) {
+        if (4 * s < net.d_in) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float wf = W1[4 * s * WS + lc.offF + 16 * m];
+            ov[m] = mfma16(wf, xi[s], ov[m]);
+            ot[m] = mfma16(wf, gi[s], ot[m]);
+          }
+        }
+      }
+    };
+
+    // ---------------------------------------------------------------- forward
+    f32x4 pv[MT], ptn[MT];
+    layer1_raw(xin, gin, pv, ptn);
+#pragma unroll
+    for (int l = 2; l <= L; ++l) {
+      const float* Wl = WH + (l - 2) * LY::HPWS;
+      f32x4 nv[MT], nt[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        nv[m] = *reinterpret_cast<const f32x4a*>(&BI[(l - 1) * 64 + m * 16 + lc.g * 4]);
+        nt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      auto zin = [&](int j) { return pv[j >> 2][j & 3]; };
+      auto zdin = [&](int j) { return ptn[j >> 2][j & 3]; };
+      auto stA = [&](int j) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * zin(j)); };
+      auto stB = [&](float e) { return __builtin_amdgcn_rcpf(1.0f + e); };
+      float wf[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = Wl[lc.offF + 16 * m];
+      float cs = stB(stA(0));
+      float cq = cs * (1.f - cs) * zdin(0);
+      a[l - 2][0] = cs;
+      zd[l - 2][0] = zdin(0);
+      float s1 = (KS > 1) ? stB(stA(1)) : 0.f;
+      float e2 = (KS > 2) ? stA(2) : 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float wn[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wn[m] = (ks + 1 < KS) ? Wl[4 * (ks + 1) * WS + lc.offF + 16 * m] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          nv[m] = mfma16(wf[m], cs, nv[m]);
+          nt[m] = mfma16(wf[m], cq, nt[m]);
+        }
+        float e3 = 0.f, s2 = 0.f, q1 = 0.f;
+        if (ks + 3 < KS) e3 = stA(ks + 3);
+        if (ks + 2 < KS) s2 = stB(e2);
+        if (ks + 1 < KS) {
+          const float zz = zdin(ks + 1);
+          q1 = s1 * (1.f - s1) * zz;
+          a[l - 2][ks + 1] = s1;
+          zd[l - 2][ks + 1] = zz;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cs = s1; cq = q1; s1 = s2; e2 = e3;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wf[m] = wn[m];
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { pv[m] = nv[m]; ptn[m] = nt[m]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      a[L - 1][ks] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * pv[ks >> 2][ks & 3]));
+      zd[L - 1][ks] = ptn[ks >> 2][ks & 3];
+    }
+    // output layer (VALU)
+    float u = 0.f, ud = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float wv = WO[4 * ks + lc.g];
+      const float av = a[L - 1][ks];
+      u += wv * av;
+      ud += wv * (av * (1.f - av) * zd[L - 1][ks]);
+    }
+    u += __shfl_xor(u, 16, 64);  ud += __shfl_xor(ud, 16, 64);
+    u += __shfl_xor(u, 32, 64);  ud += __shfl_xor(ud, 32, 64);
+    u += bo;
+
+    // ---------------------------------------------------------------- weak-form epilogue
+    float ubar = 0.f, udbar = 0.f;
+    if (interior) {
+      const int pq = pt % q;
+      const float dnt = A.time_dependent ? A.fedNt[pq] : 0.f;
+      const float wq = A.feW ? A.feW[pq] : 1.f;
+      float t = ud - dnt * u;
+      if (A.src) t -= (valid ? A.src[row] : 0.f) * A.feN[pq];
+      t *= wq;
+      if (!valid) t = 0.f;
+      const int seg = q < CW ? q : CW;
+      for (int o = 1; o < seg; o <<= 1) t += __shfl_xor(t, o, 64);
+      if (lc.g == 0 && (lc.c % seg) == 0) sInt[pt / seg] = t;
+      __syncthreads();
+      if (tid < TT) {
+        const int per = q / seg;
+        float R = 0.f;
+        for (int j = 0; j < per; ++j) R += sInt[tid * per + j];
+        const long k = r0 / q + tid;
+        float s = 0.f;
+        if (k < A.n_k) {
+          const float dj = A.detJv ? A.detJv[k] : A.detJ;
+          const float lv = dj * R * R;
+          loss_var += lv;
+          if (A.lossVec) A.lossVec[k] = lv;
+          s = 2.f * A.w2 * dj * R;
+        }
+        sR[tid] = s;
+      }
+      __syncthreads();
+      const float s = sR[pt / q] * wq;
+      udbar = s;
+      ubar = -dnt * s;
+    } else {
+      if (valid) {
+        const float e = u - A.label[row];
+        const bool isbc = row < A.bDof;
+        if (lc.g == 0) {
+          const float e2 = A.biDimVal * e * e;
+          if (isbc) loss_bc += e2; else loss_ic += e2;
+        }
+        ubar = (isbc ? cb : ci) * e;
+      }
+    }
+
+    // ---------------------------------------------------------------- backward
+    float zb[KS], zdb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float wv = WO[4 * ks + lc.g];
+      const float av = opaque(a[L - 1][ks]);
+      const float sp = av * (1.f - av);
+      const float ab = ubar * wv, adb = udbar * wv;
+      zdb[ks] = adb * sp;
+      zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[L - 1][ks];
+    }
+    {
+      float sv[1], st[1];
+      sv[0] = (lc.g == 0) ? ubar : 0.f;
+      st[0] = (lc.g == 0) ? udbar : 0.f;
+      wgrad_layer<KS, 1, false>(a[L - 1], zd[L - 1], sv, st, TA, TB, lc, wave, wacco);
+    }
+#pragma unroll
+    for (int l = L; l >= 2; --l) {
+      if (l == 2 && L > 2) {                                 // bring layer-1 activations back
+        float xr[KS0], gr[KS0];
+#pragma unroll
+        for (int s = 0; s < KS0; ++s) { xr[s] = opaque(xin[s]); gr[s] = opaque(gin[s]); }
+        f32x4 rv[MT], rt[MT];
+        layer1_raw(xr, gr, rv, rt);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          a[0][ks] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * rv[ks >> 2][ks & 3]));
+          zd[0][ks] = rt[ks >> 2][ks & 3];
+        }
+      }
+      wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2]);
+      const float* Wl = WH + (l - 2) * LY::HPWS;
+      f32x4 accv[MT], acct[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { accv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acct[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      float wf[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) wf[m] = Wl[lc.offB[m] + vpos(0, 0)];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float wn[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wn[m] = (ks + 1 < KS) ? Wl[lc.offB[m] + vpos(ks + 1, 0)] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          accv[m] = mfma16(wf[m], zb[ks], accv[m]);
+          acct[m] = mfma16(wf[m], zdb[ks], acct[m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) wf[m] = wn[m];
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float av = opaque(a[l - 2][ks]);
+        const float sp = av * (1.f - av);
+        const float ab = accv[ks >> 2][ks & 3], adb = acct[ks >> 2][ks & 3];
+        zdb[ks] = adb * sp;
+        zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[l - 2][ks];
+      }
+    }
+    wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1);
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  __syncthreads();
+  for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < NW; ++w) {                     // fixed order: bitwise reproducible sums
+    if (wave == w) {
+      wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
+#pragma unroll
+      for (int l = 2; l <= L; ++l)
+        wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
+      wgrad_flush<KS, 1, 1>(wacco, Gacc + LY::GO_OFF, lc, wave);
+    }
+    __syncthreads();
+  }
+  float* out = A.partial + (long)blockIdx.x * P;
+#pragma unroll
+  for (int l = 1; l <= L + 1; ++l) {
+    const int Hin = net.H[l - 1], Hout = net.H[l];
+    const int gs = (l == L + 1) ? 1 : LY::HP;
+    const int brow = (l == 1) ? 4 * KS0 : LY::HP;
+    const float* Gl = Gacc + ((l == 1) ? 0 : (l == L + 1) ? LY::GO_OFF : LY::G1_SZ + (l - 2) * LY::GH_SZ);
+    for (int i = tid; i < (Hin + 1) * Hout; i += NTHREADS) {
+      const int r = i / Hout, cc = i % Hout;
+      out[net.woff[l] + i] = Gl[(r < Hin ? r : brow) * gs + cc];
+    }
+  }
+  float v0 = loss_var, v1 = loss_bc, v2 = loss_ic;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v0 += __shfl_down(v0, o, 64);
+    v1 += __shfl_down(v1, o, 64);
+    v2 += __shfl_down(v2, o, 64);
+  }
+  __syncthreads();
+  if (lane == 0) { sInt[wave * 3 + 0] = v0; sInt[wave * 3 + 1] = v1; sInt[wave * 3 + 2] = v2; }
+  __syncthreads();
+  if (tid < 3) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += sInt[w * 3 + tid];
+    A.losspart[blockIdx.x * 3 + tid] = s;
+  }
+}
+
+template <int L, int KS>
+hipError_t launch_one(const VnFusedArgsD& a, int grid, hipStream_t s) {
+  using LY = Lay<L, KS>;
+  const size_t bytes = (size_t)LY::TOTAL * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)vn_fused16_kernel<L, KS>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((vn_fused16_kernel<L, KS>), dim3(grid), dim3(NTHREADS), bytes, s, a);
+  return hipGetLastError();
+}
+
+template <int L, int KS>
+size_t lds_one() {
+  return (size_t)Lay<L, KS>::TOTAL * sizeof(float);
+}
+
+int pick_ks(int hmax) {
+  if (hmax <= 20) return 5;
+  if (hmax <= 32) return 8;
+  if (hmax <= 52) return 13;
+  return 0;
+}
+
+}  // namespace
+
+#define VN_FUSED16_CASES(X) \
+  X(2, 5) X(3, 5) X(4, 5)   \
+  X(2, 8) X(3, 8) X(4, 8)   \
+  X(3, 13) X(4, 13) X(5, 13)
+
+size_t vn_fused16_lds_bytes(const VnNet& net) {
+  const int ks = pick_ks(net.hmax);
+#define X(LL, KK) if (net.L == LL && ks == KK) return lds_one<LL, KK>();
+  VN_FUSED16_CASES(X)
+#undef X
+  return 0;
+}
+
+bool vn_fused16_supported(const VnNet& net, int integ_num) {
+  if (net.d_in > 4 * KS0) return false;
+  if (integ_num < 1 || integ_num > TILE || (TILE % integ_num) != 0) return false;
+  const size_t b = vn_fused16_lds_bytes(net);
+  return b != 0 && b <= 160 * 1024;
+}
+
+hipError_t vn_fused16_launch(const VnFusedArgs& h, int grid, hipStream_t s) {
+  VnFusedArgsD a;
+  a.net = h.net; a.theta = h.theta; a.X = h.X; a.G = h.G; a.src = h.src; a.nT = h.nT; a.n_k = h.n_k;
+  a.integ_num = h.integ_num; a.feN = h.feN; a.fedNt = h.fedNt; a.feW = h.feW; a.detJv = h.detJv;
+  a.detJ = h.detJ; a.time_dependent = h.time_dependent; a.lossVec = h.lossVec; a.Xb = h.Xb;
+  a.label = h.label; a.nB = h.nB; a.bDof = h.bDof; a.biDimVal = h.biDimVal; a.w0 = h.w0; a.w1 = h.w1;
+  a.w2 = h.w2; a.partial = h.partial; a.losspart = h.losspart;
+  const int ks = pick_ks(h.net.hmax);
+#define X(LL, KK) if (h.net.L == LL && ks == KK) return launch_one<LL, KK>(a, grid, s);
+  VN_FUSED16_CASES(X)
+#undef X
+  return hipErrorInvalidValue;
+}

@@ -76,6 +76,10 @@ struct VnFusedArgs {
 bool vn_fused_supported(const VnNet& net, int integ_num);
 size_t vn_fused_lds_bytes(const VnNet& net);
 hipError_t vn_fused_launch(const VnFusedArgs& a, int grid, hipStream_t s);
+// 8-wave / 16x16x4 geometry of the same kernel (vn_fused16.hip)
+bool vn_fused16_supported(const VnNet& net, int integ_num);
+size_t vn_fused16_lds_bytes(const VnNet& net);
+hipError_t vn_fused16_launch(const VnFusedArgs& a, int grid, hipStream_t s);
 
 // ---- simple per-point evaluation kernels (float / double): vn_pointwise.hip --------------
 hipError_t vn_pointwise_forward_f32(const VnNet& net, const float* theta, const float* X, long n,

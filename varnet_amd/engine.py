@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get('VARNET_HIP_LIB', os.path.join(_HERE, 'libvarnet_hip.s
 VN_MAX_LAYERS = 6
 VN_MAX_WIDTH = 64
 VN_MAX_DIN = 8
-VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED = 0, 1, 2
+VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED, VN_KERNEL_FUSED16 = 0, 1, 2, 3
 
 
 class VnConfig(C.Structure):
