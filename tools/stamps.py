@@ -2,7 +2,7 @@
 import sys, os, numpy as np, torch
 sys.path.insert(0, '.')
 from varnet_amd import engine
-engine.LIB_PATH = os.path.join(os.path.dirname(engine.LIB_PATH), 'libvarnet_hip_stamps.so')
+engine.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), "libvarnet_hip_stamps.so")
 from varnet_amd.engine import VNEngine
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 50
@@ -11,7 +11,7 @@ n = n_k*q
 g = torch.Generator(device='cuda'); g.manual_seed(0)
 Input = torch.rand(n, d_in, device='cuda', generator=g)*2-1
 gcoef = torch.randn(n, dim, device='cuda', generator=g)
-eng = VNEngine(dim, d_in, widths, True, q)
+eng = VNEngine(dim, d_in, widths, True, q, kernel=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 eng.init_params(0)
 rng = np.random.default_rng(0)
 eng.set_fe_table(rng.uniform(0,1,q), rng.standard_normal(q))

@@ -171,6 +171,20 @@ __device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl,
   }
 }
 
+#ifdef VN_STAMPS
+#define STAMP(i)                                                          \
+  do {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    unsigned long long t_;                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    stamp_acc[i] += t_ - stamp_prev;                                      \
+    stamp_prev = t_;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 struct VnFusedArgsD {
   VnNet net;
   const float* theta;
@@ -183,6 +197,7 @@ struct VnFusedArgsD {
   float w0, w1, w2;
   float* partial;
   float* losspart;
+  unsigned long long* stamps;
 };
 
 template <int L, int KS>
@@ -268,6 +283,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
   const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
 
+#ifdef VN_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     asm volatile("" ::: "memory");                 // keep LDS fragment loads inside the loop
     const bool interior = tile < ntiles_i;
@@ -288,6 +307,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       }
     }
 
+    STAMP(0);
     float a[L][KS], zd[L][KS];
 
     // ---------------------------------------------------------------- layer 1 (also recomputed late)
@@ -368,6 +388,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       a[L - 1][ks] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * pv[ks >> 2][ks & 3]));
       zd[L - 1][ks] = ptn[ks >> 2][ks & 3];
     }
+    STAMP(1);
     // output layer (VALU)
     float u = 0.f, ud = 0.f;
 #pragma unroll
@@ -426,6 +447,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       }
     }
 
+    STAMP(2);
     // ---------------------------------------------------------------- backward
     float zb[KS], zdb[KS];
 #pragma unroll
@@ -441,7 +463,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       float sv[1], st[1];
       sv[0] = (lc.g == 0) ? ubar : 0.f;
       st[0] = (lc.g == 0) ? udbar : 0.f;
+      STAMP(3);
       wgrad_layer<KS, 1, false>(a[L - 1], zd[L - 1], sv, st, TA, TB, lc, wave, wacco);
+      STAMP(4);
     }
 #pragma unroll
     for (int l = L; l >= 2; --l) {
@@ -458,6 +482,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
         }
       }
       wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2]);
+      STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
       f32x4 accv[MT], acct[MT];
 #pragma unroll
@@ -488,11 +513,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
         zdb[ks] = adb * sp;
         zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[l - 2][ks];
       }
+      STAMP(6);
     }
     wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1);
+    STAMP(7);
   }
 
   // ------------------------------------------------------------------ epilogue
+#ifdef VN_STAMPS
+  if (A.stamps && blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 8; ++i) A.stamps[i] = stamp_acc[i];
+#endif
   __syncthreads();
   for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
   __syncthreads();
@@ -586,7 +617,7 @@ hipError_t vn_fused16_launch(const VnFusedArgs& h, int grid, hipStream_t s) {
   a.integ_num = h.integ_num; a.feN = h.feN; a.fedNt = h.fedNt; a.feW = h.feW; a.detJv = h.detJv;
   a.detJ = h.detJ; a.time_dependent = h.time_dependent; a.lossVec = h.lossVec; a.Xb = h.Xb;
   a.label = h.label; a.nB = h.nB; a.bDof = h.bDof; a.biDimVal = h.biDimVal; a.w0 = h.w0; a.w1 = h.w1;
-  a.w2 = h.w2; a.partial = h.partial; a.losspart = h.losspart;
+  a.w2 = h.w2; a.partial = h.partial; a.losspart = h.losspart; a.stamps = h.stamps;
   const int ks = pick_ks(h.net.hmax);
 #define X(LL, KK) if (h.net.L == LL && ks == KK) return launch_one<LL, KK>(a, grid, s);
   VN_FUSED16_CASES(X)
