@@ -177,3 +177,67 @@ def test_adam_trajectory_parity(kernel):
     eng.import_state(st)
     assert np.array_equal(eng.get_params(), p1) and eng.step == steps
     eng.close()
+
+
+STEADY = [
+    # d_in dim widths        integNum n_k nB  (time-independent: no IC rows, no dNt term; TFModel.py:537,646-650)
+    (1, 1, [20, 20],         4,       37, 2),
+    (2, 2, [20, 20, 20],     16,      50, 60),
+    (2, 2, [50, 50, 50],     16,      129, 33),
+    (2, 2, [7, 9],           36,      11, 20),
+]
+
+
+@pytest.mark.parametrize('kernel', [1, 0], ids=['generic', 'auto'])
+@pytest.mark.parametrize('case', STEADY)
+def test_steady_problem_parity(case, kernel):
+    from varnet_amd.engine import VNEngine
+    d_in, dim, widths, q, n_k, nB = case
+    rng = np.random.default_rng(7)
+    n = n_k * q
+    Input = rng.uniform(-1, 1, (n, d_in)).astype(np.float32)
+    gcoef = rng.standard_normal((n, dim)).astype(np.float32)
+    src = rng.standard_normal((n, 1)).astype(np.float32)
+    N1 = rng.uniform(0, 1, q).astype(np.float32)
+    integW = rng.uniform(0.5, 1, (1, q)).astype(np.float32) if q == 36 else None
+    biInput = rng.uniform(-1, 1, (nB, d_in)).astype(np.float32)
+    biLabel = rng.standard_normal((nB, 1)).astype(np.float32)
+    w = np.array([4.0, 0.0, 3.0])                                   # VarNet.py:1132: IC weight 0
+    eng = VNEngine(dim, d_in, widths, False, q, isSource=True, integWflag=integW is not None, kernel=kernel)
+    eng.init_params(seed=2)
+    flat = eng.get_params()
+    eng.set_fe_table(N1, np.zeros(q, np.float32), integW)
+    eng.set_interior(0, Input, gcoef, src, n_k=n_k, detJ=0.02)
+    eng.set_bic(biInput, biLabel, nB, 1.5)                          # every row is a boundary row
+    eng.set_weights(w)
+    ref, gref = og.loss_and_grad(
+        flat.astype(np.float64), d_in, widths, torch.float64, Input=Input.astype(np.float64),
+        gcoef=gcoef.astype(np.float64), source=src.astype(np.float64),
+        N=np.tile(N1, n_k).reshape(n, 1).astype(np.float64), dNt=np.zeros((n, 1)),
+        integW=None if integW is None else integW.astype(np.float64), intShape=[n_k, q], detJ=0.02,
+        detJvec=False, biInput=biInput.astype(np.float64), biLabel=biLabel.astype(np.float64), bDof=nB,
+        biDimVal=1.5, w=w, dim=dim, time_dependent=False, is_source=True, integWflag=integW is not None)
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy()
+    assert abs(g[eng.P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+    assert abs(g[eng.P + 2]) == 0.0                                  # ICloss is the constant 0
+    assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
+    eng.close()
+
+
+def test_engine_argument_errors():
+    from varnet_amd.engine import VNEngine, VNError
+    eng = VNEngine(1, 2, [5, 5], True, 16)
+    with pytest.raises(VNError):
+        eng.grad(0)                                                  # no data registered
+    with pytest.raises(VNError):
+        eng.lib.vn_params_set(eng.h, None, 3) and None or eng._ck(eng.lib.vn_params_set(eng.h, None, 3))
+    with pytest.raises(AssertionError):
+        eng.set_interior(0, np.zeros((17, 2), np.float32), np.zeros((17, 1), np.float32), n_k=1)
+    eng.close()
+    with pytest.raises(ValueError):
+        VNEngine(1, 2, [5], True, 16, activationFun='tanh')
+    with pytest.raises(ValueError):
+        VNEngine(1, 2, [500], True, 16)
