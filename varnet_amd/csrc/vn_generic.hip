@@ -377,36 +377,53 @@ __global__ __launch_bounds__(NTHREADS) void vn_seed_kernel(VnSeedArgs a) {
 }
 
 // grad[p] = sum over workgroup partials in a fixed order; block 0 also folds the loss partials.
-// A block owns 64 consecutive parameters; its 4 waves each sum every 4th partial (coalesced 256-B
-// rows), then the 4 sub-sums are added in wave order -> bitwise reproducible.
-__global__ __launch_bounds__(NTHREADS) void vn_reduce_kernel(const float* __restrict__ partial, int nparts, int P,
-                                                             const float* __restrict__ losspart, int nlp,
-                                                             long bDof, long nB, float w0, float w1, float w2,
-                                                             float* __restrict__ gradbuf) {
-  __shared__ float sub[4][64];
+// A block owns 64 consecutive parameters; its 16 waves each sum every 16th partial (coalesced 256-B
+// rows, 16 loads in flight per lane), then the 16 sub-sums are added in wave order -> bitwise
+// reproducible.
+constexpr int RED_GROUPS = 16;
+__global__ __launch_bounds__(64 * RED_GROUPS) void vn_reduce_kernel(const float* __restrict__ partial, int nparts,
+                                                                  int P, const float* __restrict__ losspart,
+                                                                  int nlp, long bDof, long nB, float w0, float w1,
+                                                                  float w2, float* __restrict__ gradbuf) {
+  __shared__ float sub[RED_GROUPS][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
   float acc = 0.f;
   if (p < P) {
-    for (int g = grp; g < nparts; g += 4) acc += partial[(long)g * P + p];
+    for (int g = grp; g < nparts; g += RED_GROUPS) acc += partial[(long)g * P + p];
   }
   sub[grp][lane] = acc;
   __syncthreads();
-  if (grp == 0 && p < P) gradbuf[p] = ((sub[0][lane] + sub[1][lane]) + sub[2][lane]) + sub[3][lane];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && losspart != nullptr) {
-    double tot[3] = {0.0, 0.0, 0.0};
-    for (int g = 0; g < nlp; ++g) {
-      tot[0] += (double)losspart[g * 3 + 0];
-      tot[1] += (double)losspart[g * 3 + 1];
-      tot[2] += (double)losspart[g * 3 + 2];
+  if (grp == 0 && p < P) {
+    float t = sub[0][lane];
+#pragma unroll
+    for (int j = 1; j < RED_GROUPS; ++j) t += sub[j][lane];
+    gradbuf[p] = t;
+  }
+  // loss scalars: wave 1 of block 0 folds the per-workgroup partials (lane-strided, then a fixed
+  // shuffle tree, in fp64)
+  if (blockIdx.x == 0 && grp == 1 && losspart != nullptr) {
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int g = lane; g < nlp; g += 64) {
+      t0 += (double)losspart[g * 3 + 0];
+      t1 += (double)losspart[g * 3 + 1];
+      t2 += (double)losspart[g * 3 + 2];
     }
-    const double var = tot[0];
-    const double bc = bDof > 0 ? tot[1] / (double)bDof : 0.0;             // reduce_mean, TFModel.py:645
-    const double ic = (nB - bDof) > 0 ? tot[2] / (double)(nB - bDof) : 0.0; // TFModel.py:648
-    gradbuf[P + 0] = (float)(w0 * bc + w1 * ic + w2 * var);               // TFModel.py:666
-    gradbuf[P + 1] = (float)bc;
-    gradbuf[P + 2] = (float)ic;
-    gradbuf[P + 3] = (float)var;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      t0 += __shfl_down(t0, o, 64);
+      t1 += __shfl_down(t1, o, 64);
+      t2 += __shfl_down(t2, o, 64);
+    }
+    if (lane == 0) {
+      const double var = t0;
+      const double bc = bDof > 0 ? t1 / (double)bDof : 0.0;               // reduce_mean, TFModel.py:645
+      const double ic = (nB - bDof) > 0 ? t2 / (double)(nB - bDof) : 0.0; // TFModel.py:648
+      gradbuf[P + 0] = (float)(w0 * bc + w1 * ic + w2 * var);             // TFModel.py:666
+      gradbuf[P + 1] = (float)bc;
+      gradbuf[P + 2] = (float)ic;
+      gradbuf[P + 3] = (float)var;
+    }
   }
 }
 
@@ -473,7 +490,7 @@ hipError_t vn_seed_launch(const VnSeedArgs& a, int grid, hipStream_t s) {
 hipError_t vn_reduce_launch(const float* partial, int nparts, int P, const float* losspart, int nlossparts,
                             long bDof, long nB, float w0, float w1, float w2, float* gradbuf, hipStream_t s) {
   const int grid = (P + 63) / 64;
-  hipLaunchKernelGGL(vn_reduce_kernel, dim3(grid > 0 ? grid : 1), dim3(NTHREADS), 0, s, partial, nparts, P,
+  hipLaunchKernelGGL(vn_reduce_kernel, dim3(grid > 0 ? grid : 1), dim3(64 * RED_GROUPS), 0, s, partial, nparts, P,
                      losspart, nlossparts, bDof, nB, w0, w1, w2, gradbuf);
   return hipGetLastError();
 }
