@@ -64,8 +64,9 @@ class OracleEngine:
                    None if integW is None else np.reshape(integW, -1).astype(self.dtype))
 
     def set_interior(self, batch, Input, gcoef, source=None, n_k=None, detJ=1.0, N_rows=None, dNt_rows=None):
-        self.batches[batch] = (Input.numpy().copy(), gcoef.numpy().copy(),
-                               None if source is None else source.numpy().copy(), int(n_k), detJ)
+        npy = lambda t: None if t is None else (t.numpy().copy() if isinstance(t, torch.Tensor) else np.array(t, dtype=float))
+        dj = npy(detJ) if isinstance(detJ, torch.Tensor) or np.size(detJ) > 1 else float(np.reshape(detJ, -1)[0])
+        self.batches[batch] = (npy(Input), npy(gcoef), npy(source), int(n_k), dj, npy(N_rows), npy(dNt_rows))
 
     def set_bic(self, biInput, biLabel, bDof, biDimVal):
         self.bic = (biInput.numpy().copy(), biLabel.numpy().copy(), int(bDof), float(biDimVal))
@@ -79,12 +80,14 @@ class OracleEngine:
         return self.gradbuf
 
     def _eval(self, batch):
-        Input, gcoef, src, n_k, detJ = self.batches[batch]
+        Input, gcoef, src, n_k, detJ, Nr, dNtr = self.batches[batch]
         biInput, biLabel, bDof, biDimVal = self.bic
         N, dNt, W = self.fe
         q = self.integNum
+        Nrow = np.tile(N, n_k) if Nr is None else Nr.reshape(-1)
+        dNtrow = np.tile(dNt, n_k) if dNtr is None else dNtr.reshape(-1)
         return tr.loss_and_grad(self.theta.astype(np.float64), self.inpDim, self.layerWidth, self.dim,
-                                Input, gcoef, src if self.isSource else None, np.tile(N, n_k), np.tile(dNt, n_k),
+                                Input, gcoef, src if self.isSource else None, Nrow, dNtrow,
                                 W if self.integWflag else None, n_k, q, detJ, biInput, biLabel, bDof, biDimVal,
                                 self.w, self.td)
 

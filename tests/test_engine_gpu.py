@@ -241,3 +241,48 @@ def test_engine_argument_errors():
         VNEngine(1, 2, [5], True, 16, activationFun='tanh')
     with pytest.raises(ValueError):
         VNEngine(1, 2, [500], True, 16)
+
+
+@pytest.mark.parametrize('q,widths', [(16, [20, 20, 20]), (64, [50, 50, 50]), (36, [10, 20])])
+def test_per_row_tables_and_detjvec_parity(q, widths):
+    """Non-uniform supports: per-row N / dNt arrays and a per-test-function detJ
+    (VarNetUtility.py:506-523, TFModel.py:662-663) -- generic kernels, fp64 oracle."""
+    from varnet_amd.engine import VNEngine
+    d_in, dim = (3, 2) if q != 16 else (2, 1)
+    n_k, nB, bDof = 45, 31, 17
+    rng = np.random.default_rng(11)
+    n = n_k * q
+    Input = rng.uniform(-1, 1, (n, d_in)).astype(np.float32)
+    gcoef = rng.standard_normal((n, dim)).astype(np.float32)
+    src = rng.standard_normal((n, 1)).astype(np.float32)
+    Nrow = rng.uniform(0, 1, (n, 1)).astype(np.float32)
+    dNtrow = rng.standard_normal((n, 1)).astype(np.float32)
+    detJ = rng.uniform(0.01, 0.05, (n_k, 1)).astype(np.float32)
+    integW = rng.uniform(0.5, 1, (1, q)).astype(np.float32) if q == 36 else None
+    biInput = rng.uniform(-1, 1, (nB, d_in)).astype(np.float32)
+    biLabel = rng.standard_normal((nB, 1)).astype(np.float32)
+    w = np.array([2.0, 3.0, 4.0])
+    eng = VNEngine(dim, d_in, widths, True, q, isSource=True, integWflag=integW is not None)
+    eng.init_params(seed=5)
+    flat = eng.get_params()
+    eng.set_fe_table(np.zeros(q, np.float32), np.zeros(q, np.float32), integW)   # tables unused: per-row data
+    eng.set_interior(0, Input, gcoef, src, n_k=n_k, detJ=detJ, N_rows=Nrow, dNt_rows=dNtrow)
+    eng.set_bic(biInput, biLabel, bDof, 2.0)
+    eng.set_weights(w)
+    ref, gref = og.loss_and_grad(
+        flat.astype(np.float64), d_in, widths, torch.float64, Input=Input.astype(np.float64),
+        gcoef=gcoef.astype(np.float64), source=src.astype(np.float64), N=Nrow.astype(np.float64),
+        dNt=dNtrow.astype(np.float64), integW=None if integW is None else integW.astype(np.float64),
+        intShape=[n_k, q], detJ=detJ.astype(np.float64), detJvec=True, biInput=biInput.astype(np.float64),
+        biLabel=biLabel.astype(np.float64), bDof=bDof, biDimVal=2.0, w=w, dim=dim, time_dependent=True,
+        is_source=True, integWflag=integW is not None)
+    out, lv = eng.eval_loss(0, lossVec=True)
+    assert abs(out[0] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+    assert np.max(np.abs(lv.cpu().numpy() - ref['lossVec'].reshape(-1))) <= LVEC_RTOL * np.max(np.abs(ref['lossVec']))
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy()
+    assert abs(g[eng.P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+    assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
+    eng.close()

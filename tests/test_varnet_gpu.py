@@ -156,3 +156,36 @@ def test_fullsize_sampled_oracle_check(cfg3):
     P = eng.P
     assert abs(g[P] - ref['loss']) <= 4e-5 * abs(ref['loss'])
     assert np.max(np.abs(g[:P] - gref)) <= 1e-4 * np.max(np.abs(gref))
+
+
+@pytest.mark.parametrize('suppFactor', [1.0, 0.5])
+def test_optimal_sampling_on_device(tmp_path, suppFactor):
+    """smpScheme='optimal' end to end on the GPU: residual field from vn_residual, re-drawn set on
+    the fused path (equal supports) or the per-row/detJvec generic path (scaled supports)."""
+    np.random.seed(3)
+    vn = op1dt([20, 20], 10, 16, cEx=cExact)
+    fd = vn.fixData
+    nt0 = fd.nt0
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], smpScheme='optimal', epochNum=40, saveFreq=20,
+                   verbose=False, trainUpdelay=10, tolUpd=10.0, frac=0.5, suppFactor=suppFactor)
+    assert res.inpIter == [10]
+    assert fd.nt == nt0 + int(np.ceil(0.5 * nt0)) and fd.detJvec == (suppFactor != 1.0)
+    assert vn.engine.step == 30 and np.isfinite(res.loss).all()
+    assert res.loss[-1] < res.loss[10]
+    # the device loss on the re-drawn set agrees with the oracle on the same arrays
+    d = vn.tData.mor[0]
+    vn.tData.activate()
+    vn.tData.select_mor(0)
+    vn.engine.set_weights([1.0, 1.0, 1.0])
+    out, _ = vn.engine.eval_loss(0)
+    flat = vn.engine.get_params().astype(np.float64)
+    Nr, dNxr, dNtr = fd.rows()
+    ref, _ = og.loss_and_grad(
+        flat, 2, [20, 20], torch.float64, Input=d['Input'].cpu().numpy().astype(np.float64),
+        gcoef=d['gcoef'].cpu().numpy().astype(np.float64), source=None, N=Nr, dNt=dNtr, integW=None,
+        intShape=[fd.nt, fd.integNum], detJ=np.reshape(fd.detJ, (-1, 1)) if fd.detJvec else float(fd.detJ),
+        detJvec=bool(fd.detJvec), biInput=d['biInput'].cpu().numpy().astype(np.float64),
+        biLabel=d['biLabel'].cpu().numpy().astype(np.float64).reshape(-1, 1), bDof=fd.bDofsum,
+        biDimVal=float(fd.biDimVal), w=np.ones(3), dim=1, time_dependent=True, is_source=False, integWflag=False)
+    assert abs(out[0] - ref['loss']) <= 1e-4 * abs(ref['loss'])
+    vn.engine.close()

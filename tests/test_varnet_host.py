@@ -218,3 +218,59 @@ def test_constructor_errors():
         vn.train(None, epochNum=1)
     with pytest.raises(ValueError):
         vn.train('/tmp/x', weight=[1., 1.], epochNum=1)
+
+
+def test_rejection_sampling_follows_density():
+    """Accepted samples follow func/max(func): density ~ x^2 on [0,1] has mean 3/4."""
+    from varnet_amd.utility import UF
+    uf = UF()
+    np.random.seed(0)
+    f = lambda x=None: (np.linspace(0, 1, 200).reshape(-1, 1) if x is None else x) ** 2
+    smp = uf.rejectionSampling(f, lambda: np.random.uniform(0, 1, (200, 1)), 3000)
+    assert smp.shape == (3000, 1) and abs(smp.mean() - 0.75) < 0.02
+    segs = uf.listSegment(np.arange(10).reshape(10, 1), [3, 4])
+    assert [len(x) for x in segs] == [3, 4, 3]
+    two = uf.rejectionSampling(lambda x=None: np.ones((20, 1)) if x is None else np.ones((len(x), 1)),
+                               lambda: np.random.uniform(0, 1, (20, 1)), [5, 7], [8, 12])
+    assert two.shape == (12, 1)
+
+
+@pytest.mark.parametrize('addTrainPts,suppFactor', [(True, 1.0), (True, 0.5), (False, 1.0)])
+def test_optimal_sampling_training(tmp_path, addTrainPts, suppFactor):
+    """smpScheme='optimal' (VarNet.py:1385-1421, 1696-1966): after the convergence test fires the
+    training set is re-drawn from the residual field, fixed data follow updateOptimData, variables
+    are re-initialised and the weights re-derived."""
+    np.random.seed(1)
+    vn = op1dt(layerWidth=[6, 6], discNum=6, tDiscNum=8, cEx=cExact)
+    fd = vn.fixData
+    nt0, q = fd.nt0, fd.integNum
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], smpScheme='optimal', epochNum=12, saveFreq=6,
+                   verbose=False, trainUpdelay=5, tolUpd=10.0, frac=0.5, addTrainPts=addTrainPts,
+                   suppFactor=suppFactor, adjustWeight=True)
+    assert res.inpIter == [5]                                      # one update (multiTrainUpd=False)
+    td = vn.tData
+    if addTrainPts:
+        nt1 = int(np.ceil(0.5 * nt0))
+        assert fd.nt == nt0 + nt1 and fd.nT == fd.nt * q
+        assert list(fd.biDof) == [b + int(np.ceil(0.5 * b)) for b in fd.biDof0]
+        assert td.mor[0]['Input'].shape[0] == fd.nT
+        assert td.mor[0]['biInput'].shape[0] == sum(fd.biDof)
+    else:
+        assert fd.nt == nt0 and td.mor[0]['Input'].shape[0] == nt0 * q
+    if suppFactor != 1.0:
+        assert fd.detJvec and np.shape(fd.detJ) == (fd.nt, 1)
+        nt1 = fd.nt - nt0
+        np.testing.assert_allclose(fd.detJ[:nt1, 0], fd.detJ[-1, 0] * 0.5 ** fd.feDim)
+        Nr, dNxr, dNtr = fd.rows()
+        assert Nr.shape == (fd.nT, 1)
+        np.testing.assert_allclose(dNtr[:nt1 * q], np.tile(fd.dNt, nt1).reshape(-1, 1) / 0.5)
+        assert td.mor[0]['N_rows'] is not None and td.mor[0]['detJ'].shape[0] == fd.nt
+        # supports of the added test functions are half as wide
+        Inp = td.mor[0]['Input'].numpy().reshape(fd.nt, q, 2)
+        assert np.ptp(Inp[0, :, 0]) < 0.6 * np.ptp(Inp[-1, :, 0])
+    else:
+        assert not fd.detJvec
+    assert vn.engine.step == 7                                     # re-initialised at epoch 5, then 7 more steps
+    assert np.isfinite(res.loss).all()
+    # weights were re-derived with 5x on BC/IC (adjustWeight) and renormalised to 1e6
+    np.testing.assert_allclose(res.loss[5], 1e6, rtol=1e-6)

@@ -188,8 +188,8 @@ class Domain1D(Domain):
         rfrac = min(max(rfrac, 0), 1)
         lim = self.lim
         he = (lim[1] - lim[0]) / (discNum + 1)                      # shape (1,), as the reference
-        tol = he if discTol is None else float(np.reshape(discTol, -1)[0])
-        c = _axis_nodes(lim[0], lim[1], discNum, rfrac, sortflg, tol)
+        tol = float(he[0]) if discTol is None else float(np.reshape(discTol, -1)[0])
+        c = _axis_nodes(float(lim[0, 0]), float(lim[1, 0]), discNum, rfrac, sortflg, tol)
         coordinates = np.reshape(c, [discNum, 1])
         bdof = np.ones(2, dtype=int)
         bCoordinates = np.reshape(lim, [2, 1, 1])

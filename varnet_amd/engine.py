@@ -222,23 +222,30 @@ class VNEngine:
 
     def set_interior(self, batch, Input, gcoef, source=None, n_k=None, detJ=1.0, N_rows=None,
                      dNt_rows=None):
+        torch = self.torch
+
+        def flat(a):
+            if a is None:
+                return None
+            if isinstance(a, torch.Tensor):
+                return self.dev(a.reshape(-1))
+            return self.dev(np.reshape(a, -1))
+
         Input = self.dev(Input)
         gcoef = self.dev(gcoef)
-        source = None if source is None else self.dev(np.reshape(source, -1) if isinstance(source, np.ndarray) else source.reshape(-1))
+        source = flat(source)
         nT = Input.shape[0]
         if n_k is None:
             n_k = nT // self.integNum
         assert n_k * self.integNum == nT, 'rows must be whole test functions'
         assert Input.shape[1] == self.inpDim and gcoef.shape == (nT, self.dim)
-        detJv = None
-        if np.size(detJ) > 1:
-            detJv = self.dev(np.reshape(detJ, -1))
+        detJv, detJ_s = None, 0.0
+        if isinstance(detJ, torch.Tensor) or np.size(detJ) > 1:
+            detJv = flat(detJ)
             assert detJv.numel() == n_k
-            detJ_s = 0.0
         else:
             detJ_s = float(np.reshape(detJ, -1)[0]) if not np.isscalar(detJ) else float(detJ)
-        Nr = None if N_rows is None else self.dev(np.reshape(N_rows, -1))
-        dNr = None if dNt_rows is None else self.dev(np.reshape(dNt_rows, -1))
+        Nr, dNr = flat(N_rows), flat(dNt_rows)
         self._keep[('int', batch)] = (Input, gcoef, source, detJv, Nr, dNr)
         self._ck(self.lib.vn_set_interior(self.h, batch, _ptr(Input), _ptr(gcoef), _ptr(source), n_k,
                                           _ptr(detJv), detJ_s, _ptr(Nr), _ptr(dNr)))

@@ -117,6 +117,65 @@ class UF:
                 raise ValueError('\'x\' and \'y\' must be the same length!')
         return 0.5 * np.abs(np.dot(x, np.roll(y, 1)) - np.dot(y, np.roll(x, 1)))
 
+    # -- segmentation / rejection sampling (UtilityFunc.py:342-451): host-side sampling policy of
+    #    smpScheme='optimal' --------------------------------------------------------------
+    def listSegment(self, vec, segdof, func=None):
+        """Cut `vec` into consecutive segments of `segdof` rows (a trailing remainder becomes one
+        more segment); optionally map `func(segment, index)` over them."""
+        n = len(vec)
+        if segdof is None:
+            return [vec] if func is None else [func(vec, 0)]
+        if isinstance(segdof, numbers.Number):
+            segdof = [segdof]
+        segdof = [int(v) for v in segdof]
+        if segdof[-1] > n:
+            raise ValueError('\'segdof\' is out of bound!')
+        out, ind, i = [], 0, 0
+        for i, cnt in enumerate(segdof):
+            seg = vec[ind:ind + cnt]
+            out.append(seg if func is None else func(seg, i))
+            ind += cnt
+        if ind < n:
+            seg = vec[ind:]
+            out.append(seg if func is None else func(seg, i))
+        return out
+
+    def rejectionSampling(self, func, smpfun, dof, dofT=None):
+        """
+        Draw `dof[i]` samples per segment with acceptance probability func/max(func over the
+        reference grid): `func()` gives the values on the fixed grid, `func(samples)` on
+        candidates produced by `smpfun()` (UtilityFunc.py:342-404).
+        """
+        if isinstance(dof, numbers.Number):
+            if dofT is not None:
+                raise ValueError('\'dofT\' must be None for scalar \'dof\'')
+            dof = [dof]
+        dof = [int(v) for v in dof]
+        m = len(dof)
+        if m > 1 and dofT is None:
+            raise ValueError('\'dofT\' must be provided when \'dof\' is a list!')
+        fmax = self.listSegment(func(), dofT, lambda x, i: np.max(x))
+        kept = [[] for _ in range(m)]
+        ns = [0] * m
+        again = True
+        while again:
+            samples = smpfun()
+            smpList = self.listSegment(samples, dofT)
+            val = func(samples)
+
+            def accept(v, i):
+                u = np.random.uniform(size=[len(v), 1])
+                return np.reshape(u < (v / fmax[i]), len(v))
+
+            ind = self.listSegment(val, dofT, accept)
+            again = False
+            for i in range(m):
+                kept[i] = self.vstack([kept[i], smpList[i][ind[i]]])
+                ns[i] += int(np.sum(ind[i]))
+                if ns[i] < dof[i]:
+                    again = True
+        return np.vstack([kept[i][:dof[i], :] for i in range(m)])
+
     def nodeNum(self, x, val):
         """Index of the entry of x closest to each value in val."""
         x = np.reshape(np.asarray(x, dtype=float), -1)

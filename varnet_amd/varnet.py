@@ -14,7 +14,7 @@ constructor and `train / evaluate / residual / loadModel` surface
                                                     gradient over RCCL (torch.distributed)
   loss read back every step (VarNetUtility.py:1044) accumulated on device, read once per epoch
 
-Out of scope here: modelId='RNN', smpScheme='optimal', updateWeights, plots.
+Out of scope here: modelId='RNN', updateWeights, plots.
 """
 import math
 import os
@@ -112,6 +112,7 @@ class FIXData:
         fe = FE(self.feDim, self.integPnum)
         integNum, detJ, delta, integW, N, dN = fe.basisTable(self.hVec)
         self.integNum, self.biDof = integNum, biDof
+        self.segments, self.detJvec = None, False
         self.nt, self.nT = self.nt0, self.nt0 * integNum
         self.delta, self.integW, self.detJ = delta, integW, detJ
         self.N = N
@@ -119,10 +120,44 @@ class FIXData:
         self.dNt = dN[:, self.dim] if self.timeDependent else np.zeros(integNum)
 
     def rows(self, nt=None):
-        """Tiled [nT,1], [nT,dim], [nT,1] forms of N, dNx, dNt (what the reference stores)."""
+        """Tiled [nT,1], [nT,dim], [nT,1] forms of N, dNx, dNt (what the reference stores).  After
+        `updateOptimData` with a support scaling the rows of the added (optimal) test functions
+        come first and use their own tables (VarNetUtility.py:506-523)."""
+        if getattr(self, 'segments', None):
+            Ns, dNxs, dNts = [], [], []
+            for cnt, N, dNx, dNt in self.segments:
+                Ns.append(np.tile(N.reshape(-1, 1), (cnt, 1)))
+                dNxs.append(np.tile(dNx, (cnt, 1)))
+                dNts.append(np.tile(dNt.reshape(-1, 1), (cnt, 1)))
+            return np.vstack(Ns), np.vstack(dNxs), np.vstack(dNts)
         nt = self.nt if nt is None else nt
         return (np.tile(self.N.reshape(-1, 1), (nt, 1)), np.tile(self.dNx, (nt, 1)),
                 np.tile(self.dNt.reshape(-1, 1), (nt, 1)))
+
+    def updateOptimData(self, frac, suppFactor):
+        """
+        Fixed data after `ceil(frac*nt0)` residual-driven test functions were ADDED in front of
+        the uniform ones (VarNetUtility.py:466-545): new nt/nT/biDof/bDofsum; with a support scaling
+        (`suppFactor != 1`) the added test functions get their own element sizes, so `detJ`
+        becomes a per-test-function vector (`detJvec=True`) and N/dN per-row.
+        """
+        if self.nt > self.nt0:
+            return
+        nt0 = self.nt0
+        nt1 = math.ceil(frac * nt0)
+        scaled = np.abs(suppFactor - 1.0) > 1.e-15
+        self.nt = nt0 + nt1
+        self.nT = self.nt * self.integNum
+        if scaled:
+            fe = FE(self.feDim, self.integPnum)
+            _, detJ1, _, _, N1, dN1 = fe.basisTable(suppFactor * self.hVec)
+            dNt1 = dN1[:, self.dim] if self.timeDependent else np.zeros(self.integNum)
+            self.segments = [(nt1, N1, dN1[:, 0:self.dim], dNt1), (nt0, self.N, self.dNx, self.dNt)]
+            self.detJ = np.vstack([detJ1 * np.ones([nt1, 1]), self.detJ * np.ones([nt0, 1])])
+            self.detJvec = True
+        biDof = [b + math.ceil(frac * b) for b in self.biDof0]
+        self.biDof = biDof
+        self.bDofsum = int(np.sum(biDof[:-1])) if self.timeDependent else int(np.sum(biDof))
 
 
 # ======================================================================================
@@ -211,6 +246,8 @@ class ManageTrainData:
         self.mor = mor_data                      # list (per MOR batch) of dicts of device tensors
         fd = vn.fixData
         self.nt, self.integNum = fd.nt, fd.integNum
+        # snapshot of the fixed data this set was built with (the trainer may later re-sample)
+        self.detJ, self.bDofsum, self.biDimVal = fd.detJ, fd.bDofsum, fd.biDimVal
         puNum = vn.world
         if batchNum is None and batchLen is None:
             batchNum = 1
@@ -237,22 +274,21 @@ class ManageTrainData:
     def _register(self):
         eng, q = self.vn.engine, self.integNum
         torch = eng.torch
-        fd = self.vn.fixData
-        self._held = {}
         for mb, d in enumerate(self.mor):
             for bi in range(self.batchNum):
                 n0, n1 = self.block(bi)
                 if self.shuffled:
                     tf = torch.as_tensor(self.batchInd[n0:n1], device=eng.device, dtype=torch.long)
                     rows = (tf[:, None] * q + torch.arange(q, device=eng.device)[None, :]).reshape(-1)
-                    Inp = d['Input'].index_select(0, rows)
-                    gc = d['gcoef'].index_select(0, rows)
-                    src = None if d['source'] is None else d['source'].index_select(0, rows)
+                    pick = lambda t: None if t is None else t.index_select(0, rows)
+                    pick_k = lambda t: None if t is None else t.index_select(0, tf)
                 else:
-                    Inp = d['Input'][n0 * q:n1 * q]
-                    gc = d['gcoef'][n0 * q:n1 * q]
-                    src = None if d['source'] is None else d['source'][n0 * q:n1 * q]
-                eng.set_interior(self.engine_batch(mb, bi), Inp, gc, src, n_k=n1 - n0, detJ=fd.detJ)
+                    pick = lambda t: None if t is None else t[n0 * q:n1 * q]
+                    pick_k = lambda t: None if t is None else t[n0:n1]
+                detJ = pick_k(d.get('detJ'))
+                eng.set_interior(self.engine_batch(mb, bi), pick(d['Input']), pick(d['gcoef']), pick(d['source']),
+                                 n_k=n1 - n0, detJ=self.detJ if detJ is None else detJ,
+                                 N_rows=pick(d.get('N_rows')), dNt_rows=pick(d.get('dNt_rows')))
 
     def shuffleTrainData(self):
         """Permute the test-function order (VarNetUtility.py:957-1017); every rank draws the
@@ -261,10 +297,13 @@ class ManageTrainData:
         self.shuffled = True
         self._register()
 
+    def activate(self):
+        """(Re-)register this set's batches with the engine (after another set used it)."""
+        self._register()
+
     def select_mor(self, mb):
         d = self.mor[mb]
-        fd = self.vn.fixData
-        self.vn.engine.set_bic(d['biInput'], d['biLabel'], fd.bDofsum, fd.biDimVal)
+        self.vn.engine.set_bic(d['biInput'], d['biLabel'], self.bDofsum, self.biDimVal)
 
 
 # ======================================================================================
@@ -384,7 +423,7 @@ class VarNet:
         test functions ordered space-major, time-minor.
         """
         if smpScheme == 'optimal':
-            raise NotImplementedError('smpScheme=\'optimal\' (residual-driven resampling) is a later-round item')
+            return self.optTrainPoints(frac, addTrainPts, suppFactor)
         rfrac = frac if smpScheme == 'random' else 0.
         dim, PDE, fd = self.dim, self.PDE, self.fixData
         domain = PDE.domain
@@ -413,6 +452,116 @@ class VarNet:
             Input = Coord
         biInput, biDof = self.biTrainPoints(mesh, t_coord)
         return Input, [], biInput, biDof
+
+    def optTrainPoints(self, frac=0.25, addTrainPts=True, suppFactor=1.0):
+        """
+        Residual-driven ("optimal") training points (VarNet.py:1696-1868): keep (or thin) the uniform
+        test functions and draw the others by rejection sampling with acceptance probability
+        |PDE residual| / max|residual on the uniform grid|; optionally shrink the support of the
+        added ones by `suppFactor`.  The residual field comes from the device (`vn_residual`).
+        """
+        dim, PDE, fd = self.dim, self.PDE, self.fixData
+        td, domain = PDE.timeDependent, PDE.domain
+        feDim, integNum, nt, nT, hVec, delta = fd.feDim, fd.integNum, fd.nt0, fd.nT, fd.hVec, fd.delta
+        frac2 = 1 if addTrainPts else (1 - frac) ** (1 / feDim)
+        if td:
+            tDiscNum2 = math.ceil(frac2 * self.tDiscNum)
+            _, t_coord = self.timeDisc(tDiscNum2)
+        else:
+            tDiscNum2, t_coord = 1, []
+        discNum2 = [math.ceil(frac2 * d) for d in self.discNum]
+        mesh = domain.getMesh(discNum2, self.bDiscNum)
+        input2 = uf.pairMats(mesh.coordinates, t_coord)
+        nt1 = math.ceil(frac * nt) if addTrainPts else nt - mesh.dof * tDiscNum2
+        scaled = np.abs(suppFactor - 1.0) > 1.e-15
+        tole = suppFactor * hVec[:dim] if scaled else None
+        tolt = suppFactor * hVec[-1] if (scaled and td) else None
+
+        def resfun(inpuT=None):
+            _, resVec, _, _ = self.residual(inpuT)
+            return np.abs(resVec)
+
+        def smpfun():
+            tc = self.timeDisc(rfrac=1, sortflg=False, discTol=tolt)[1] if td else []
+            m = domain.getMesh(self.discNum, self.bDiscNum, rfrac=1, sortflg=False, discTol=tole)
+            return uf.pairMats(m.coordinates, tc)
+
+        input1 = uf.rejectionSampling(resfun, smpfun, nt1)
+        if addTrainPts:
+            nt = nt1 + nt
+            nT = nt * integNum
+        inpuT = np.vstack([input1, input2])
+        coord = inpuT[:, :dim]
+        if td and not scaled:                                        # sort by time only for equal supports
+            t_coord = inpuT[:, dim:dim + 1]
+            ind = np.reshape(np.argsort(t_coord, axis=0), nt)
+            coord, t_coord = coord[ind], t_coord[ind]
+        elif td:
+            t_coord = inpuT[:, dim:dim + 1]
+        biInput, biDof, _, _ = self.optBiTrainPoints(frac, addTrainPts)
+
+        he = np.reshape(hVec[:dim], -1)
+        suppScale = 1.0
+        if scaled:
+            suppScale = np.ones([nt, 1])
+            suppScale[:nt1, :] = suppFactor
+        Coord = np.empty([nT, dim])
+        for d in range(dim):
+            Coord[:, d] = (np.reshape(coord[:, d], [nt, 1]) + he[d] * delta[d, :] * suppScale).reshape(nT)
+        if td:
+            tC = t_coord + float(np.reshape(hVec[-1], -1)[0]) * delta[-1, :] * suppScale
+            Input = np.concatenate([Coord, tC.reshape(nT, 1)], axis=1)
+        else:
+            Input = Coord
+        if addTrainPts:
+            fd.updateOptimData(frac, suppFactor)
+        return Input, [], biInput, biDof
+
+    def optBiTrainPoints(self, frac=0.25, addTrainPts=True):
+        """Optimal boundary / initial points (VarNet.py:1872-1966): rejection sampling per
+        Dirichlet edge and for the initial slice with density (model - label)^2."""
+        dim, PDE, fd = self.dim, self.PDE, self.fixData
+        td, domain = PDE.timeDependent, PDE.domain
+        biDof = fd.biDof0
+        frac2 = 1 if addTrainPts else (1 - frac) ** (1 / (fd.feDim - 1))
+        t_coord = self.timeDisc(math.ceil(frac2 * self.tDiscNum))[1] if td else []
+        discNum2 = [math.ceil(frac2 * d) for d in self.discNum]
+        bDisc = self.bDiscNum
+        bDisc2 = math.ceil(frac2 * bDisc) if isinstance(bDisc, (int, float)) else bDisc
+        mesh = domain.getMesh(discNum2, bDisc2)
+        biInput2, biDof2 = self.biTrainPoints(mesh, t_coord)
+        if addTrainPts:
+            biDof1 = [math.ceil(frac * b) for b in biDof]
+        else:
+            biDof1 = list(np.array(biDof) - np.array(biDof2))
+
+        def resfun(biInpuT=None):
+            if biInpuT is None:
+                biInpuT = fd.uniform_biInput
+            val = self._model_on(biInpuT)
+            return (val - self.biTrainData(biInpuT, biDof)) ** 2
+
+        def smpfun():
+            tc = self.timeDisc(rfrac=1, sortflg=False)[1] if td else []
+            m = domain.getMesh(self.discNum, self.bDiscNum, rfrac=1, sortflg=False)
+            return self.biTrainPoints(m, tc)[0]
+
+        biInput1 = uf.rejectionSampling(resfun, smpfun, biDof1, biDof)
+        biDofNew = list(np.array(biDof1) + np.array(biDof2)) if addTrainPts else list(biDof)
+        seg1 = uf.listSegment(biInput1, biDof1)
+        seg2 = uf.listSegment(biInput2, biDof2)
+        out = []
+        for i in range(len(biDof1)):
+            b = uf.vstack([seg1[i], seg2[i]])
+            if td:
+                ind = np.reshape(np.argsort(b[:, dim:dim + 1], axis=0), biDofNew[i])
+                b = b[ind]
+            out.append(b)
+        return uf.vstack(out), [int(v) for v in biDofNew], biInput1, biInput2
+
+    def _model_on(self, Input):
+        """model(Input) for space-time rows without MOR columns (VarNet.py:1930) -> [n,1]."""
+        return self.engine.forward(Input).cpu().numpy().astype(np.float64).reshape(-1, 1)
 
     def biTrainPoints(self, mesh, t_coord):
         """Dirichlet-edge x time points, then IC points [x,0] (VarNet.py:604-645)."""
@@ -508,19 +657,31 @@ class VarNet:
         biLabel = self.biTrainData(biInput, biDof, biArg)
         diff, vel, src = self.PDEinpData(Input, inpArg)
         nt, q, dim = fd.nt, fd.integNum, self.dim
-        # gcoef = kappa*dNx + v*N  (VarNet.py:837) with the period tables broadcast over test functions
-        gcoef = (diff.reshape(nt, q, 1) * fd.dNx[None, :, :] +
-                 vel.reshape(nt, q, dim) * fd.N[None, :, None]).reshape(nt * q, dim)
+        N_rows = dNt_rows = None
+        if fd.detJvec:
+            # non-uniform supports: per-row tables (VarNetUtility.py:506-523)
+            Nr, dNxr, dNtr = fd.rows()
+            gcoef = diff * dNxr + vel * Nr                          # VarNet.py:837
+            N_rows, dNt_rows = eng.dev(Nr.reshape(-1)), eng.dev(dNtr.reshape(-1))
+        else:
+            # gcoef = kappa*dNx + v*N  (VarNet.py:837) with the period tables broadcast over test functions
+            gcoef = (diff.reshape(nt, q, 1) * fd.dNx[None, :, :] +
+                     vel.reshape(nt, q, dim) * fd.N[None, :, None]).reshape(nt * q, dim)
         if MORinp is not None:
             Input = np.hstack([Input, np.tile(MORinp, [Input.shape[0], 1])])
             biInput = np.hstack([biInput, np.tile(MORinp, [biInput.shape[0], 1])])
         return dict(Input=eng.dev(Input), gcoef=eng.dev(gcoef),
                     source=eng.dev(src.reshape(-1)) if self.lossOpt['isSource'] else None,
-                    biInput=eng.dev(biInput), biLabel=eng.dev(biLabel.reshape(-1)))
+                    biInput=eng.dev(biInput), biLabel=eng.dev(biLabel.reshape(-1)),
+                    N_rows=N_rows, dNt_rows=dNt_rows,
+                    detJ=eng.dev(np.reshape(fd.detJ, -1)) if fd.detJvec else None)
 
-    def _build_tdata(self, batchNum=None, batchLen=None, smpScheme='uniform', frac=0.5):
+    def _build_tdata(self, batchNum=None, batchLen=None, smpScheme='uniform', frac=0.5, addTrainPts=True,
+                     suppFactor=1.0):
         fd = self.fixData
-        Input, _, biInput, biDof = self.trainingPoints(smpScheme, frac)
+        Input, _, biInput, biDof = self.trainingPoints(smpScheme, frac, addTrainPts, suppFactor)
+        if smpScheme == 'optimal' and not addTrainPts:
+            fd.biDof = [int(b) for b in biDof]
         MORdiscArg = fd.MORdiscArg
         mor = [self._assemble(Input, biInput, biDof, b, MORdiscArg) for b in range(fd.MORbatchNum)]
         return ManageTrainData(self, mor, batchNum, batchLen)
@@ -603,7 +764,8 @@ class VarNet:
               addTrainPts=True, suppFactor=1.0, multiTrainUpd=False, trainUpdelay=2e4, tolUpd=0.01,
               reinitrain=True, updateWeights=False, normalizeW=False, adjustWeight=False,
               useOriginalW=False, batchNum=None, batchLen=None, shuffleData=False, shuffleFreq=1):
-        """Training loop of /root/reference/VarNet.py:1197-1421 (uniform / random sampling)."""
+        """Training loop of /root/reference/VarNet.py:1197-1421 (uniform, random and residual-driven
+        "optimal" sampling with re-initialisation and re-weighting)."""
         if uf.isnone(folderpath) or uf.isempty(folderpath):
             raise ValueError('a folder path must be provided to backup the trained model!')
         self.folderpath = folderpath
@@ -616,8 +778,6 @@ class VarNet:
             raise ValueError('weight dimension does not match!')
         if smpScheme not in ('uniform', 'random', 'optimal'):
             raise ValueError('sampling scheme is not valid!')
-        if smpScheme == 'optimal':
-            raise NotImplementedError('smpScheme=\'optimal\' is a later-round item')
         if updateWeights:
             raise NotImplementedError('updateWeights=True is broken in the reference (VarNet.py:1373)')
         self.smpScheme = smpScheme
@@ -628,24 +788,33 @@ class VarNet:
             shuffleData = False
         argDict = {k: v for k, v in locals().items() if k != 'self'}
 
+        if not addTrainPts and np.abs(suppFactor - 1.0) > 1.e-15:
+            warnings.warn('\'suppFactor\' is set to 1.0 since the number of training points does not change!')
+            suppFactor = 1.0
         eng, fd = self.engine, self.fixData
         torch = eng.torch
-        tData = self._build_tdata(batchNum, batchLen)
+        tData = self._build_tdata(batchNum, batchLen)        # first set is always uniform (VarNet.py:1300)
         trainRes = TrainResult(folderpath if self.rank == 0 else None, fd.cEx is not None, verbose, saveFreq)
         trainRes.initializeCase(self, argDict)
         self.trainRes = trainRes
 
-        eng.set_weights([1.0, 1.0, 1.0])
-        trainW, tData, lossVal = self.trainWeight(weight, tData, normalizeW, useOriginalW)
+        def set_train_weights(tD, wts):
+            eng.set_weights([1.0, 1.0, 1.0])
+            tW, tD, lv = self.trainWeight(wts, tD, normalizeW, useOriginalW)
+            w_e = tW.copy()
+            w_e[:-1] = w_e[:-1] / tD.batchNum / tD.puNum              # VarNetUtility.py:900-901
+            eng.set_weights(w_e)
+            return tW, w_e, lv
+
+        trainW, w_eff, lossVal = set_train_weights(tData, weight)
         trainRes.trainWeight = trainW.copy()
-        w_eff = trainW.copy()
-        w_eff[:-1] = w_eff[:-1] / tData.batchNum / tData.puNum        # VarNetUtility.py:900-901
-        eng.set_weights(w_eff)
         trainRes.lossComp.append(lossVal)
         self.tData = tData
+        tData0 = tData                                         # uniform set for universal cost comparison
 
         min_loss = float('inf')
         epoch_time = 0.0
+        tp_epoch, tp_updates = 1, 0
         resVal = err = lossComp = lossVec = None
         loss_acc = torch.zeros((), dtype=torch.float32, device=eng.device)
         for epoch in range(1, epochNum + 1):
@@ -666,7 +835,11 @@ class VarNet:
                     self.saveModel(epoch)
                 resVal, _, err, _ = self.residual()
                 eng.set_weights([1.0, 1.0, 1.0])
-                lossComp, _, lossVec = self.splitLoss(tData)
+                if tData0 is not tData:
+                    tData0.activate()
+                lossComp, _, lossVec = self.splitLoss(tData0)       # VarNet.py:1365
+                if tData0 is not tData:
+                    tData.activate()
                 eng.set_weights(w_eff)
             trainRes.iterOutput(epoch, current_loss, min_loss, epoch_time, resVal, err, lossComp, lossVec)
 
@@ -675,6 +848,29 @@ class VarNet:
                 if verbose and self.rank == 0:
                     print('Training completed!')
                 break
+
+            # regenerate the training set (VarNet.py:1385-1421)
+            if smpScheme != 'uniform' and (multiTrainUpd or tp_updates == 0) and (epoch - tp_epoch) >= (trainUpdelay - 1):
+                t_loss = np.array(trainRes.loss[-5:])
+                tp_conv = t_loss[:-1] - t_loss[1:]
+                tp_conv = np.sum(tp_conv[tp_conv > 0])
+                if tp_conv / t_loss[-1] < tolUpd:
+                    min_loss = float('inf')
+                    tp_epoch = epoch
+                    tp_updates += 1
+                    trainRes.inpIter.append(epoch)
+                    tData = self._build_tdata(batchNum, batchLen, smpScheme, frac, addTrainPts, suppFactor)
+                    self.tData = tData
+                    msg = '\n\n==========================================================\nTraining points updated.\n\n'
+                    if reinitrain:
+                        eng.init_params(seed=tp_updates)            # global_variables_initializer, VarNet.py:1412
+                        msg += 'trainable variables reinitialized.\n\n'
+                    if verbose and self.rank == 0:
+                        print(msg)
+                    trainRes.writeCase(msg)
+                    if adjustWeight:
+                        weight = [5 * wv for wv in weight[:-1]] + [weight[-1]]
+                    trainW, w_eff, _ = set_train_weights(tData, weight)
         return trainRes
 
     # -- checkpoints ----------------------------------------------------------------------------------
