@@ -243,11 +243,13 @@ def test_engine_argument_errors():
         VNEngine(1, 2, [500], True, 16)
 
 
+@pytest.mark.parametrize('kernel', [1, 0, 2], ids=['generic', 'auto', 'fused32'])
 @pytest.mark.parametrize('q,widths', [(16, [20, 20, 20]), (64, [50, 50, 50]), (36, [10, 20])])
-def test_per_row_tables_and_detjvec_parity(q, widths):
+def test_per_row_tables_and_detjvec_parity(q, widths, kernel):
     """Non-uniform supports: per-row N / dNt arrays and a per-test-function detJ
-    (VarNetUtility.py:506-523, TFModel.py:662-663) -- generic kernels, fp64 oracle."""
+    (VarNetUtility.py:506-523, TFModel.py:662-663) on every kernel path, fp64 oracle."""
     from varnet_amd.engine import VNEngine
+    _skip_unsupported(kernel, widths, q)
     d_in, dim = (3, 2) if q != 16 else (2, 1)
     n_k, nB, bDof = 45, 31, 17
     rng = np.random.default_rng(11)
@@ -262,7 +264,7 @@ def test_per_row_tables_and_detjvec_parity(q, widths):
     biInput = rng.uniform(-1, 1, (nB, d_in)).astype(np.float32)
     biLabel = rng.standard_normal((nB, 1)).astype(np.float32)
     w = np.array([2.0, 3.0, 4.0])
-    eng = VNEngine(dim, d_in, widths, True, q, isSource=True, integWflag=integW is not None)
+    eng = VNEngine(dim, d_in, widths, True, q, isSource=True, integWflag=integW is not None, kernel=kernel)
     eng.init_params(seed=5)
     flat = eng.get_params()
     eng.set_fe_table(np.zeros(q, np.float32), np.zeros(q, np.float32), integW)   # tables unused: per-row data

@@ -448,12 +448,13 @@ int vn_grad(vn_engine* h, int32_t batch) {
   if (int rc = check_batch(h, batch)) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   const Batch& b = h->batches[batch];
-  if (h->use_fused && !b.Nrow) {
+  if (h->use_fused) {
     VnFusedArgs a{};
     a.net = h->net; a.theta = h->theta;
     a.X = b.Input; a.G = b.gcoef; a.src = h->cfg.has_source ? b.source : nullptr;
     a.nT = b.n_k * h->cfg.integ_num; a.n_k = b.n_k; a.integ_num = h->cfg.integ_num;
     a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
+    a.Nrow = b.Nrow; a.dNtrow = b.dNtrow;
     a.detJv = b.detJv; a.detJ = (float)b.detJ; a.time_dependent = h->cfg.time_dependent;
     a.lossVec = nullptr;
     a.Xb = h->biInput; a.label = h->biLabel; a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;

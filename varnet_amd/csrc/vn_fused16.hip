@@ -191,6 +191,7 @@ struct VnFusedArgsD {
   const float* X; const float* G; const float* src;
   long nT, n_k; int integ_num;
   const float* feN; const float* fedNt; const float* feW;
+  const float* Nrow; const float* dNtrow;
   const float* detJv; float detJ; int time_dependent;
   float* lossVec;
   const float* Xb; const float* label; long nB, bDof; float biDimVal;
@@ -406,10 +407,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
     float ubar = 0.f, udbar = 0.f;
     if (interior) {
       const int pq = pt % q;
-      const float dnt = A.time_dependent ? A.fedNt[pq] : 0.f;
+      // per-row tables (non-uniform supports, VarNetUtility.py:506-523) override the periodic ones
+      const float dnt = !A.time_dependent ? 0.f : (A.dNtrow ? (valid ? A.dNtrow[row] : 0.f) : A.fedNt[pq]);
       const float wq = A.feW ? A.feW[pq] : 1.f;
       float t = ud - dnt * u;
-      if (A.src) t -= (valid ? A.src[row] : 0.f) * A.feN[pq];
+      if (A.src) t -= (valid ? A.src[row] : 0.f) * (A.Nrow ? (valid ? A.Nrow[row] : 0.f) : A.feN[pq]);
       t *= wq;
       if (!valid) t = 0.f;
       const int seg = q < CW ? q : CW;
@@ -614,7 +616,7 @@ bool vn_fused16_supported(const VnNet& net, int integ_num) {
 hipError_t vn_fused16_launch(const VnFusedArgs& h, int grid, hipStream_t s) {
   VnFusedArgsD a;
   a.net = h.net; a.theta = h.theta; a.X = h.X; a.G = h.G; a.src = h.src; a.nT = h.nT; a.n_k = h.n_k;
-  a.integ_num = h.integ_num; a.feN = h.feN; a.fedNt = h.fedNt; a.feW = h.feW; a.detJv = h.detJv;
+  a.integ_num = h.integ_num; a.feN = h.feN; a.fedNt = h.fedNt; a.feW = h.feW; a.Nrow = h.Nrow; a.dNtrow = h.dNtrow; a.detJv = h.detJv;
   a.detJ = h.detJ; a.time_dependent = h.time_dependent; a.lossVec = h.lossVec; a.Xb = h.Xb;
   a.label = h.label; a.nB = h.nB; a.bDof = h.bDof; a.biDimVal = h.biDimVal; a.w0 = h.w0; a.w1 = h.w1;
   a.w2 = h.w2; a.partial = h.partial; a.losspart = h.losspart; a.stamps = h.stamps;

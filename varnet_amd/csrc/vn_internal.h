@@ -65,6 +65,7 @@ struct VnFusedArgs {
   const float* X; const float* G; const float* src;   // interior rows
   long nT, n_k; int integ_num;
   const float* feN; const float* fedNt; const float* feW;
+  const float* Nrow; const float* dNtrow;              // per-row overrides or nullptr
   const float* detJv; float detJ; int time_dependent;
   float* lossVec;
   const float* Xb; const float* label; long nB, bDof; float biDimVal;   // BC/IC rows
