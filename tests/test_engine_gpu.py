@@ -68,15 +68,17 @@ CASES = [
     (2, 1, [50, 50, 50, 50],     16,      801, 450, 400, True,  False, True),     # config-2 shaped
     (3, 2, [20, 20, 20],         64,      33,  70,  30,  True,  False, False),
     (3, 2, [32, 17],             32,      50,  10,  4,   False, True,  True),
+    (2, 1, [20, 20, 20],         36,      41,  25,  9,   True,  True,  False),    # 3-point Gauss, 1D+t
+    (3, 2, [50, 50, 50],         36,      17,  12,  5,   False, True,  True),
 ]
 
 
 def _skip_unsupported(kernel, widths, integNum):
-    if kernel == 2 and (128 % integNum != 0 or max(widths) > 50 or
+    if kernel == 2 and (integNum > 128 or max(widths) > 50 or
                         (max(widths) > 20 and len(widths) < 2) or (max(widths) > 32 and len(widths) < 3) or
                         len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused32 not instantiated for this shape')
-    if kernel == 3 and (128 % integNum != 0 or max(widths) > 52 or len(widths) < 2 or
+    if kernel == 3 and (integNum > 128 or max(widths) > 52 or len(widths) < 2 or
                         (max(widths) > 32 and len(widths) < 3) or len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused16 not instantiated for this shape')
 

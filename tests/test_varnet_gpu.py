@@ -189,3 +189,37 @@ def test_optimal_sampling_on_device(tmp_path, suppFactor):
         biDimVal=float(fd.biDimVal), w=np.ones(3), dim=1, time_dependent=True, is_source=False, integWflag=False)
     assert abs(out[0] - ref['loss']) <= 1e-4 * abs(ref['loss'])
     vn.engine.close()
+
+
+def test_three_point_gauss_on_device(tmp_path):
+    """integPnum=3 (SURVEY 8f-4): integNum = 4*9 = 36 with quadrature weights (TFModel.py:660);
+    fused kernel with 3 test functions per 128-point tile; device loss vs oracle on the same arrays."""
+    pde = ADPDE(Domain1D(), diff=0.1 / pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                IC=lambda x: -np.sin(pi * x), source=lambda x, t=0: np.sin(x) * np.ones([len(x), 1]))
+    vn = VarNet(pde, layerWidth=[20, 20, 20], discNum=12, bDiscNum=None, tDiscNum=20, integPnum=3)
+    fd = vn.fixData
+    assert fd.integNum == 36 and vn.lossOpt == {'integWflag': True, 'isSource': True}
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=50, saveFreq=25, verbose=False)
+    assert res.loss[-1] < res.loss[0]
+    d = vn.tData.mor[0]
+    vn.tData.select_mor(0)
+    vn.engine.set_weights([1.0, 1.0, 1.0])
+    out, lv = vn.engine.eval_loss(0, lossVec=True)
+    flat = vn.engine.get_params().astype(np.float64)
+    Nr, dNxr, dNtr = fd.rows()
+    ref, _ = og.loss_and_grad(
+        flat, 2, [20, 20, 20], torch.float64, Input=d['Input'].cpu().numpy().astype(np.float64),
+        gcoef=d['gcoef'].cpu().numpy().astype(np.float64),
+        source=d['source'].cpu().numpy().astype(np.float64).reshape(-1, 1), N=Nr, dNt=dNtr,
+        integW=fd.integW, intShape=[fd.nt, 36], detJ=float(fd.detJ), detJvec=False,
+        biInput=d['biInput'].cpu().numpy().astype(np.float64),
+        biLabel=d['biLabel'].cpu().numpy().astype(np.float64).reshape(-1, 1), bDof=fd.bDofsum,
+        biDimVal=float(fd.biDimVal), w=np.ones(3), dim=1, time_dependent=True, is_source=True, integWflag=True)
+    assert abs(out[0] - ref['loss']) <= 1e-4 * abs(ref['loss'])
+    assert np.max(np.abs(lv.cpu().numpy() - ref['lossVec'].reshape(-1))) <= 1e-4 * np.max(np.abs(ref['lossVec']))
+    # the training step itself ran on the fused path: its loss output agrees too
+    gb = vn.engine.bind_grad_buffer()
+    vn.engine.grad(0)
+    torch.cuda.synchronize()
+    assert abs(float(gb[vn.engine.P]) - ref['loss']) <= 1e-4 * abs(ref['loss'])
+    vn.engine.close()

@@ -276,8 +276,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
 
   const float bo = A.theta[net.boff[L + 1]];
   const int q = A.integ_num;
-  const int TT = TILE / q;
-  const long ntiles_i = (A.nT + TILE - 1) / TILE;
+  const int TT = TILE / q;                                   // whole test functions per tile
+  const int TPTS = TT * q;                                   // points used in an interior tile (<= TILE)
+  const bool qtree = (TILE % q) == 0;                        // q divides the tile: shuffle-tree R_k
+  const long ntiles_i = (A.n_k + TT - 1) / TT;
   const long ntiles = ntiles_i + (A.nB + TILE - 1) / TILE;
   float loss_var = 0.f, loss_bc = 0.f, loss_ic = 0.f;
   const long nI = A.nB - A.bDof;
@@ -291,11 +293,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     asm volatile("" ::: "memory");                 // keep LDS fragment loads inside the loop
     const bool interior = tile < ntiles_i;
-    const long r0 = (interior ? tile : tile - ntiles_i) * TILE;
+    const long r0 = interior ? tile * TPTS : (tile - ntiles_i) * TILE;
     const long nrows = interior ? A.nT : A.nB;
     const int pt = wave * CW + lc.c;
     const long row = r0 + pt;
-    const bool valid = row < nrows;
+    const bool valid = row < nrows && (!interior || pt < TPTS);
 
     float xin[KS0], gin[KS0];
     {
@@ -415,13 +417,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       t *= wq;
       if (!valid) t = 0.f;
       const int seg = q < CW ? q : CW;
-      for (int o = 1; o < seg; o <<= 1) t += __shfl_xor(t, o, 64);
-      if (lc.g == 0 && (lc.c % seg) == 0) sInt[pt / seg] = t;
+      if (qtree) {
+        for (int o = 1; o < seg; o <<= 1) t += __shfl_xor(t, o, 64);
+        if (lc.g == 0 && (lc.c % seg) == 0) sInt[pt / seg] = t;
+      } else if (lc.g == 0) {
+        sInt[pt] = t;                                                 // q does not divide the tile: serial sum
+      }
       __syncthreads();
       if (tid < TT) {
-        const int per = q / seg;
         float R = 0.f;
-        for (int j = 0; j < per; ++j) R += sInt[tid * per + j];
+        if (qtree) {
+          const int per = q / seg;                                    // partials per test function
+          for (int j = 0; j < per; ++j) R += sInt[tid * per + j];     // :661
+        } else {
+          for (int p = 0; p < q; ++p) R += sInt[tid * q + p];
+        }
         const long k = r0 / q + tid;
         float s = 0.f;
         if (k < A.n_k) {
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
         sR[tid] = s;
       }
       __syncthreads();
-      const float s = sR[pt / q] * wq;
+      const float s = (pt < TPTS ? sR[pt / q] : 0.f) * wq;
       udbar = s;
       ubar = -dnt * s;
     } else {
@@ -608,7 +618,7 @@ size_t vn_fused16_lds_bytes(const VnNet& net) {
 
 bool vn_fused16_supported(const VnNet& net, int integ_num) {
   if (net.d_in > 4 * KS0) return false;
-  if (integ_num < 1 || integ_num > TILE || (TILE % integ_num) != 0) return false;
+  if (integ_num < 1 || integ_num > TILE) return false;   // whole test functions must fit a tile
   const size_t b = vn_fused16_lds_bytes(net);
   return b != 0 && b <= 160 * 1024;
 }
