@@ -105,6 +105,16 @@ int vn_set_fe_table(vn_engine* h, const float* N, const float* dNt, const float*
 int vn_set_interior(vn_engine* h, int32_t batch, const float* Input_dev, const float* gcoef_dev,
                     const float* source_dev, int64_t n_k, const float* detJ_dev, double detJ,
                     const float* N_rows_dev, const float* dNt_rows_dev);
+/* OPTIONAL, no reference counterpart: de-duplicated formulation for `batch`.  On uniform grids every
+ * quadrature point is shared by the 2^feDim hat functions around it, so the reference evaluates the
+ * network 2^feDim times per point (VarNet.py:576-588).  Given the unique points Xu [U, d_in], the map
+ * uid [n_k*integ_num] row -> unique point and its CSR inverse (rowptr [U+1], rowidx [n_k*integ_num]),
+ * vn_grad evaluates value and input gradient once per unique point and assembles the same loss and
+ * gradient (same math, different rounding).  All device pointers.  Xu == NULL switches it off.
+ * Requires the 8-wave fused kernel and uniform supports. */
+int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu_dev, int64_t U, const int32_t* uid_dev,
+                 const int32_t* rowptr_dev, const int32_t* rowidx_dev);
+
 /* Feed of tower.biInput / biLabel / bDof / biDimVal (VarNetUtility.py:841-849).
  * biInput [nB, d_in], biLabel [nB]; rows [0,bDof) are boundary, [bDof,nB) initial condition. */
 int vn_set_bic(vn_engine* h, const float* biInput_dev, const float* biLabel_dev, int64_t nB,

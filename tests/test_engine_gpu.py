@@ -290,3 +290,77 @@ def test_per_row_tables_and_detjvec_parity(q, widths, kernel):
     assert abs(g[eng.P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
     assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
     eng.close()
+
+
+def _csr(uid, U):
+    order = np.argsort(uid, kind='stable').astype(np.int32)
+    rowptr = np.zeros(U + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(np.bincount(uid, minlength=U))
+    return rowptr, order
+
+
+@pytest.mark.parametrize('case', [
+    # d_in dim widths            q   n_k  U     nB  bDof source integW
+    (2, 1, [20, 20, 20],         16, 50,  230,  30, 18,  False, False),
+    (3, 2, [50, 50, 50, 50, 50], 64, 40,  500,  77, 40,  True,  False),
+    (3, 2, [32, 17],             32, 33,  300,  10, 4,   False, True),
+    (3, 1, [10, 20, 30],         16, 64,  400,  19, 7,   True,  False),      # MOR-style extra input
+])
+def test_dedup_formulation_parity(case):
+    """De-duplicated formulation (one network evaluation per unique quadrature point): same loss
+    and gradient as the row-wise formulation -- against the fp64 oracle on the expanded rows and
+    against the engine's own row-wise path."""
+    from varnet_amd.engine import VNEngine
+    d_in, dim, widths, q, n_k, U, nB, bDof, source, integW = case
+    rng = np.random.default_rng(21)
+    n = n_k * q
+    Xu = rng.uniform(-1, 1, (U, d_in)).astype(np.float32)
+    uid = rng.integers(0, U, n).astype(np.int32)
+    uid[:U] = np.arange(U)                                           # every unique point is used
+    rng.shuffle(uid)
+    Input = Xu[uid]
+    gcoef = rng.standard_normal((n, dim)).astype(np.float32)
+    src = rng.standard_normal((n, 1)).astype(np.float32) if source else None
+    N1 = rng.uniform(0, 1, q).astype(np.float32)
+    dNt1 = rng.standard_normal(q).astype(np.float32)
+    W = rng.uniform(0.5, 1, (1, q)).astype(np.float32) if integW else None
+    biInput = rng.uniform(-1, 1, (nB, d_in)).astype(np.float32)
+    biLabel = rng.standard_normal((nB, 1)).astype(np.float32)
+    w = np.array([3.0, 2.0, 5.0])
+    eng = VNEngine(dim, d_in, widths, True, q, isSource=source, integWflag=integW)
+    eng.init_params(seed=4)
+    flat = eng.get_params()
+    eng.set_fe_table(N1, dNt1, W)
+    eng.set_interior(0, Input, gcoef, src, n_k=n_k, detJ=0.05)
+    eng.set_bic(biInput, biLabel, bDof, 2.0)
+    eng.set_weights(w)
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g_rows = gb.cpu().numpy().copy()
+    rowptr, rowidx = _csr(uid, U)
+    eng.set_dedup(0, Xu, uid, rowptr, rowidx)
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g_dd = gb.cpu().numpy().copy()
+    ref, gref = og.loss_and_grad(
+        flat.astype(np.float64), d_in, widths, torch.float64, Input=Input.astype(np.float64),
+        gcoef=gcoef.astype(np.float64), source=None if src is None else src.astype(np.float64),
+        N=np.tile(N1, n_k).reshape(n, 1).astype(np.float64), dNt=np.tile(dNt1, n_k).reshape(n, 1).astype(np.float64),
+        integW=None if W is None else W.astype(np.float64), intShape=[n_k, q], detJ=0.05, detJvec=False,
+        biInput=biInput.astype(np.float64), biLabel=biLabel.astype(np.float64), bDof=bDof, biDimVal=2.0, w=w,
+        dim=dim, time_dependent=True, is_source=source, integWflag=integW)
+    P = eng.P
+    for g in (g_rows, g_dd):
+        assert abs(g[P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+        assert np.max(np.abs(g[:P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
+    assert np.allclose(g_dd[P + 1:P + 4], g_rows[P + 1:P + 4], rtol=1e-5)
+    # bitwise reproducible, and switching it off restores the row-wise path
+    eng.grad(0)
+    torch.cuda.synchronize()
+    assert np.array_equal(gb.cpu().numpy(), g_dd)
+    eng.set_dedup(0)
+    eng.grad(0)
+    torch.cuda.synchronize()
+    assert np.array_equal(gb.cpu().numpy(), g_rows)
+    eng.close()

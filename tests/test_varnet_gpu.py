@@ -223,3 +223,20 @@ def test_three_point_gauss_on_device(tmp_path):
     torch.cuda.synchronize()
     assert abs(float(gb[vn.engine.P]) - ref['loss']) <= 1e-4 * abs(ref['loss'])
     vn.engine.close()
+
+
+def test_dedup_training_matches_rowwise(tmp_path):
+    """train(dedup=True): same loss trajectory as the row-wise formulation (fp32 rounding only) on a
+    2D+t grid where every interior quadrature point is shared by 8 test functions."""
+    losses = []
+    for dd in (False, True):
+        vn = op2dt([20, 20, 20], [8, 6], 6, 8)
+        res = vn.train(str(tmp_path / ('dd%d' % dd)), weight=[5., 1., 1.], epochNum=60, saveFreq=30,
+                       verbose=False, dedup=dd)
+        if dd:
+            assert vn.tData.dedup_on
+            U = vn.tData._dd_cache[(0, 0)][0].shape[0]
+            assert vn.fixData.nT / U > 5.0
+        losses.append(np.array(res.loss))
+        vn.engine.close()
+    assert np.max(np.abs(losses[0] - losses[1]) / losses[0]) < 2e-3

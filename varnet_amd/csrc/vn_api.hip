@@ -40,6 +40,12 @@ struct Batch {
   long n_k = 0;
   double detJ = 0.0;
   bool set = false;
+  // de-duplicated formulation (vn_set_dedup)
+  const float* Xu = nullptr;
+  const int* uid = nullptr;
+  const int* rowptr = nullptr;
+  const int* rowidx = nullptr;
+  long U = 0;
 };
 
 constexpr int PROF_CAP = 4096;
@@ -81,6 +87,10 @@ struct vn_engine {
   bool use_fused16 = false;
   float* fused_losspart = nullptr;   // [ncu*3]
   unsigned long long* stamps = nullptr;   // 8 counters, diagnostic builds
+  // de-duplicated formulation work buffers
+  float *dd_uv = nullptr, *dd_ug = nullptr, *dd_su = nullptr, *dd_sg = nullptr, *dd_partial = nullptr,
+        *dd_losspart = nullptr;
+  long dd_capU = 0, dd_cap_lp = 0;
 
   // profiling of the dominant kernel
   bool prof_on = false;
@@ -188,6 +198,64 @@ int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* l
   return VN_OK;
 }
 
+// One gradient evaluation in the de-duplicated formulation (vn_dedup.hip header): forward at the
+// unique points for each spatial direction, weak-form assembly over rows, seed gather, one reverse
+// pass per direction.  with_grad = false stops after the loss (vn_eval_loss).
+int run_dedup(vn_engine* h, const Batch& b, bool with_grad, float* lossVec, float* gradbuf) {
+  const int dim = h->cfg.dim, q = h->cfg.integ_num, grid = h->ncu, P = h->net.P;
+  const long nT = b.n_k * q;
+  const int sblk = (int)((b.n_k + 255) / 256);
+  float* lp = h->dd_losspart;                       // [dim*grid + sblk][3]
+  VnFusedArgs f{};
+  f.net = h->net; f.theta = h->theta; f.X = b.Xu; f.G = nullptr; f.src = nullptr;
+  f.nT = b.U; f.n_k = 0; f.integ_num = q;
+  f.feN = h->feN; f.fedNt = h->fedNt; f.feW = nullptr; f.detJv = nullptr; f.detJ = 0.f;
+  f.time_dependent = h->cfg.time_dependent; f.lossVec = nullptr;
+  f.Xb = h->biInput; f.label = h->biLabel; f.nB = 0; f.bDof = h->bDof; f.biDimVal = (float)h->biDimVal;
+  f.w0 = (float)h->w[0]; f.w1 = (float)h->w[1]; f.w2 = (float)h->w[2];
+  f.partial = h->dd_partial; f.losspart = lp; f.stamps = nullptr;
+  f.ostride = dim;
+  // 1. (u, du/dx_d) at the unique points
+  for (int d = 0; d < dim; ++d) {
+    f.mode = 1; f.dir = d; f.out_u = (d == 0) ? h->dd_uv : nullptr; f.out_ud = h->dd_ug + d;
+    HIPCHK(vn_fused16_launch(f, grid, h->stream));
+  }
+  // 2. weak-form assembly over (test function, quadrature point) rows
+  VnDedupArgs a{};
+  a.uv = h->dd_uv; a.ug = h->dd_ug; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
+  a.gcoef = b.gcoef; a.source = h->cfg.has_source ? b.source : nullptr;
+  a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
+  a.detJv = b.detJv; a.detJ = (float)b.detJ; a.n_k = b.n_k; a.U = b.U; a.q = q; a.dim = dim;
+  a.time_dependent = h->cfg.time_dependent; a.w2 = (float)h->w[2];
+  a.srow = with_grad ? h->u : nullptr; a.lossVec = lossVec; a.part = lp + (long)dim * grid * 3;
+  a.seed_u = h->dd_su; a.seed_g = h->dd_sg;
+  (void)nT;
+  HIPCHK(vn_dedup_seed_launch(a, sblk, h->stream));
+  if (!with_grad) {
+    // boundary / initial loss: forward of the BC rows through the generic kernel + seed epilogue
+    return VN_OK;
+  }
+  HIPCHK(vn_dedup_gather_launch(a, h->stream));
+  // 3. reverse pass per direction (BC/IC tiles ride along in the first one)
+  for (int d = 0; d < dim; ++d) {
+    f.mode = 2; f.dir = d; f.out_u = nullptr; f.out_ud = nullptr;
+    f.seed_u = (d == 0) ? h->dd_su : nullptr; f.seed_ud = h->dd_sg + d;
+    f.nB = (d == 0) ? h->nB : 0;
+    f.partial = h->dd_partial + (long)d * grid * P;
+    f.losspart = lp + (long)d * grid * 3;
+    const bool rec = h->prof_on && h->prof_n < PROF_CAP && d == 0;
+    if (rec) {
+      if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
+      HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
+    }
+    HIPCHK(vn_fused16_launch(f, grid, h->stream));
+    if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
+  }
+  HIPCHK(vn_reduce_launch(h->dd_partial, dim * grid, P, lp, dim * grid + sblk, h->bDof, h->nB, f.w0, f.w1, f.w2,
+                          gradbuf, h->stream));
+  return VN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -277,7 +345,8 @@ int vn_destroy(vn_engine* h) {
   if (!h) return VN_OK;
   (void)hipSetDevice(h->cfg.device);
   void* ptrs[] = {h->theta, h->m, h->v, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
-                  h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart, h->stamps};
+                  h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart, h->stamps, h->dd_uv, h->dd_ug, h->dd_su, h->dd_sg, h->dd_partial,
+                  h->dd_losspart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
@@ -404,6 +473,7 @@ int vn_set_interior(vn_engine* h, int32_t batch, const float* Input, const float
   Batch& b = h->batches[batch];
   b.Input = Input; b.gcoef = gcoef; b.source = source; b.detJv = detJ_dev; b.detJ = detJ;
   b.Nrow = N_rows; b.dNtrow = dNt_rows; b.n_k = n_k; b.set = true;
+  b.Xu = nullptr; b.uid = nullptr; b.rowptr = nullptr; b.rowidx = nullptr; b.U = 0;   // re-register with vn_set_dedup
   const long nT = n_k * h->cfg.integ_num;
   if (nT > h->work_rows) {
     long c0 = h->work_rows, c1 = h->work_rows, c2 = h->work_rows, c3 = h->work_rows;
@@ -413,6 +483,44 @@ int vn_set_interior(vn_engine* h, int32_t batch, const float* Input, const float
     if (int rc = ensure(&h->udbar, &c3, nT)) return rc;
     h->work_rows = nT;
   }
+  return VN_OK;
+}
+
+int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const int32_t* uid,
+                 const int32_t* rowptr, const int32_t* rowidx) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  if (batch < 0 || batch >= (int)h->batches.size() || !h->batches[batch].set)
+    return fail(VN_ESTATE, "batch %d has no interior data (call vn_set_interior first)", batch);
+  Batch& b = h->batches[batch];
+  if (!Xu) {                                   // switch the formulation off for this batch
+    b.Xu = nullptr; b.uid = nullptr; b.rowptr = nullptr; b.rowidx = nullptr; b.U = 0;
+    return VN_OK;
+  }
+  if (!uid || !rowptr || !rowidx || U <= 0) return fail(VN_EINVAL, "null argument");
+  if (!h->use_fused16) return fail(VN_EUNSUPPORTED, "de-duplication needs the 8-wave fused kernel for this network");
+  if (b.Nrow || b.detJv) return fail(VN_EUNSUPPORTED, "de-duplication needs uniform supports (no per-row tables)");
+  if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "de-duplication supports dim <= 3");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int dim = h->cfg.dim;
+  if (U > h->dd_capU) {
+    float** bufs[] = {&h->dd_uv, &h->dd_ug, &h->dd_su, &h->dd_sg};
+    const long sizes[] = {U, U * dim, U, U * dim};
+    for (int i = 0; i < 4; ++i) {
+      if (*bufs[i]) (void)hipFree(*bufs[i]);
+      *bufs[i] = nullptr;
+      HIPCHK(hipMalloc((void**)bufs[i], (size_t)sizes[i] * sizeof(float)));
+    }
+    h->dd_capU = U;
+  }
+  if (!h->dd_partial) HIPCHK(hipMalloc((void**)&h->dd_partial, (size_t)3 * h->ncu * h->net.P * sizeof(float)));
+  const long need_lp = ((long)3 * h->ncu + (b.n_k + 255) / 256) * 3;
+  if (need_lp > h->dd_cap_lp) {
+    if (h->dd_losspart) (void)hipFree(h->dd_losspart);
+    h->dd_losspart = nullptr;
+    HIPCHK(hipMalloc((void**)&h->dd_losspart, (size_t)need_lp * sizeof(float)));
+    h->dd_cap_lp = need_lp;
+  }
+  b.Xu = Xu; b.U = U; b.uid = uid; b.rowptr = rowptr; b.rowidx = rowidx;
   return VN_OK;
 }
 
@@ -448,6 +556,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
   if (int rc = check_batch(h, batch)) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   const Batch& b = h->batches[batch];
+  if (b.Xu && h->use_fused16) return run_dedup(h, b, true, nullptr, h->gradbuf);
   if (h->use_fused) {
     VnFusedArgs a{};
     a.net = h->net; a.theta = h->theta;

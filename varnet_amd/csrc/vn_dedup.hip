@@ -1,0 +1,85 @@
+// De-duplicated weak-form assembly.  On the reference's uniform grids neighbouring hat functions
+// share elements, so every quadrature point is evaluated 2^feDim times (once per test function
+// whose support contains it; VarNet.py:576-588).  The network value and input gradient depend
+// only on the point, so they are computed ONCE per unique point; this file holds the two small
+// HBM-bound kernels that connect unique points and (test function, quadrature point) rows:
+//   vn_dedup_seed_kernel   rows gather (u, grad u) of their point, form the weak-form integrand
+//                          sum_d u_{x_d} gcoef_d - u dNt - s N (TFModel.py:653-657), R_k, lossVec,
+//                          loss partials and the per-row seed 2 w2 detJ R_k w_p;
+//   vn_dedup_gather_kernel each unique point sums the seeds of its rows, in CSR order (fixed ->
+//                          bitwise reproducible), into d loss/d u and d loss/d u_{x_d}.
+#include "vn_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void vn_dedup_seed_kernel(VnDedupArgs a) {
+  __shared__ float red[4];
+  const long k = (long)blockIdx.x * 256 + threadIdx.x;
+  float lv = 0.f;
+  if (k < a.n_k) {
+    const int q = a.q, dim = a.dim;
+    const long base = k * q;
+    float R = 0.f;
+    for (int p = 0; p < q; ++p) {
+      const long r = base + p;
+      const long j = a.uid[r];
+      float t = 0.f;
+      for (int d = 0; d < dim; ++d) t += a.ug[j * dim + d] * a.gcoef[r * dim + d];   // :653-654
+      if (a.time_dependent) t -= a.uv[j] * a.fedNt[p];                              // :655
+      if (a.source) t -= a.source[r] * a.feN[p];                                    // :657
+      if (a.feW) t *= a.feW[p];                                                     // :660
+      R += t;
+    }
+    const float dj = a.detJv ? a.detJv[k] : a.detJ;
+    lv = dj * R * R;
+    if (a.lossVec) a.lossVec[k] = lv;
+    if (a.srow) {
+      const float s0 = 2.f * a.w2 * dj * R;
+      for (int p = 0; p < q; ++p) a.srow[base + p] = a.feW ? s0 * a.feW[p] : s0;
+    }
+  }
+  const float s = block_sum256(lv, red);
+  if (threadIdx.x == 0) {
+    a.part[blockIdx.x * 3 + 0] = s;
+    a.part[blockIdx.x * 3 + 1] = 0.f;
+    a.part[blockIdx.x * 3 + 2] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void vn_dedup_gather_kernel(VnDedupArgs a) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= a.U) return;
+  const int dim = a.dim, q = a.q;
+  float su = 0.f, sg[3] = {0.f, 0.f, 0.f};
+  for (int e = a.rowptr[j]; e < a.rowptr[j + 1]; ++e) {
+    const long r = a.rowidx[e];
+    const float s = a.srow[r];
+    const int p = (int)(r % q);
+    if (a.time_dependent) su -= a.fedNt[p] * s;
+    for (int d = 0; d < dim; ++d) sg[d] += a.gcoef[r * dim + d] * s;
+  }
+  a.seed_u[j] = su;
+  for (int d = 0; d < dim; ++d) a.seed_g[j * dim + d] = sg[d];
+}
+
+}  // namespace
+
+hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(vn_dedup_seed_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t vn_dedup_gather_launch(const VnDedupArgs& a, hipStream_t s) {
+  const int grid = (int)((a.U + 255) / 256);
+  hipLaunchKernelGGL(vn_dedup_gather_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}

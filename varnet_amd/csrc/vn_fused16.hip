@@ -199,6 +199,12 @@ struct VnFusedArgsD {
   float* partial;
   float* losspart;
   unsigned long long* stamps;
+  // de-duplicated formulation (rows = unique quadrature points, no test-function grouping):
+  int mode;                 // 0 fused step; 1 forward only -> out_u/out_ud; 2 reverse pass with external seeds
+  int dir;                  // >= 0: tangent direction is the unit vector e_dir (G ignored)
+  int ostride;              // element stride of out_ud / seed_ud
+  float* out_u; float* out_ud;
+  const float* seed_u; const float* seed_ud;
 };
 
 template <int L, int KS>
@@ -279,8 +285,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   const int TT = TILE / q;                                   // whole test functions per tile
   const int TPTS = TT * q;                                   // points used in an interior tile (<= TILE)
   const bool qtree = (TILE % q) == 0;                        // q divides the tile: shuffle-tree R_k
-  const long ntiles_i = (A.n_k + TT - 1) / TT;
-  const long ntiles = ntiles_i + (A.nB + TILE - 1) / TILE;
+  const long ntiles_i = A.mode ? (A.nT + TILE - 1) / TILE : (A.n_k + TT - 1) / TT;
+  const long ntiles = ntiles_i + (A.mode == 1 ? 0 : (A.nB + TILE - 1) / TILE);
   float loss_var = 0.f, loss_bc = 0.f, loss_ic = 0.f;
   const long nI = A.nB - A.bDof;
   const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
@@ -293,11 +299,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     asm volatile("" ::: "memory");                 // keep LDS fragment loads inside the loop
     const bool interior = tile < ntiles_i;
-    const long r0 = interior ? tile * TPTS : (tile - ntiles_i) * TILE;
+    const long r0 = (interior && !A.mode) ? tile * TPTS : (interior ? tile : tile - ntiles_i) * TILE;
     const long nrows = interior ? A.nT : A.nB;
     const int pt = wave * CW + lc.c;
     const long row = r0 + pt;
-    const bool valid = row < nrows && (!interior || pt < TPTS);
+    const bool valid = row < nrows && (!interior || A.mode || pt < TPTS);
 
     float xin[KS0], gin[KS0];
     {
@@ -306,7 +312,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       for (int s = 0; s < KS0; ++s) {
         const int f = 4 * s + lc.g;
         xin[s] = (valid && f < net.d_in) ? Xp[row * net.d_in + f] : 0.f;
-        gin[s] = (valid && interior && f < net.dim) ? A.G[row * net.dim + f] : 0.f;
+        if (A.dir >= 0) gin[s] = (valid && interior && f == A.dir) ? 1.f : 0.f;
+        else gin[s] = (valid && interior && f < net.dim) ? A.G[row * net.dim + f] : 0.f;
       }
     }
 
@@ -406,8 +413,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
     u += bo;
 
     // ---------------------------------------------------------------- weak-form epilogue
+    if (A.mode == 1) {                                       // forward only: model value and directional derivative
+      if (valid && lc.g == 0) {
+        if (A.out_u) A.out_u[row] = u;
+        A.out_ud[row * A.ostride] = ud;
+      }
+      continue;
+    }
     float ubar = 0.f, udbar = 0.f;
-    if (interior) {
+    if (interior && A.mode == 2) {                           // seeds were assembled per unique point
+      if (valid) {
+        ubar = A.seed_u ? A.seed_u[row] : 0.f;
+        udbar = A.seed_ud[row * A.ostride];
+      }
+    } else if (interior) {
       const int pq = pt % q;
       // per-row tables (non-uniform supports, VarNetUtility.py:506-523) override the periodic ones
       const float dnt = !A.time_dependent ? 0.f : (A.dNtrow ? (valid ? A.dNtrow[row] : 0.f) : A.fedNt[pq]);
@@ -630,6 +649,8 @@ hipError_t vn_fused16_launch(const VnFusedArgs& h, int grid, hipStream_t s) {
   a.detJ = h.detJ; a.time_dependent = h.time_dependent; a.lossVec = h.lossVec; a.Xb = h.Xb;
   a.label = h.label; a.nB = h.nB; a.bDof = h.bDof; a.biDimVal = h.biDimVal; a.w0 = h.w0; a.w1 = h.w1;
   a.w2 = h.w2; a.partial = h.partial; a.losspart = h.losspart; a.stamps = h.stamps;
+  a.mode = h.mode; a.dir = h.mode ? h.dir : -1; a.ostride = h.ostride; a.out_u = h.out_u; a.out_ud = h.out_ud;
+  a.seed_u = h.seed_u; a.seed_ud = h.seed_ud;
   const int ks = pick_ks(h.net.hmax);
 #define X(LL, KK) if (h.net.L == LL && ks == KK) return launch_one<LL, KK>(a, grid, s);
   VN_FUSED16_CASES(X)

@@ -73,6 +73,12 @@ struct VnFusedArgs {
   float* partial;    // [grid, P] per-workgroup gradient partials
   float* losspart;   // [grid, 3] per-workgroup (var, bc, ic) partial sums
   unsigned long long* stamps;   // diagnostic builds (-DVN_STAMPS) only: 8 phase cycle sums, else nullptr
+  // de-duplicated formulation (8-wave kernel only; rows X = unique quadrature points):
+  int mode;                     // 0 fused step | 1 forward only | 2 reverse pass with external seeds
+  int dir;                      // tangent direction e_dir (modes 1, 2)
+  int ostride;                  // element stride of out_ud / seed_ud
+  float* out_u; float* out_ud;  // mode 1 outputs
+  const float* seed_u; const float* seed_ud;   // mode 2 seeds (seed_u may be nullptr = 0)
 };
 bool vn_fused_supported(const VnNet& net, int integ_num);
 size_t vn_fused_lds_bytes(const VnNet& net);
@@ -81,6 +87,24 @@ hipError_t vn_fused_launch(const VnFusedArgs& a, int grid, hipStream_t s);
 bool vn_fused16_supported(const VnNet& net, int integ_num);
 size_t vn_fused16_lds_bytes(const VnNet& net);
 hipError_t vn_fused16_launch(const VnFusedArgs& a, int grid, hipStream_t s);
+
+// ---- de-duplicated weak-form assembly (vn_dedup.hip) -----------------------------------------
+struct VnDedupArgs {
+  const float* uv; const float* ug;          // [U], [U, dim]: model value / input gradient at unique points
+  const int* uid;                            // [nT] row -> unique point
+  const int* rowptr; const int* rowidx;      // CSR unique point -> rows
+  const float* gcoef; const float* source;   // [nT, dim], [nT] or nullptr
+  const float* feN; const float* fedNt; const float* feW;
+  const float* detJv; float detJ;
+  long n_k, U; int q, dim, time_dependent;
+  float w2;
+  float* srow;                               // [nT] per-row seed (nullptr: loss only)
+  float* lossVec;                            // [n_k] or nullptr
+  float* part;                               // [grid*3] block partials (var, 0, 0)
+  float* seed_u; float* seed_g;              // [U], [U, dim] gathered seeds
+};
+hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s);
+hipError_t vn_dedup_gather_launch(const VnDedupArgs& a, hipStream_t s);
 
 // ---- simple per-point evaluation kernels (float / double): vn_pointwise.hip --------------
 hipError_t vn_pointwise_forward_f32(const VnNet& net, const float* theta, const float* X, long n,

@@ -49,6 +49,7 @@ _SIGS = {
     'vn_set_fe_table': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'vn_set_interior': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    'vn_set_dedup': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'vn_set_bic': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double]),
     'vn_set_weights': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     'vn_bind_grad_buffer': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -249,6 +250,21 @@ class VNEngine:
         self._keep[('int', batch)] = (Input, gcoef, source, detJv, Nr, dNr)
         self._ck(self.lib.vn_set_interior(self.h, batch, _ptr(Input), _ptr(gcoef), _ptr(source), n_k,
                                           _ptr(detJv), detJ_s, _ptr(Nr), _ptr(dNr)))
+
+    def set_dedup(self, batch, Xu=None, uid=None, rowptr=None, rowidx=None):
+        """Register (or, with Xu=None, clear) the de-duplicated formulation of `batch`."""
+        t = self.torch
+        if Xu is None:
+            self._keep.pop(('dd', batch), None)
+            self._ck(self.lib.vn_set_dedup(self.h, batch, None, 0, None, None, None))
+            return
+        Xu = self.dev(Xu)
+        i32 = lambda a: (a if isinstance(a, t.Tensor) else t.as_tensor(np.ascontiguousarray(a))).to(
+            device=self.device, dtype=t.int32).contiguous()
+        uid, rowptr, rowidx = i32(uid), i32(rowptr), i32(rowidx)
+        assert rowptr.numel() == Xu.shape[0] + 1 and uid.numel() == rowidx.numel()
+        self._keep[('dd', batch)] = (Xu, uid, rowptr, rowidx)
+        self._ck(self.lib.vn_set_dedup(self.h, batch, _ptr(Xu), Xu.shape[0], _ptr(uid), _ptr(rowptr), _ptr(rowidx)))
 
     def set_bic(self, biInput, biLabel, bDof, biDimVal):
         if biInput is None or len(biInput) == 0:

@@ -32,6 +32,33 @@ shape = np.shape
 size = np.size
 
 
+def unique_points(Input, feDim, hVec):
+    """
+    Unique quadrature points of an `Input` block (rows = test function x quadrature point).
+    On the uniform grid the 2^feDim hat functions around an element share its quadrature points
+    (VarNet.py:576-588), so rows repeat; coordinates reached from different nodes differ only by
+    fp64 rounding and are merged on a lattice of h/4096.  Returns (first-occurrence row of every
+    unique point, uid [n] row -> unique point, rowptr [U+1], rowidx [n] CSR inverse).
+    """
+    X = np.asarray(Input)[:, :feDim]
+    h = np.reshape(np.asarray(hVec, dtype=float), (1, feDim))
+    k = np.rint((X - X.min(axis=0, keepdims=True)) / h * 4096.0).astype(np.int64)
+    bits = [int(np.ceil(np.log2(max(int(k[:, d].max()), 1) + 1))) for d in range(feDim)]
+    if sum(bits) <= 62:
+        key = np.zeros(X.shape[0], dtype=np.int64)
+        for d in range(feDim):
+            key = (key << bits[d]) | k[:, d]
+        _, first, uid = np.unique(key, return_index=True, return_inverse=True)
+    else:
+        _, first, uid = np.unique(k, axis=0, return_index=True, return_inverse=True)
+    uid = np.reshape(uid, -1).astype(np.int32)
+    U = first.shape[0]
+    rowidx = np.argsort(uid, kind='stable').astype(np.int32)
+    rowptr = np.zeros(U + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(np.bincount(uid, minlength=U))
+    return first, uid, rowptr, rowidx
+
+
 # ======================================================================================
 class FIXData:
     """
@@ -300,6 +327,39 @@ class ManageTrainData:
     def activate(self):
         """(Re-)register this set's batches with the engine (after another set used it)."""
         self._register()
+        if getattr(self, 'dedup_on', False):
+            self.enable_dedup()
+
+    def enable_dedup(self):
+        """
+        Switch every registered batch to the de-duplicated formulation (`vn_set_dedup`): one network
+        evaluation per unique quadrature point instead of one per (test function, point) row.
+        Needs the periodic FE tables (uniform supports) and an unshuffled set; returns the total
+        number of unique points, or 0 if it does not apply.
+        """
+        vn = self.vn
+        fd = vn.fixData
+        if self.shuffled or fd.detJvec or not hasattr(vn.engine, 'set_dedup'):
+            return 0
+        q, total = self.integNum, 0
+        cache = getattr(self, '_dd_cache', {})
+        for mb, d in enumerate(self.mor):
+            for bi in range(self.batchNum):
+                n0, n1 = self.block(bi)
+                key = (mb, bi)
+                if key not in cache:
+                    blk = d['Input_host'][n0 * q:n1 * q]
+                    first, uid, rowptr, rowidx = unique_points(blk, fd.feDim, fd.hVec)
+                    cache[key] = (vn.engine.dev(blk[first]), uid, rowptr, rowidx)
+                Xu, uid, rowptr, rowidx = cache[key]
+                try:
+                    vn.engine.set_dedup(self.engine_batch(mb, bi), Xu, uid, rowptr, rowidx)
+                except Exception:
+                    return 0
+                total += Xu.shape[0]
+        self._dd_cache = cache
+        self.dedup_on = True
+        return total
 
     def select_mor(self, mb):
         d = self.mor[mb]
@@ -670,7 +730,7 @@ class VarNet:
         if MORinp is not None:
             Input = np.hstack([Input, np.tile(MORinp, [Input.shape[0], 1])])
             biInput = np.hstack([biInput, np.tile(MORinp, [biInput.shape[0], 1])])
-        return dict(Input=eng.dev(Input), gcoef=eng.dev(gcoef),
+        return dict(Input=eng.dev(Input), Input_host=Input, gcoef=eng.dev(gcoef),
                     source=eng.dev(src.reshape(-1)) if self.lossOpt['isSource'] else None,
                     biInput=eng.dev(biInput), biLabel=eng.dev(biLabel.reshape(-1)),
                     N_rows=N_rows, dNt_rows=dNt_rows,
@@ -763,7 +823,8 @@ class VarNet:
               verbose=True, saveFreq=100, pltReplace=True, saveMORdata=False, frac=None,
               addTrainPts=True, suppFactor=1.0, multiTrainUpd=False, trainUpdelay=2e4, tolUpd=0.01,
               reinitrain=True, updateWeights=False, normalizeW=False, adjustWeight=False,
-              useOriginalW=False, batchNum=None, batchLen=None, shuffleData=False, shuffleFreq=1):
+              useOriginalW=False, batchNum=None, batchLen=None, shuffleData=False, shuffleFreq=1,
+              dedup=False):
         """Training loop of /root/reference/VarNet.py:1197-1421 (uniform, random and residual-driven
         "optimal" sampling with re-initialisation and re-weighting)."""
         if uf.isnone(folderpath) or uf.isempty(folderpath):
@@ -794,6 +855,8 @@ class VarNet:
         eng, fd = self.engine, self.fixData
         torch = eng.torch
         tData = self._build_tdata(batchNum, batchLen)        # first set is always uniform (VarNet.py:1300)
+        if dedup and not shuffleData:
+            tData.enable_dedup()                                # extension: one evaluation per unique point
         trainRes = TrainResult(folderpath if self.rank == 0 else None, fd.cEx is not None, verbose, saveFreq)
         trainRes.initializeCase(self, argDict)
         self.trainRes = trainRes
