@@ -12,11 +12,15 @@
 //   * activations (a_l, zdot_l) of all layers stay in registers for the reverse pass;
 //   * weights sit in LDS once per workgroup as [in-feature][out-position] images (stride 65,
 //     conflict-free for both the forward and the transposed backward fragment reads);
-//   * weight gradients contract over points, which needs the operands transposed: each wave
-//     bounces 32x64 tiles through a private LDS buffer (ds_write_b32 / ds_read_b128) and
-//     accumulates G[in][out] (+ bias row through a constant-one input row) with MFMA, then adds
-//     the tile into the workgroup's LDS gradient image (ds_add_f32), which is the flat parameter
-//     layout; one partial per workgroup goes to HBM at the end.
+//   * weight gradients contract over points, which needs the operands transposed: all four waves
+//     publish their 32 point-columns of (a | adot) and (zbar | zdbar) into two shared LDS images
+//     [64 rows][128 points] (ds_write_b32), barrier, and wave w contracts ONE 32x32 output tile over
+//     the 128 points (ds_read_b128 fragments) into a persistent register accumulator per layer -- no
+//     atomics in the tile loop, fixed summation order; the bias gradient rides along as a
+//     constant-one input row.  After the loop the accumulators are added wave by wave into an LDS
+//     gradient image and one partial per workgroup goes to HBM.
+//   * this is the 4-wave (one wave per SIMD) geometry; vn_fused16.hip is the 8-wave geometry of the
+//     same algorithm, which VN_KERNEL_AUTO prefers where it is instantiated.
 //
 // Math: oracle/tangent_ref.py; reference graph TFModel.py:536, 643-668, 709.
 #include "vn_internal.h"
@@ -90,16 +94,6 @@ __device__ __forceinline__ float opaque(float x) {
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// Lanes of one wave exchange data through the wave's private LDS buffer.  The hardware executes a
-// wave's LDS instructions in order, but the compiler reasons per thread: without a fence it may
-// forward or reorder a lane's loads across ANOTHER lane's stores.  Wavefront-scope fences + the
-// wave barrier pin the program order of the LDS traffic (no s_barrier is emitted).
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 struct LaneC {
