@@ -299,6 +299,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
   const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
   const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
 
+  // the quadrature index of this lane's point is the same in every interior tile (tiles start at
+  // whole test functions), so the periodic FE table entries are lane constants
+  const int pq_l = (wave * 32 + lc.c) % q;
+  const float tab_dnt = A.time_dependent ? A.fedNt[pq_l] : 0.f;
+  const float tab_w = A.feW ? A.feW[pq_l] : 1.f;
+  const float tab_N = A.feN[pq_l];
 #ifdef VN_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -474,12 +480,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void vn_fused_kernel(VnFusedArgsD A) {
     // ---------------------------------------------------------------- weak-form epilogue
     float ubar = 0.f, udbar = 0.f;
     if (interior) {
-      const int pq = pt % q;
       // per-row tables (non-uniform supports, VarNetUtility.py:506-523) override the periodic ones
-      const float dnt = !A.time_dependent ? 0.f : (A.dNtrow ? (valid ? A.dNtrow[row] : 0.f) : A.fedNt[pq]);
-      const float wq = A.feW ? A.feW[pq] : 1.f;
+      const float dnt = !A.time_dependent ? 0.f : (A.dNtrow ? (valid ? A.dNtrow[row] : 0.f) : tab_dnt);
+      const float wq = tab_w;
       float t = ud - dnt * u;                                           // TFModel.py:653-655
-      if (A.src) t -= (valid ? A.src[row] : 0.f) * (A.Nrow ? (valid ? A.Nrow[row] : 0.f) : A.feN[pq]);           // :657
+      if (A.src) t -= (valid ? A.src[row] : 0.f) * (A.Nrow ? (valid ? A.Nrow[row] : 0.f) : tab_N);           // :657
       t *= wq;                                                          // :660
       if (!valid) t = 0.f;
       // R_k = sum over the test function's q quadrature points: xor-shuffle tree inside the wave

@@ -292,6 +292,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
   const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
 
+  // the quadrature index of this lane's point is the same in every interior tile (tiles start at
+  // whole test functions), so the periodic FE table entries are lane constants
+  const int pq_l = (wave * CW + lc.c) % q;
+  const float tab_dnt = A.time_dependent ? A.fedNt[pq_l] : 0.f;
+  const float tab_w = A.feW ? A.feW[pq_l] : 1.f;
+  const float tab_N = A.feN[pq_l];
 #ifdef VN_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -427,12 +433,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
         udbar = A.seed_ud[row * A.ostride];
       }
     } else if (interior) {
-      const int pq = pt % q;
       // per-row tables (non-uniform supports, VarNetUtility.py:506-523) override the periodic ones
-      const float dnt = !A.time_dependent ? 0.f : (A.dNtrow ? (valid ? A.dNtrow[row] : 0.f) : A.fedNt[pq]);
-      const float wq = A.feW ? A.feW[pq] : 1.f;
+      const float dnt = !A.time_dependent ? 0.f : (A.dNtrow ? (valid ? A.dNtrow[row] : 0.f) : tab_dnt);
+      const float wq = tab_w;
       float t = ud - dnt * u;
-      if (A.src) t -= (valid ? A.src[row] : 0.f) * (A.Nrow ? (valid ? A.Nrow[row] : 0.f) : A.feN[pq]);
+      if (A.src) t -= (valid ? A.src[row] : 0.f) * (A.Nrow ? (valid ? A.Nrow[row] : 0.f) : tab_N);
       t *= wq;
       if (!valid) t = 0.f;
       const int seg = q < CW ? q : CW;
