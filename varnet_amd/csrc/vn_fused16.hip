@@ -211,6 +211,14 @@ template <int L, int KS>
 __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A) {
   using LY = Lay<L, KS>;
   constexpr int MT = mtiles(KS);
+  // EDGE: the last 16-row tile holds a single k-step (features 4(KS-1) .. 4(KS-1)+3, e.g. 48,49 of a
+  // 50-wide layer).  Producing those few rows with an MFMA tile costs a quarter of the matrix work of
+  // the layer; instead every lane accumulates its share of their dot products on the VALU (which runs
+  // under the partner wave's MFMAs) and the four lane groups are summed with two shuffles.
+  constexpr bool EDGE = (KS % 4) == 1 && KS > 1;
+  constexpr int MTM = EDGE ? MT - 1 : MT;            // row tiles produced by MFMA in hidden layers
+  constexpr int NVE = (KS == 13) ? 2 : 4;            // edge features that can be non-padding
+  constexpr int EPOS = 16 * (MT - 1);                // accumulator row of edge feature 0
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VnNet& net = A.net;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -362,9 +370,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       auto zdin = [&](int j) { return ptn[j >> 2][j & 3]; };
       auto stA = [&](int j) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * zin(j)); };
       auto stB = [&](float e) { return __builtin_amdgcn_rcpf(1.0f + e); };
-      float wf[MT];
+      float wf[MTM], we[NVE], ev[NVE], et[NVE];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) wf[m] = Wl[lc.offF + 16 * m];
+      for (int m = 0; m < MTM; ++m) wf[m] = Wl[lc.offF + 16 * m];
+#pragma unroll
+      for (int v = 0; v < NVE; ++v) {
+        we[v] = EDGE ? Wl[lc.offF - lc.c + EPOS + 4 * v] : 0.f;
+        ev[v] = 0.f;
+        et[v] = 0.f;
+      }
       float cs = stB(stA(0));
       float cq = cs * (1.f - cs) * zdin(0);
       a[l - 2][0] = cs;
@@ -373,14 +387,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       float e2 = (KS > 2) ? stA(2) : 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        float wn[MT];
+        float wn[MTM], wen[NVE];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) wn[m] = (ks + 1 < KS) ? Wl[4 * (ks + 1) * WS + lc.offF + 16 * m] : 0.f;
+        for (int m = 0; m < MTM; ++m) wn[m] = (ks + 1 < KS) ? Wl[4 * (ks + 1) * WS + lc.offF + 16 * m] : 0.f;
+#pragma unroll
+        for (int v = 0; v < NVE; ++v)
+          wen[v] = (EDGE && ks + 1 < KS) ? Wl[4 * (ks + 1) * WS + lc.offF - lc.c + EPOS + 4 * v] : 0.f;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MTM; ++m) {
           nv[m] = mfma16(wf[m], cs, nv[m]);
           nt[m] = mfma16(wf[m], cq, nt[m]);
+        }
+        if (EDGE) {
+#pragma unroll
+          for (int v = 0; v < NVE; ++v) { ev[v] += we[v] * cs; et[v] += we[v] * cq; }
         }
         float e3 = 0.f, s2 = 0.f, q1 = 0.f;
         if (ks + 3 < KS) e3 = stA(ks + 3);
@@ -394,7 +415,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
         __builtin_amdgcn_sched_barrier(0);
         cs = s1; cq = q1; s1 = s2; e2 = e3;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) wf[m] = wn[m];
+        for (int m = 0; m < MTM; ++m) wf[m] = wn[m];
+#pragma unroll
+        for (int v = 0; v < NVE; ++v) we[v] = wen[v];
+      }
+      if (EDGE) {
+        // sum the four lane groups' shares; group g keeps edge feature g
+        float zsel = 0.f, tsel = 0.f;
+#pragma unroll
+        for (int v = 0; v < NVE; ++v) {
+          float x = ev[v], y = et[v];
+          x += __shfl_xor(x, 16, 64);  y += __shfl_xor(y, 16, 64);
+          x += __shfl_xor(x, 32, 64);  y += __shfl_xor(y, 32, 64);
+          if (lc.g == v) { zsel = x; tsel = y; }
+        }
+        nv[MT - 1][0] += zsel;                       // bias was loaded above
+        nt[MT - 1][0] = tsel;
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) { pv[m] = nv[m]; ptn[m] = nt[m]; }
@@ -523,23 +559,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       f32x4 accv[MT], acct[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) { accv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acct[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      float wf[MT];
+      float wf[MTM], we[NVE], ev[NVE], et[NVE];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) wf[m] = Wl[lc.offB[m] + vpos(0, 0)];
+      for (int m = 0; m < MTM; ++m) wf[m] = Wl[lc.offB[m] + vpos(0, 0)];
+#pragma unroll
+      for (int v = 0; v < NVE; ++v) {
+        we[v] = EDGE ? Wl[(4 * (KS - 1) + v) * WS + 4 * lc.g + vpos(0, 0)] : 0.f;
+        ev[v] = 0.f;
+        et[v] = 0.f;
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        float wn[MT];
+        float wn[MTM], wen[NVE];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) wn[m] = (ks + 1 < KS) ? Wl[lc.offB[m] + vpos(ks + 1, 0)] : 0.f;
+        for (int m = 0; m < MTM; ++m) wn[m] = (ks + 1 < KS) ? Wl[lc.offB[m] + vpos(ks + 1, 0)] : 0.f;
+#pragma unroll
+        for (int v = 0; v < NVE; ++v)
+          wen[v] = (EDGE && ks + 1 < KS) ? Wl[(4 * (KS - 1) + v) * WS + 4 * lc.g + vpos(ks + 1, 0)] : 0.f;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MTM; ++m) {
           accv[m] = mfma16(wf[m], zb[ks], accv[m]);
           acct[m] = mfma16(wf[m], zdb[ks], acct[m]);
         }
+        if (EDGE) {
+#pragma unroll
+          for (int v = 0; v < NVE; ++v) { ev[v] += we[v] * zb[ks]; et[v] += we[v] * zdb[ks]; }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) wf[m] = wn[m];
+        for (int m = 0; m < MTM; ++m) wf[m] = wn[m];
+#pragma unroll
+        for (int v = 0; v < NVE; ++v) we[v] = wen[v];
+      }
+      if (EDGE) {
+        float vsel = 0.f, tsel = 0.f;
+#pragma unroll
+        for (int v = 0; v < NVE; ++v) {
+          float x = ev[v], y = et[v];
+          x += __shfl_xor(x, 16, 64);  y += __shfl_xor(y, 16, 64);
+          x += __shfl_xor(x, 32, 64);  y += __shfl_xor(y, 32, 64);
+          if (lc.g == v) { vsel = x; tsel = y; }
+        }
+        accv[MT - 1][0] = vsel;
+        acct[MT - 1][0] = tsel;
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -621,7 +684,7 @@ size_t lds_one() {
 int pick_ks(int hmax) {
   if (hmax <= 20) return 5;
   if (hmax <= 32) return 8;
-  if (hmax <= 52) return 13;
+  if (hmax <= 50) return 13;      // NVE == 2: the edge k-step carries features 48, 49 only
   return 0;
 }
 
