@@ -3,9 +3,12 @@
 import sys, os, numpy as np, torch
 sys.path.insert(0, '.')
 from varnet_amd import engine
-names = sys.argv[1:3]
-kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+if ',' in sys.argv[1]:                      # python tools/ab_perf.py a,b,c [kernel] [rounds]
+    names = sys.argv[1].split(','); rest = sys.argv[2:]
+else:
+    names = sys.argv[1:3]; rest = sys.argv[3:]
+kernel = int(rest[0]) if len(rest) > 0 else 0
+rounds = int(rest[1]) if len(rest) > 1 else 5
 d_in, dim, widths, q, n_k, nB = 3, 2, [50]*5, 64, 100000, 14000
 n = n_k*q
 g = torch.Generator(device='cuda'); g.manual_seed(0)
@@ -34,5 +37,5 @@ for r in range(rounds):
         res[nm].append(ms)
 for nm in names:
     v = np.array(res[nm]); print('%-12s kernel ms: median %.4f  min %.4f  max %.4f' % (nm, np.median(v), v.min(), v.max()))
-a, b = np.median(res[names[0]]), np.median(res[names[1]])
-print('B/A = %.4f' % (b / a))
+a = np.median(res[names[0]])
+for nm in names[1:]: print('%s / %s = %.4f' % (nm, names[0], np.median(res[nm]) / a))

@@ -21,7 +21,8 @@ eng.set_weights([1,1,1])
 for _ in range(3): eng.train_step(0)
 torch.cuda.synchronize()
 st = np.array(eng.debug_stamps(), dtype=np.float64)
-names = ['inputs', 'fwd GEMMs', 'output+epilogue', 'zbar_L', 'wgrad out', 'wgrad hidden', 'bwd-data+zbar', 'wgrad L1']
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+names = ['inputs+forward', 'epilogue', 'wgrad publish', 'wait publish barrier', 'wgrad contraction', 'wait release barrier', 'bwd GEMMs + zbar', '-'] if mode == 2 else ['inputs', 'fwd GEMMs', 'output+epilogue', 'zbar_L', 'wgrad out', 'wgrad hidden', 'bwd-data+zbar', 'wgrad L1']
 tiles = (n/128 + nB/128)/256
 tot = st.sum()
 print('cycles/tile:', tot/tiles)

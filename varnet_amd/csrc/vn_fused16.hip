@@ -90,20 +90,53 @@ struct WG {
   static_assert(NT < NW || NTB % TPW == 0, "a wave's tiles must share a row tile");
 };
 
+#ifdef VN_STAMPS
+// Diagnostic build only (-DVN_STAMPS=1: phases of the tile loop; =2: inside the cooperative weight
+// gradient: 0 inputs+forward, 1 epilogue, 2 publish, 3 wait at the publish barrier, 4 contraction,
+// 5 wait at the release barrier, 6 backward GEMMs + zbar).
+#define STAMP_RAW(i)                                                      \
+  do {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    unsigned long long t_;                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    stamp_acc[i] += t_ - stamp_prev;                                      \
+    stamp_prev = t_;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+#if VN_STAMPS == 2
+#define STAMP(i) STAMP_RAW(((i) <= 1 ? 0 : (i) == 2 ? 1 : 6))
+#define WSTAMP(i) STAMP_RAW(i)
+#else
+#define STAMP(i) STAMP_RAW(i)
+#define WSTAMP(i) do {} while (0)
+#endif
+#define STAMP_PARAMS , unsigned long long (&stamp_acc)[8], unsigned long long& stamp_prev
+#define STAMP_ARGS , stamp_acc, stamp_prev
+#else
+#define STAMP(i) do {} while (0)
+#define WSTAMP(i) do {} while (0)
+#define STAMP_PARAMS
+#define STAMP_ARGS
+#endif
+
 // Cooperative weight gradient (see vn_fused.hip): all waves publish their 16 point-columns of
 // the transposed operands, then each wave contracts its output tile(s) over its share of the
 // 128 points into persistent accumulators.
 template <int KSA, int KSB, bool RAWA, int NACC>
 __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float (&azd)[KSA],
                                             const float (&bv)[KSB], const float (&bt)[KSB], float* TA,
-                                            float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC]) {
+                                            float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC] STAMP_PARAMS) {
   using W = WG<KSA, KSB>;
   static_assert(NACC == W::TPW, "accumulator count");
   const int t0 = (W::NT >= NW) ? wave * W::TPW : wave % W::NT;
   const int sidx = (W::NT >= NW) ? 0 : wave / W::NT;
   const int m = t0 / W::NTB, n0 = t0 % W::NTB;
-  const int rdA = (16 * m + lc.c) * TSW + sidx * W::PTS + lc.g * W::PG;
-  const int rdB = (16 * n0 + lc.c) * TSW + sidx * W::PTS + lc.g * W::PG;
+  // ds_read_b128 is served in 16-lane groups that mix two neighbouring lane groups g over 64
+  // banks: with the row stride == 4 (mod 64) the 16 rows of a group are conflict-free only if
+  // the point offsets of g and g^1 differ by a multiple of 64 -> g = 0,1,2,3 start at 0,64,32,96.
+  const int goff = (W::PG == 32) ? 64 * (lc.g & 1) + 32 * (lc.g >> 1) : lc.g * W::PG;
+  const int rdA = (16 * m + lc.c) * TSW + sidx * W::PTS + goff;
+  const int rdB = (16 * n0 + lc.c) * TSW + sidx * W::PTS + goff;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -120,7 +153,9 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
     if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
+    WSTAMP(2);
     __syncthreads();
+    WSTAMP(3);
     f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA]);
     f32x4 b4[W::TPW];
 #pragma unroll
@@ -146,7 +181,9 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
 #pragma unroll
       for (int t = 0; t < W::TPW; ++t) b4[t] = bn[t];
     }
+    WSTAMP(4);
     __syncthreads();
+    WSTAMP(5);
   }
 }
 
@@ -171,19 +208,6 @@ __device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl,
   }
 }
 
-#ifdef VN_STAMPS
-#define STAMP(i)                                                          \
-  do {                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    unsigned long long t_;                                                \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-    stamp_acc[i] += t_ - stamp_prev;                                      \
-    stamp_prev = t_;                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-  } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
 
 struct VnFusedArgsD {
   VnNet net;
@@ -536,7 +560,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       sv[0] = (lc.g == 0) ? ubar : 0.f;
       st[0] = (lc.g == 0) ? udbar : 0.f;
       STAMP(3);
-      wgrad_layer<KS, 1, false>(a[L - 1], zd[L - 1], sv, st, TA, TB, lc, wave, wacco);
+      wgrad_layer<KS, 1, false>(a[L - 1], zd[L - 1], sv, st, TA, TB, lc, wave, wacco STAMP_ARGS);
       STAMP(4);
     }
 #pragma unroll
@@ -553,7 +577,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
           zd[0][ks] = rt[ks >> 2][ks & 3];
         }
       }
-      wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2]);
+      wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
       STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
       f32x4 accv[MT], acct[MT];
@@ -614,7 +638,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       }
       STAMP(6);
     }
-    wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1);
+    wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1 STAMP_ARGS);
     STAMP(7);
   }
 
