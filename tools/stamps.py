@@ -2,7 +2,7 @@
 import sys, os, numpy as np, torch
 sys.path.insert(0, '.')
 from varnet_amd import engine
-engine.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), "libvarnet_hip_stamps.so")
+engine.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), os.environ.get("VN_STAMPS_LIB", "libvarnet_hip_stamps.so"))
 from varnet_amd.engine import VNEngine
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 50
@@ -22,7 +22,7 @@ for _ in range(3): eng.train_step(0)
 torch.cuda.synchronize()
 st = np.array(eng.debug_stamps(), dtype=np.float64)
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-names = ['inputs+forward', 'epilogue', 'wgrad publish', 'wait publish barrier', 'wgrad contraction', 'wait release barrier', 'bwd GEMMs + zbar', '-'] if mode == 2 else ['inputs', 'fwd GEMMs', 'output+epilogue', 'zbar_L', 'wgrad out', 'wgrad hidden', 'bwd-data+zbar', 'wgrad L1']
+names = ['inputs+forward', 'out layer + int1', 'wait barrier 1', 'R_k', 'wait barrier 2', 'seeds', 'zbar_L', 'rest of reverse'] if mode == 3 else ['inputs+forward', 'epilogue', 'wgrad publish', 'wait publish barrier', 'wgrad contraction', 'wait release barrier', 'bwd GEMMs + zbar', '-'] if mode == 2 else ['inputs', 'fwd GEMMs', 'output+epilogue', 'zbar_L', 'wgrad out', 'wgrad hidden', 'bwd-data+zbar', 'wgrad L1']
 tiles = (n/128 + nB/128)/256
 tot = st.sum()
 print('cycles/tile:', tot/tiles)

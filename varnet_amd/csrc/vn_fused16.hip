@@ -106,15 +106,27 @@ struct WG {
 #if VN_STAMPS == 2
 #define STAMP(i) STAMP_RAW(((i) <= 1 ? 0 : (i) == 2 ? 1 : 6))
 #define WSTAMP(i) STAMP_RAW(i)
+#define ESTAMP(i) do {} while (0)
+#elif VN_STAMPS == 3
+// epilogue detail: 0 inputs+forward, 1 output layer + int1, 2 wait barrier 1, 3 R_k, 4 wait barrier 2,
+// 5 seeds, 6 zbar_L, 7 rest of the reverse pass
+#define STAMP(i) STAMP_RAW(((i) <= 1 ? 0 : (i) == 2 ? 5 : (i) == 3 ? 6 : 7))
+#define WSTAMP(i) do {} while (0)
+#define ESTAMP(i) STAMP_RAW(i)
 #else
 #define STAMP(i) STAMP_RAW(i)
 #define WSTAMP(i) do {} while (0)
+#define ESTAMP(i) do {} while (0)
+#endif
+#ifndef VN_STAMP_WAVE
+#define VN_STAMP_WAVE 0                    // which wave of block 0 reports
 #endif
 #define STAMP_PARAMS , unsigned long long (&stamp_acc)[8], unsigned long long& stamp_prev
 #define STAMP_ARGS , stamp_acc, stamp_prev
 #else
 #define STAMP(i) do {} while (0)
 #define WSTAMP(i) do {} while (0)
+#define ESTAMP(i) do {} while (0)
 #define STAMP_PARAMS
 #define STAMP_ARGS
 #endif
@@ -507,7 +519,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       } else if (lc.g == 0) {
         sInt[pt] = t;                                                 // q does not divide the tile: serial sum
       }
+      ESTAMP(1);
       __syncthreads();
+      ESTAMP(2);
       if (tid < TT) {
         float R = 0.f;
         if (qtree) {
@@ -527,7 +541,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
         }
         sR[tid] = s;
       }
+      ESTAMP(3);
       __syncthreads();
+      ESTAMP(4);
       const float s = (pt < TPTS ? sR[pt / q] : 0.f) * wq;
       udbar = s;
       ubar = -dnt * s;
@@ -644,7 +660,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
 
   // ------------------------------------------------------------------ epilogue
 #ifdef VN_STAMPS
-  if (A.stamps && blockIdx.x == 0 && tid == 0)
+  if (A.stamps && blockIdx.x == 0 && tid == 64 * VN_STAMP_WAVE)
     for (int i = 0; i < 8; ++i) A.stamps[i] = stamp_acc[i];
 #endif
   __syncthreads();
