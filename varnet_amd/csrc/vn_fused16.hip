@@ -199,6 +199,183 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
   }
 }
 
+// ---- 50-wide hidden layers (KS == 13) -----------------------------------------------------------
+// A 51 x 50 gradient (50 inputs + bias row, 50 outputs) padded to 4 x 4 tiles of 16 x 16 wastes 38 %
+// of the matrix work.  Here the 48 x 48 core is 3 x 3 tiles of v_mfma_f32_16x16x4_f32 and the two
+// thin borders -- rows {48, 49, bias} x all columns and columns {48, 49} x rows 0..47 -- are
+// accumulated with v_mfma_f32_4x4x1_16B_f32: 16 independent 4 x 4 blocks per instruction, one point
+// per instruction, so a border of 4 rows x 64 columns costs 8 cycles per point instead of 32.
+// Jobs (w and w+4 share a SIMD; every SIMD gets 3 tile-times instead of 4).  The matrix pipe
+// alternates between the two waves of a SIMD per instruction, so an 8-cycle 4x4x1 stream paired with a
+// 32-cycle 16x16x4 stream would crawl at the partner's pace: the two border jobs share a SIMD.
+//   w = 0,1,2: tile (w,0) over all 128 points + tile (w,2) over one half of the points
+//   w = 4,5,6: tile (w-4,1) over all points   + tile (w-4,2) over the other half
+//   w = 3: row border          w = 7: column border
+// so the six tile waves run one instruction stream (48 MFMAs per round) and share the A fragment.
+// D layout of the 4x4x1 MFMA: lane 4b+j, register i  =  sum_p A[lane 4b+i] * B[lane 4b+j].
+struct H13 {
+  static constexpr int ROW48 = vpos(12, 0), ROW49 = vpos(12, 1);      // accumulator rows of features 48, 49
+  static constexpr int ONES = vones(13);                              // bias ("ones") row of TA
+  static constexpr int ZERO = ONES + 1;                               // a row nobody writes
+  __device__ static __forceinline__ int edge_row(int i) { return i == 0 ? ROW48 : i == 1 ? ROW49 : i == 2 ? ONES : ZERO; }
+  __device__ static __forceinline__ int edge_col(int j) { return j == 0 ? ROW48 : j == 1 ? ROW49 : ZERO; }
+  // role 0: core tiles; 1: row border; 2: column border
+  __device__ static __forceinline__ int role(int wave) { return wave == 3 ? 1 : wave == 7 ? 2 : 0; }
+  __device__ static __forceinline__ int tile_m(int wave) { return wave & 3; }
+  __device__ static __forceinline__ int tile_n(int wave) { return wave >= 4 ? 1 : 0; }
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void h13_contract(const float* TA, const float* TB, const LaneC& lc, int wave, int lane,
+                                             f32x4 (&acc)[2]) {
+  const int role = H13::role(wave);
+  if (role == 1 || role == 2) {
+    // border job: every lane walks all 128 points, 4 per ds_read_b128; two accumulators alternate
+    const int sel = lane & 3;
+    const int rdA = (role == 1 ? H13::edge_row(sel) : lane) * TSW;
+    const int rdB = (role == 1 ? lane : H13::edge_col(sel)) * TSW;
+    // 8 points per stage, two register buffers used alternately (no rotation copies, so a stage's
+    // loads are waited for only one stage later): the 16 MFMAs of a stage cover the LDS latency
+    constexpr int PS = 8, NSTG = TILE / PS;
+    f32x4 a0[2], b0[2], a1[2], b1[2];
+    auto load = [&](f32x4 (&a4)[2], f32x4 (&b4)[2], int stage) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        a4[h] = *reinterpret_cast<const f32x4a*>(&TA[rdA + PS * stage + 4 * h]);
+        b4[h] = *reinterpret_cast<const f32x4a*>(&TB[rdB + PS * stage + 4 * h]);
+      }
+    };
+    auto compute = [&](const f32x4 (&a4)[2], const f32x4 (&b4)[2]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0] = mfma4(a4[0][e], b4[0][e], acc[0]);
+        acc[1] = mfma4(a4[1][e], b4[1][e], acc[1]);
+      }
+    };
+    load(a0, b0, 0);
+#pragma unroll 1
+    for (int q = 0; q < NSTG; q += 2) {
+      load(a1, b1, q + 1);
+      compute(a0, b0);
+      if (q + 2 < NSTG) load(a0, b0, q + 2);
+      compute(a1, b1);
+    }
+    return;
+  }
+  const int m = H13::tile_m(wave), n0 = H13::tile_n(wave);
+  const int goff = 64 * (lc.g & 1) + 32 * (lc.g >> 1);         // see wgrad_layer
+  const int rdA = (16 * m + lc.c) * TSW + goff;
+  const int rdB = (16 * n0 + lc.c) * TSW + goff;
+  const int rdC = (16 * 2 + lc.c) * TSW + goff;
+  // a lane group's 32 points are taken in two halves of 16: the shared tile (m,2) only in the first
+  const int base1 = (wave >= NW / 2) ? 16 : 0, base2 = 16 - base1;
+  f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA + base1]);
+  f32x4 b4 = *reinterpret_cast<const f32x4a*>(&TB[rdB + base1]);
+  f32x4 c4 = *reinterpret_cast<const f32x4a*>(&TB[rdC + base1]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 an, bn, cn = c4;
+    if (j + 1 < 4) {
+      an = *reinterpret_cast<const f32x4a*>(&TA[rdA + base1 + 4 * (j + 1)]);
+      bn = *reinterpret_cast<const f32x4a*>(&TB[rdB + base1 + 4 * (j + 1)]);
+      cn = *reinterpret_cast<const f32x4a*>(&TB[rdC + base1 + 4 * (j + 1)]);
+    } else {
+      an = *reinterpret_cast<const f32x4a*>(&TA[rdA + base2]);
+      bn = *reinterpret_cast<const f32x4a*>(&TB[rdB + base2]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0] = mfma16(a4[e], b4[e], acc[0]);
+      acc[1] = mfma16(a4[e], c4[e], acc[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    a4 = an; b4 = bn; c4 = cn;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 an = a4, bn = b4;
+    if (j + 1 < 4) {
+      an = *reinterpret_cast<const f32x4a*>(&TA[rdA + base2 + 4 * (j + 1)]);
+      bn = *reinterpret_cast<const f32x4a*>(&TB[rdB + base2 + 4 * (j + 1)]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0] = mfma16(a4[e], b4[e], acc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    a4 = an; b4 = bn;
+  }
+}
+
+// both rounds of a 50-wide hidden layer
+__device__ __forceinline__ void h13_wgrad_layer(const float (&av)[13], const float (&azd)[13], const float (&bv)[13],
+                                                const float (&bt)[13], float* TA, float* TB, const LaneC& lc, int wave,
+                                                int lane, f32x4 (&acc)[2] STAMP_PARAMS) {
+  using W = WG<13, 13>;
+  static_assert(W::ONES == H13::ONES, "bias row");
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ks = 0; ks < 13; ++ks) {
+      float v;
+      if (half == 0) v = av[ks];
+      else {
+        const float x = opaque(av[ks]);
+        v = x * (1.f - x) * azd[ks];
+      }
+      TA[lc.twr + vpos(ks, 0) * TSW] = v;
+    }
+    if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 13; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
+    WSTAMP(2);
+    __syncthreads();
+    WSTAMP(3);
+    h13_contract(TA, TB, lc, wave, lane, acc);
+    WSTAMP(4);
+    __syncthreads();
+    WSTAMP(5);
+  }
+}
+
+template <int GS>
+__device__ __forceinline__ void h13_flush(const f32x4 (&acc)[2], float* Gl, const LaneC& lc, int wave, int lane) {
+  const int role = H13::role(wave);
+  if (role == 1) {                                   // rows 48, 49, bias x every column position
+    const int pos = lane;                            // 4b + j
+    const int col = vfeat(pos);
+    if (vks(pos) < 13 && col < GS) {
+      Gl[48 * GS + col] += acc[0][0] + acc[1][0];
+      Gl[49 * GS + col] += acc[0][1] + acc[1][1];
+      Gl[52 * GS + col] += acc[0][2] + acc[1][2];    // bias row of the gradient image (row 4*KS)
+    }
+    return;
+  }
+  if (role == 2) {                                   // rows 0..47 x columns 48, 49
+    const int j = lane & 3;
+    if (j < 2 && 48 + j < GS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pos = (lane & ~3) + i;             // 4b + i
+        if (pos < 48) Gl[vfeat(pos) * GS + 48 + j] += acc[0][i] + acc[1][i];
+      }
+    }
+    return;
+  }
+  const int m = H13::tile_m(wave), n0 = H13::tile_n(wave);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int col = vfeat(16 * (t ? 2 : n0) + lc.c);           // slot 1: this wave's share of tile (m,2)
+    if (col < GS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Gl[(4 * (4 * m + i) + lc.g) * GS + col] += acc[t][i];
+    }
+  }
+}
+
 template <int KSA, int KSB, int GS, int NACC>
 __device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl, const LaneC& lc, int wave) {
   using W = WG<KSA, KSB>;
@@ -257,7 +434,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   constexpr int EPOS = 16 * (MT - 1);                // accumulator row of edge feature 0
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VnNet& net = A.net;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int P = net.P;
   float* W1 = lds + LY::W1_OFF;
   float* WH = lds + LY::WH_OFF;
@@ -314,13 +491,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   using W1G = WG<KS0, KS>;
   using WHG = WG<KS, KS>;
   using WOG = WG<KS, 1>;
-  f32x4 wacc1[W1G::TPW], wacch[L > 1 ? L - 1 : 1][WHG::TPW], wacco[WOG::TPW];
+  constexpr bool HID13 = (KS == 13);                 // 50-wide hidden layers: 3x3 core tiles + 4x4x1 borders
+  constexpr int NHACC = HID13 ? 2 : WHG::TPW;
+  f32x4 wacc1[W1G::TPW], wacch[L > 1 ? L - 1 : 1][NHACC], wacco[WOG::TPW];
 #pragma unroll
   for (int t = 0; t < W1G::TPW; ++t) wacc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int l = 0; l < (L > 1 ? L - 1 : 1); ++l)
 #pragma unroll
-    for (int t = 0; t < WHG::TPW; ++t) wacch[l][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NHACC; ++t) wacch[l][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < WOG::TPW; ++t) wacco[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -593,7 +772,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
           zd[0][ks] = rt[ks >> 2][ks & 3];
         }
       }
-      wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
+      if constexpr (HID13) h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, lane, wacch[l - 2] STAMP_ARGS);
+      else wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
       STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
       f32x4 accv[MT], acct[MT];
@@ -671,7 +851,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
 #pragma unroll
       for (int l = 2; l <= L; ++l)
-        wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
+        if constexpr (HID13) h13_flush<LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, lane);
+        else wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
       wgrad_flush<KS, 1, 1>(wacco, Gacc + LY::GO_OFF, lc, wave);
     }
     __syncthreads();
