@@ -1,4 +1,8 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d gpurun_out/pmc_icache -o ic --output-format csv -- python tools/ab_perf.py base work 3 1 > gpurun_out/pmc_icache.log 2>&1
-ls gpurun_out/pmc_icache
+mkdir -p gpurun_out
+for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace -d gpurun_out/pmc_sq_$tag -o p --output-format csv -- python tools/quick_perf.py 3 > gpurun_out/pmc_sq_$tag.log 2>&1 || { tail -5 gpurun_out/pmc_sq_$tag.log; exit 1; }
+done
+ls gpurun_out

@@ -199,6 +199,111 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
   }
 }
 
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+// ---- thin layers: output layer (one column) and input layer with d_in <= 3 (rows x0..x2 + bias) ---
+// Few rows (or columns) against all 64 positions is one 4x4x1 MFMA per point, so there is nothing to
+// share between waves: every wave transposes its own 16 points through its own 16 columns of the
+// images and contracts them at once -- no workgroup barrier, 16 short MFMAs per round instead of 16
+// long ones, and the partial sums of the 8 waves meet in the fixed-order flush.
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS operations of one wave complete in order; the fences stop the compiler from moving a
+  // lane's loads across other lanes' stores (per-thread alias reasoning)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A side: 64 positions (lane = row), B side: rows brow(j) for j = lane & 3;  TRANSPOSED swaps the roles
+template <bool A_IS_LANE>
+__device__ __forceinline__ void thin_contract(const float* TA, const float* TB, int rowsel, int wave, int lane, f32x4& acc) {
+  const int rdA = (A_IS_LANE ? lane : rowsel) * TSW + wave * CW;
+  const int rdB = (A_IS_LANE ? rowsel : lane) * TSW + wave * CW;
+  f32x4 a4[CW / 4], b4[CW / 4];
+#pragma unroll
+  for (int q = 0; q < CW / 4; ++q) {
+    a4[q] = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * q]);
+    b4[q] = *reinterpret_cast<const f32x4a*>(&TB[rdB + 4 * q]);
+  }
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < CW / 4; ++q) {
+    acc = mfma4(a4[q][0], b4[q][0], acc);
+    t = mfma4(a4[q][1], b4[q][1], t);
+    acc = mfma4(a4[q][2], b4[q][2], acc);
+    t = mfma4(a4[q][3], b4[q][3], t);
+  }
+  acc += t;
+}
+
+// output layer: rows = the KS*4 positions of a (and the bias row), one column ubar (lanes g == 0 publish it
+// into row 0, the other lane groups publish zeros into rows 4, 8, 12)
+template <int KS>
+__device__ __forceinline__ void thin_wgrad_out(const float (&av)[KS], const float (&azd)[KS], float ubar, float udbar,
+                                               float* TA, float* TB, const LaneC& lc, int wave, int lane, f32x4& acc) {
+  using W = WG<KS, 1>;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float v = av[ks];
+      if (half == 1) {
+        const float x = opaque(av[ks]);
+        v = x * (1.f - x) * azd[ks];
+      }
+      TA[lc.twr + vpos(ks, 0) * TSW] = v;
+    }
+    if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
+    TB[lc.twr] = (lc.g == 0) ? (half == 0 ? ubar : udbar) : 0.f;
+    wave_lds_sync();
+    thin_contract<true>(TA, TB, (lane & 3) == 0 ? 0 : 4, wave, lane, acc);
+    wave_lds_sync();
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ void thin_flush_out(const f32x4& acc, float* Gl, int lane) {
+  if ((lane & 3) != 0) return;                         // column j = 0 holds the products with ubar
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pos = lane + i;
+    if (vks(pos) < KS) Gl[vfeat(pos)] += acc[i];
+    else if (pos == vones(KS)) Gl[4 * KS] += acc[i];
+  }
+}
+
+// input layer, d_in <= 3: rows x0, x1, x2 (positions 0, 4, 8) and the bias row against all columns
+template <int KS>
+__device__ __forceinline__ void thin_wgrad_in(const float (&xv)[KS0], const float (&gv)[KS0], const float (&bv)[KS],
+                                              const float (&bt)[KS], float* TA, float* TB, const LaneC& lc, int wave,
+                                              int lane, f32x4& acc) {
+  using W = WG<KS0, KS>;
+  const int sel = lane & 3;
+  const int rowsel = sel == 3 ? W::ONES : 4 * sel;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    TA[lc.twr] = (half == 0) ? xv[0] : gv[0];                                     // feature g at position 4g
+    if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
+    wave_lds_sync();
+    thin_contract<false>(TA, TB, rowsel, wave, lane, acc);
+    wave_lds_sync();
+  }
+}
+
+template <int KS, int GS>
+__device__ __forceinline__ void thin_flush_in(const f32x4& acc, float* Gl, int lane) {
+  const int col = vfeat(lane);                         // lane = 4b + j = column position
+  if (vks(lane) < KS && col < GS) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Gl[i * GS + col] += acc[i];
+    Gl[4 * KS0 * GS + col] += acc[3];                  // bias row of the input layer's gradient image
+  }
+}
+
 // ---- 50-wide hidden layers (KS == 13) -----------------------------------------------------------
 // A 51 x 50 gradient (50 inputs + bias row, 50 outputs) padded to 4 x 4 tiles of 16 x 16 wastes 38 %
 // of the matrix work.  Here the 48 x 48 core is 3 x 3 tiles of v_mfma_f32_16x16x4_f32 and the two
@@ -224,10 +329,6 @@ struct H13 {
   __device__ static __forceinline__ int tile_m(int wave) { return wave & 3; }
   __device__ static __forceinline__ int tile_n(int wave) { return wave >= 4 ? 1 : 0; }
 };
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-}
 
 __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, const LaneC& lc, int wave, int lane,
                                              f32x4 (&acc)[2]) {
@@ -504,6 +605,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   for (int t = 0; t < WOG::TPW; ++t) wacco[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const float bo = A.theta[net.boff[L + 1]];
+  const bool thin_in = net.d_in <= 3;                // input-layer weight gradient without workgroup barriers
   const int q = A.integ_num;
   const int TT = TILE / q;                                   // whole test functions per tile
   const int TPTS = TT * q;                                   // points used in an interior tile (<= TILE)
@@ -750,14 +852,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       zdb[ks] = adb * sp;
       zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[L - 1][ks];
     }
-    {
-      float sv[1], st[1];
-      sv[0] = (lc.g == 0) ? ubar : 0.f;
-      st[0] = (lc.g == 0) ? udbar : 0.f;
-      STAMP(3);
-      wgrad_layer<KS, 1, false>(a[L - 1], zd[L - 1], sv, st, TA, TB, lc, wave, wacco STAMP_ARGS);
-      STAMP(4);
-    }
+    STAMP(3);
+    thin_wgrad_out<KS>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0]);
+    STAMP(4);
 #pragma unroll
     for (int l = L; l >= 2; --l) {
       if (l == 2 && L > 2) {                                 // bring layer-1 activations back
@@ -834,7 +931,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       }
       STAMP(6);
     }
-    wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1 STAMP_ARGS);
+    if (thin_in) thin_wgrad_in<KS>(xin, gin, zb, zdb, TA, TB, lc, wave, lane, wacc1[0]);
+    else wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1 STAMP_ARGS);
     STAMP(7);
   }
 
@@ -848,12 +946,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   __syncthreads();
   for (int w = 0; w < NW; ++w) {                     // fixed order: bitwise reproducible sums
     if (wave == w) {
-      wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
+      if (thin_in) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
+      else wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
 #pragma unroll
       for (int l = 2; l <= L; ++l)
         if constexpr (HID13) h13_flush<LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, lane);
         else wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
-      wgrad_flush<KS, 1, 1>(wacco, Gacc + LY::GO_OFF, lc, wave);
+      thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
     }
     __syncthreads();
   }
