@@ -45,7 +45,7 @@ struct Lay {
   static constexpr int WH_OFF = al4(8 * WS);                // [L-1][HP][WS]
   static constexpr int BI_OFF = WH_OFF + (L - 1) * HPWS;    // [L][64] biases in (tile, g, i) order
   static constexpr int WO_OFF = BI_OFF + L * 64;            // [4*KS]
-  static constexpr int MISC_OFF = WO_OFF + al4(4 * KS);     // sInt[128] | sR[128]
+  static constexpr int MISC_OFF = WO_OFF + al4(4 * KS);     // sInt[128] (+128 spare)
   static constexpr int T_OFF = MISC_OFF + 256;              // TA | TB
   static constexpr int G1_SZ = (4 * KS0 + 1) * HP;
   static constexpr int GH_SZ = (HP + 1) * HP;
@@ -542,7 +542,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   float* BI = lds + LY::BI_OFF;
   float* WO = lds + LY::WO_OFF;
   float* sInt = lds + LY::MISC_OFF;
-  float* sR = sInt + TILE;
   float* TA = lds + LY::T_OFF;
   float* TB = TA + TROWS * TSW;
   float* Gacc = lds + LY::T_OFF;
@@ -620,6 +619,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   // the quadrature index of this lane's point is the same in every interior tile (tiles start at
   // whole test functions), so the periodic FE table entries are lane constants
   const int pq_l = (wave * CW + lc.c) % q;
+  const int tf_l = (wave * CW + lc.c) / q;           // ... and so is its test function within the tile
   const float tab_dnt = A.time_dependent ? A.fedNt[pq_l] : 0.f;
   const float tab_w = A.feW ? A.feW[pq_l] : 1.f;
   const float tab_N = A.feN[pq_l];
@@ -803,29 +803,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       ESTAMP(1);
       __syncthreads();
       ESTAMP(2);
-      if (tid < TT) {
-        float R = 0.f;
-        if (qtree) {
-          const int per = q / seg;                                    // partials per test function
-          for (int j = 0; j < per; ++j) R += sInt[tid * per + j];     // :661
-        } else {
-          for (int p = 0; p < q; ++p) R += sInt[tid * q + p];
-        }
-        const long k = r0 / q + tid;
-        float s = 0.f;
-        if (k < A.n_k) {
-          const float dj = A.detJv ? A.detJv[k] : A.detJ;
+      // every lane sums the partials of its own test function (same order in all lanes, so all
+      // agree bit for bit): no second barrier and no serial section
+      float R = 0.f;
+      if (qtree) {
+        const int per = q / seg;                                      // partials per test function
+        for (int j = 0; j < per; ++j) R += sInt[tf_l * per + j];      // :661
+      } else {
+        for (int p = 0; p < q; ++p) R += sInt[tf_l * q + p];
+      }
+      const long k = tile * TT + tf_l;                                // = r0 / q + tf_l
+      float s = 0.f;
+      if (pt < TPTS && k < A.n_k) {
+        const float dj = A.detJv ? A.detJv[k] : A.detJ;
+        if (lc.g == 0 && pq_l == 0) {                                 // one lane per test function
           const float lv = dj * R * R;
           loss_var += lv;
           if (A.lossVec) A.lossVec[k] = lv;
-          s = 2.f * A.w2 * dj * R;
         }
-        sR[tid] = s;
+        s = 2.f * A.w2 * dj * R * wq;
       }
       ESTAMP(3);
-      __syncthreads();
       ESTAMP(4);
-      const float s = (pt < TPTS ? sR[pt / q] : 0.f) * wq;
       udbar = s;
       ubar = -dnt * s;
     } else {
