@@ -1,0 +1,35 @@
+"""Copy the judged summaries of gpurun_out/prof_<tag>/ into profiles/ (tracked):
+   python tools/summarise_profiles.py <tag> <round-prefix>      e.g.  r1b r1"""
+import csv, collections, glob, json, os, shutil, sys
+tag, pre = sys.argv[1], sys.argv[2]
+src = 'gpurun_out/prof_%s' % tag
+os.makedirs('profiles', exist_ok=True)
+shutil.copy(src + '/bench.json', 'profiles/%s_bench_default.json' % pre)
+st = glob.glob(src + '/stats/**/s_kernel_stats.csv', recursive=True)[0]
+shutil.copy(st, 'profiles/%s_fused16_kernel_stats.csv' % pre)
+tot = {}
+for f in glob.glob(src + '/pmc_*/**/p_counter_collection.csv', recursive=True):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'vn_fused16_kernel' in r['Kernel_Name']:
+            d[r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, v in d.items():
+        v = sorted(v); tot[k] = v[len(v) // 2]
+    name = os.path.basename(os.path.dirname(os.path.dirname(f))) if 'pmc_' not in os.path.basename(os.path.dirname(f)) else os.path.basename(os.path.dirname(f))
+    shutil.copy(f, 'profiles/%s_%s_fused16.csv' % (pre, [p for p in f.split('/') if p.startswith('pmc_')][0].lower()))
+cyc = tot['GRBM_GUI_ACTIVE'] / 8.0
+out = {
+    'kernel': 'vn_fused16_kernel<5,13>', 'workload': 'bench.py config 3 (6.4M points/step)',
+    'FETCH_SIZE_KB_per_launch': tot['FETCH_SIZE'], 'WRITE_SIZE_KB_per_launch': tot['WRITE_SIZE'],
+    'correction': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE taken as is',
+    'hbm_bytes_per_launch': (2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0,
+    'algorithmic_input_bytes_per_launch': 128224000,
+    'mfma': {'SQ_VALU_MFMA_BUSY_CYCLES': tot['SQ_VALU_MFMA_BUSY_CYCLES'], 'GRBM_GUI_ACTIVE_sum_over_8_XCD': tot['GRBM_GUI_ACTIVE'],
+             'shader_cycles_per_launch': cyc, 'mfma_pipe_utilisation': tot['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / cyc,
+             'SQ_LDS_IDX_ACTIVE': tot['SQ_LDS_IDX_ACTIVE'], 'SQ_LDS_BANK_CONFLICT': tot['SQ_LDS_BANK_CONFLICT'],
+             'lds_utilisation': tot['SQ_LDS_IDX_ACTIVE'] / 256.0 / cyc},
+    'waves': {k: tot[k] for k in ('SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU') if k in tot},
+    'command': 'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dedup',
+}
+json.dump(out, open('profiles/%s_pmc_traffic.json' % pre, 'w'), indent=1)
+print(json.dumps(out, indent=1))

@@ -52,7 +52,14 @@ struct Lay {
   static constexpr int GO_OFF = G1_SZ + (L - 1) * GH_SZ;
   static constexpr int G_SZ = al4(GO_OFF + HP + 1);
   static constexpr int T_SZ = (2 * TROWS * TSW > G_SZ) ? 2 * TROWS * TSW : G_SZ;
-  static constexpr int TOTAL = T_OFF + T_SZ;
+  // Weight-gradient accumulators of the first NST hidden layers live in LDS between their uses
+  // (2 x f32x4 per lane and layer): registers are short while the forward pass stores activations,
+  // and what the compiler spills instead goes to scratch, i.e. through L2 to HBM.
+  static constexpr int ST_OFF = T_OFF + T_SZ;
+  static constexpr int ST_LAYER = NW * 2 * 64 * 4;
+  static constexpr int ST_FIT = (160 * 256 - ST_OFF) / ST_LAYER;
+  static constexpr int NST = (KS != 13 || L < 2) ? 0 : (ST_FIT < L - 1 ? ST_FIT : L - 1);
+  static constexpr int TOTAL = ST_OFF + NST * ST_LAYER;
 };
 
 __device__ __forceinline__ float opaque(float x) {
@@ -593,13 +600,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   using WOG = WG<KS, 1>;
   constexpr bool HID13 = (KS == 13);                 // 50-wide hidden layers: 3x3 core tiles + 4x4x1 borders
   constexpr int NHACC = HID13 ? 2 : WHG::TPW;
+  f32x4a* stash = reinterpret_cast<f32x4a*>(lds + LY::ST_OFF) + wave * 2 * 64 + lane;   // [layer][wave][slot][lane]
+  constexpr int ST_L = LY::ST_LAYER / 4;
   f32x4 wacc1[W1G::TPW], wacch[L > 1 ? L - 1 : 1][NHACC], wacco[WOG::TPW];
 #pragma unroll
   for (int t = 0; t < W1G::TPW; ++t) wacc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int l = 0; l < (L > 1 ? L - 1 : 1); ++l)
 #pragma unroll
-    for (int t = 0; t < NHACC; ++t) wacch[l][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NHACC; ++t) {
+      wacch[l][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (l < LY::NST) stash[l * ST_L + t * 64] = wacch[l][t];
+    }
 #pragma unroll
   for (int t = 0; t < WOG::TPW; ++t) wacco[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -868,7 +880,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
           zd[0][ks] = rt[ks >> 2][ks & 3];
         }
       }
-      if constexpr (HID13) h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, lane, wacch[l - 2] STAMP_ARGS);
+      if constexpr (HID13) {
+        if (l - 2 < LY::NST) {
+          f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
+          h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, lane, acc2 STAMP_ARGS);
+          stash[(l - 2) * ST_L] = acc2[0];
+          stash[(l - 2) * ST_L + 64] = acc2[1];
+        } else {
+          h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, lane, wacch[l - 2] STAMP_ARGS);
+        }
+      }
       else wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
       STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
@@ -949,7 +970,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       else wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
 #pragma unroll
       for (int l = 2; l <= L; ++l)
-        if constexpr (HID13) h13_flush<LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, lane);
+        if constexpr (HID13) {
+          if (l - 2 < LY::NST) {
+            const f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
+            h13_flush<LY::HP>(acc2, Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, lane);
+          } else {
+            h13_flush<LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, lane);
+          }
+        }
         else wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
       thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
     }
