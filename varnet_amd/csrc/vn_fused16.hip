@@ -23,7 +23,16 @@ constexpr int TILE = 128;
 constexpr int CW = 16;        // points per wave
 constexpr int WS = 65;        // weight image row stride
 constexpr int TSW = 132;      // transposition image row stride
-constexpr int TROWS = 64;
+// Rows of a transposition image.  Positions are accumulator rows 16(ks>>2)+4g+(ks&3); a 50-wide layer
+// (KS == 13) uses positions 0..47, 48 (feature 48), 52 (feature 49), 49 (bias row) and one all-zero row,
+// so its images are packed into 52 rows (position 52 -> row 51, every unused position -> the zero row 50):
+// the 12 KB this frees hold another layer's accumulators (Lay::NST).
+__host__ __device__ constexpr int t_rows(int KS) { return KS == 13 ? 52 : 64; }
+template <int KS>
+__device__ __forceinline__ int trow(int pos) {
+  if (KS != 13) return pos;
+  return pos < 50 ? pos : pos == 52 ? 51 : 50;
+}
 constexpr int KS0 = 2;        // input layer k-steps (d_in <= 8)
 
 __host__ __device__ constexpr int al4(int x) { return (x + 3) & ~3; }
@@ -51,7 +60,7 @@ struct Lay {
   static constexpr int GH_SZ = (HP + 1) * HP;
   static constexpr int GO_OFF = G1_SZ + (L - 1) * GH_SZ;
   static constexpr int G_SZ = al4(GO_OFF + HP + 1);
-  static constexpr int T_SZ = (2 * TROWS * TSW > G_SZ) ? 2 * TROWS * TSW : G_SZ;
+  static constexpr int T_SZ = (2 * t_rows(KS) * TSW > G_SZ) ? 2 * t_rows(KS) * TSW : G_SZ;
   // Weight-gradient accumulators of the first NST hidden layers live in LDS between their uses
   // (2 x f32x4 per lane and layer): registers are short while the forward pass stores activations,
   // and what the compiler spills instead goes to scratch, i.e. through L2 to HBM.
@@ -138,6 +147,16 @@ struct WG {
 #define STAMP_ARGS
 #endif
 
+// store of one published value: lane (c, g) owns row vpos(ks,0)+4g, column wave*16+c
+template <int KS>
+__device__ __forceinline__ void t_write(float* T, const LaneC& lc, int ks, float v) {
+  if (KS == 13 && ks == 12) {                       // features 48, 49 -> rows 48, 51; 50, 51 are padding
+    if (lc.g < 2) T[lc.twr + (48 - lc.g) * TSW] = v;
+  } else {
+    T[lc.twr + vpos(ks, 0) * TSW] = v;
+  }
+}
+
 // Cooperative weight gradient (see vn_fused.hip): all waves publish their 16 point-columns of
 // the transposed operands, then each wave contracts its output tile(s) over its share of the
 // 128 points into persistent accumulators.
@@ -154,8 +173,10 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
   // banks: with the row stride == 4 (mod 64) the 16 rows of a group are conflict-free only if
   // the point offsets of g and g^1 differ by a multiple of 64 -> g = 0,1,2,3 start at 0,64,32,96.
   const int goff = (W::PG == 32) ? 64 * (lc.g & 1) + 32 * (lc.g >> 1) : lc.g * W::PG;
-  const int rdA = (16 * m + lc.c) * TSW + sidx * W::PTS + goff;
-  const int rdB = (16 * n0 + lc.c) * TSW + sidx * W::PTS + goff;
+  const int rdA = trow<KSA>(16 * m + lc.c) * TSW + sidx * W::PTS + goff;
+  int rdBt[W::TPW];
+#pragma unroll
+  for (int t = 0; t < W::TPW; ++t) rdBt[t] = trow<KSB>(16 * (n0 + t) + lc.c) * TSW + sidx * W::PTS + goff;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -167,18 +188,18 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
         const float x = opaque(av[ks]);
         v = x * (1.f - x) * azd[ks];
       }
-      TA[lc.twr + vpos(ks, 0) * TSW] = v;
+      t_write<KSA>(TA, lc, ks, v);
     }
     if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KSB; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
+    for (int ks = 0; ks < KSB; ++ks) t_write<KSB>(TB, lc, ks, (half == 0) ? bv[ks] : bt[ks]);
     WSTAMP(2);
     __syncthreads();
     WSTAMP(3);
     f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA]);
     f32x4 b4[W::TPW];
 #pragma unroll
-    for (int t = 0; t < W::TPW; ++t) b4[t] = *reinterpret_cast<const f32x4a*>(&TB[rdB + 16 * t * TSW]);
+    for (int t = 0; t < W::TPW; ++t) b4[t] = *reinterpret_cast<const f32x4a*>(&TB[rdBt[t]]);
 #pragma unroll
     for (int j = 0; j < W::PG / 4; ++j) {
       f32x4 an = a4, bn[W::TPW];
@@ -188,7 +209,7 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
         an = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * (j + 1)]);
 #pragma unroll
         for (int t = 0; t < W::TPW; ++t)
-          bn[t] = *reinterpret_cast<const f32x4a*>(&TB[rdB + 16 * t * TSW + 4 * (j + 1)]);
+          bn[t] = *reinterpret_cast<const f32x4a*>(&TB[rdBt[t] + 4 * (j + 1)]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -224,10 +245,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // A side: 64 positions (lane = row), B side: rows brow(j) for j = lane & 3;  TRANSPOSED swaps the roles
-template <bool A_IS_LANE>
+template <int KS, bool A_IS_LANE>
 __device__ __forceinline__ void thin_contract(const float* TA, const float* TB, int rowsel, int wave, int lane, f32x4& acc) {
-  const int rdA = (A_IS_LANE ? lane : rowsel) * TSW + wave * CW;
-  const int rdB = (A_IS_LANE ? rowsel : lane) * TSW + wave * CW;
+  const int rdA = (A_IS_LANE ? trow<KS>(lane) : rowsel) * TSW + wave * CW;
+  const int rdB = (A_IS_LANE ? rowsel : trow<KS>(lane)) * TSW + wave * CW;
   f32x4 a4[CW / 4], b4[CW / 4];
 #pragma unroll
   for (int q = 0; q < CW / 4; ++q) {
@@ -260,12 +281,12 @@ __device__ __forceinline__ void thin_wgrad_out(const float (&av)[KS], const floa
         const float x = opaque(av[ks]);
         v = x * (1.f - x) * azd[ks];
       }
-      TA[lc.twr + vpos(ks, 0) * TSW] = v;
+      t_write<KS>(TA, lc, ks, v);
     }
     if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
     TB[lc.twr] = (lc.g == 0) ? (half == 0 ? ubar : udbar) : 0.f;
     wave_lds_sync();
-    thin_contract<true>(TA, TB, (lane & 3) == 0 ? 0 : 4, wave, lane, acc);
+    thin_contract<KS, true>(TA, TB, (lane & 3) == 0 ? 0 : 4, wave, lane, acc);
     wave_lds_sync();
   }
 }
@@ -294,9 +315,9 @@ __device__ __forceinline__ void thin_wgrad_in(const float (&xv)[KS0], const floa
     TA[lc.twr] = (half == 0) ? xv[0] : gv[0];                                     // feature g at position 4g
     if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
+    for (int ks = 0; ks < KS; ++ks) t_write<KS>(TB, lc, ks, (half == 0) ? bv[ks] : bt[ks]);
     wave_lds_sync();
-    thin_contract<false>(TA, TB, rowsel, wave, lane, acc);
+    thin_contract<KS, false>(TA, TB, rowsel, wave, lane, acc);
     wave_lds_sync();
   }
 }
@@ -326,7 +347,7 @@ __device__ __forceinline__ void thin_flush_in(const f32x4& acc, float* Gl, int l
 // so the six tile waves run one instruction stream (48 MFMAs per round) and share the A fragment.
 // D layout of the 4x4x1 MFMA: lane 4b+j, register i  =  sum_p A[lane 4b+i] * B[lane 4b+j].
 struct H13 {
-  static constexpr int ROW48 = vpos(12, 0), ROW49 = vpos(12, 1);      // accumulator rows of features 48, 49
+  static constexpr int ROW48 = 48, ROW49 = 51;                        // image rows of features 48, 49 (packed, see trow)
   static constexpr int ONES = vones(13);                              // bias ("ones") row of TA
   static constexpr int ZERO = ONES + 1;                               // a row nobody writes
   __device__ static __forceinline__ int edge_row(int i) { return i == 0 ? ROW48 : i == 1 ? ROW49 : i == 2 ? ONES : ZERO; }
@@ -343,8 +364,8 @@ __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, c
   if (role == 1 || role == 2) {
     // border job: every lane walks all 128 points, 4 per ds_read_b128; two accumulators alternate
     const int sel = lane & 3;
-    const int rdA = (role == 1 ? H13::edge_row(sel) : lane) * TSW;
-    const int rdB = (role == 1 ? lane : H13::edge_col(sel)) * TSW;
+    const int rdA = (role == 1 ? H13::edge_row(sel) : trow<13>(lane)) * TSW;
+    const int rdB = (role == 1 ? trow<13>(lane) : H13::edge_col(sel)) * TSW;
     // 8 points per stage, two register buffers used alternately (no rotation copies, so a stage's
     // loads are waited for only one stage later): the 16 MFMAs of a stage cover the LDS latency
     constexpr int PS = 8, NSTG = TILE / PS;
@@ -434,11 +455,11 @@ __device__ __forceinline__ void h13_wgrad_layer(const float (&av)[13], const flo
         const float x = opaque(av[ks]);
         v = x * (1.f - x) * azd[ks];
       }
-      TA[lc.twr + vpos(ks, 0) * TSW] = v;
+      t_write<13>(TA, lc, ks, v);
     }
     if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 13; ++ks) TB[lc.twr + vpos(ks, 0) * TSW] = (half == 0) ? bv[ks] : bt[ks];
+    for (int ks = 0; ks < 13; ++ks) t_write<13>(TB, lc, ks, (half == 0) ? bv[ks] : bt[ks]);
     WSTAMP(2);
     __syncthreads();
     WSTAMP(3);
@@ -550,7 +571,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   float* WO = lds + LY::WO_OFF;
   float* sInt = lds + LY::MISC_OFF;
   float* TA = lds + LY::T_OFF;
-  float* TB = TA + TROWS * TSW;
+  float* TB = TA + t_rows(KS) * TSW;
   float* Gacc = lds + LY::T_OFF;
 
   // ------------------------------------------------------------------ prologue: LDS images
