@@ -21,9 +21,16 @@ def run(d_in, dim, widths, q, n_k, nB, bDof, source=False, integW=False, detJvec
         gw, rw = g[off:off+i*o], gref[off:off+i*o]; off += i*o
         gbb, rb = g[off:off+o], gref[off:off+o]; off += o
         print('  layer %dx%d  W err %.2e (max ref %.2e)  b err %.2e (max ref %.2e)' % (i, o, abs(gw-rw).max(), abs(rw).max(), abs(gbb-rb).max(), abs(rb).max()))
+        if len(sys.argv) > 1 and abs(gw-rw).max() > 1e-3*abs(rw).max():
+            E = abs(gw-rw).reshape(i, o) > 1e-3*abs(rw).max()
+            print('    bad rows (in-features):', np.nonzero(E.any(axis=1))[0].tolist())
+            print('    bad cols (out-features):', np.nonzero(E.any(axis=0))[0].tolist())
     eng.close()
-run(3, 1, [10, 20, 30], 16, 21, 19, 7)
-run(3, 1, [30, 30, 30], 16, 21, 19, 7)
-run(3, 1, [20, 20, 20], 16, 21, 19, 7)
-run(3, 2, [30, 30, 30], 16, 21, 19, 7)
-run(2, 1, [30, 30], 16, 21, 19, 7)
+if len(sys.argv) > 1:
+    run(3, 2, [50, 50, 50, 50, 50], 64, 9, 77, 40)
+else:
+    run(3, 1, [10, 20, 30], 16, 21, 19, 7)
+    run(3, 1, [30, 30, 30], 16, 21, 19, 7)
+    run(3, 1, [20, 20, 20], 16, 21, 19, 7)
+    run(3, 2, [30, 30, 30], 16, 21, 19, 7)
+    run(2, 1, [30, 30], 16, 21, 19, 7)

@@ -60,7 +60,10 @@ struct Lay {
   static constexpr int GH_SZ = (HP + 1) * HP;
   static constexpr int GO_OFF = G1_SZ + (L - 1) * GH_SZ;
   static constexpr int G_SZ = al4(GO_OFF + HP + 1);
-  static constexpr int T_SZ = (2 * t_rows(KS) * TSW > G_SZ) ? 2 * t_rows(KS) * TSW : G_SZ;
+  static constexpr int T_IMG = 2 * t_rows(KS) * TSW;
+  static constexpr int T_H13 = (KS == 13) ? 27 * (NW * 64 + 4) : 0;         // lane-major images of the 50-wide path (H13)
+  static constexpr int T_MAX = T_IMG > T_H13 ? T_IMG : T_H13;
+  static constexpr int T_SZ = al4(T_MAX > G_SZ ? T_MAX : G_SZ);
   // Weight-gradient accumulators of the first NST hidden layers live in LDS between their uses
   // (2 x f32x4 per lane and layer): registers are short while the forward pass stores activations,
   // and what the compiler spills instead goes to scratch, i.e. through L2 to HBM.
@@ -346,17 +349,44 @@ __device__ __forceinline__ void thin_flush_in(const f32x4& acc, float* Gl, int l
 //   w = 3: row border          w = 7: column border
 // so the six tile waves run one instruction stream (48 MFMAs per round) and share the A fragment.
 // D layout of the 4x4x1 MFMA: lane 4b+j, register i  =  sum_p A[lane 4b+i] * B[lane 4b+j].
+// Image layout of this path ("lane-major"): element (position pos, point (w, c)) of an image sits at
+//   vks(pos)*RS + w*64 + g(pos)*16 + c          (g(pos) = (pos>>2)&3, RS = 8*64 + 4 floats)
+// i.e. one image row per k-step holds, per wave, the 64 lanes of that wave's register in lane order.  A
+// publishing store is then `ds_write_addtid_b32` (address = M0 + offset + 4*lane, no address VGPR,
+// 128 B/clk/CU instead of the 64 B/clk of ds_write_b32 -- the publish rounds are bound by the LDS store
+// path), and a reader still finds 4 consecutive points of one feature in one ds_read_b128.
+// TA: rows 0..12 = k-steps, row 13 = [bias ones | zeros | zeros | zeros]; TB: rows 0..12.
 struct H13 {
-  static constexpr int ROW48 = 48, ROW49 = 51;                        // image rows of features 48, 49 (packed, see trow)
-  static constexpr int ONES = vones(13);                              // bias ("ones") row of TA
-  static constexpr int ZERO = ONES + 1;                               // a row nobody writes
-  __device__ static __forceinline__ int edge_row(int i) { return i == 0 ? ROW48 : i == 1 ? ROW49 : i == 2 ? ONES : ZERO; }
-  __device__ static __forceinline__ int edge_col(int j) { return j == 0 ? ROW48 : j == 1 ? ROW49 : ZERO; }
+  static constexpr int RS = NW * 64 + 4;
+  static constexpr int TA_ROWS = 14, TB_ROWS = 13;
+  static constexpr int P48 = vpos(12, 0), P49 = vpos(12, 1);          // positions of features 48, 49
+  static constexpr int ONES = vones(13);                              // position (13, g=0): the bias row
+  static constexpr int ZERO = ONES + 4;                               // position (13, g=1): always zero (TA only)
+  __host__ __device__ static constexpr int off(int pos) { return vks(pos) * RS + ((pos >> 2) & 3) * 16; }
+  __device__ static __forceinline__ int edge_row(int i) { return i == 0 ? P48 : i == 1 ? P49 : i == 2 ? ONES : ZERO; }
   // role 0: core tiles; 1: row border; 2: column border
   __device__ static __forceinline__ int role(int wave) { return wave == 3 ? 1 : wave == 7 ? 2 : 0; }
   __device__ static __forceinline__ int tile_m(int wave) { return wave & 3; }
   __device__ static __forceinline__ int tile_n(int wave) { return wave >= 4 ? 1 : 0; }
 };
+static_assert(H13::ZERO == 53 && vks(H13::ZERO) == 13, "zero position");
+static_assert(Lay<5, 13>::T_H13 == (H13::TA_ROWS + H13::TB_ROWS) * H13::RS, "image size");
+
+// ds_write_addtid_b32: LDS[M0 + OFF + 4*lane] = v.  M0 is written once per publishing round (the wait
+// state is the documented SALU-writes-M0 -> add-TID hazard); nothing else in this kernel uses M0.
+__device__ __forceinline__ void addtid_base(unsigned m0_bytes) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(m0_bytes) : "memory");
+}
+template <int OFF_BYTES>
+__device__ __forceinline__ void addtid_store(float v) {
+  static_assert(OFF_BYTES >= 0 && OFF_BYTES < 65536, "16-bit offset");
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(v), "n"(OFF_BYTES) : "memory");
+#endif
+}
+__device__ __forceinline__ void addtid_drain() {     // the compiler does not count these stores in lgkmcnt
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, const LaneC& lc, int wave, int lane,
                                              f32x4 (&acc)[2]) {
@@ -364,17 +394,24 @@ __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, c
   if (role == 1 || role == 2) {
     // border job: every lane walks all 128 points, 4 per ds_read_b128; two accumulators alternate
     const int sel = lane & 3;
-    const int rdA = (role == 1 ? H13::edge_row(sel) : trow<13>(lane)) * TSW;
-    const int rdB = (role == 1 ? trow<13>(lane) : H13::edge_col(sel)) * TSW;
-    // 8 points per stage, two register buffers used alternately (no rotation copies, so a stage's
-    // loads are waited for only one stage later): the 16 MFMAs of a stage cover the LDS latency
-    constexpr int PS = 8, NSTG = TILE / PS;
+    // offsets relative to TA (TB = TA + TBO): one LDS base pointer, integer selects only
+    constexpr int TBO = H13::TA_ROWS * H13::RS;
+    const int lane_off = vks(lane) * H13::RS + ((lane >> 2) & 3) * 16;        // lane = position
+    const int oA = (role == 1) ? H13::off(H13::edge_row(sel)) : lane_off;
+    const int oB = (role == 1) ? TBO + lane_off
+                               : (sel == 0 ? TBO + H13::off(H13::P48) : sel == 1 ? TBO + H13::off(H13::P49) : H13::off(H13::ZERO));
+    const float* pA = TA + oA;
+    const float* pB = TA + oB;
+    // 8 points per stage (wave w's columns 0..7 or 8..15), two register buffers used alternately (no
+    // rotation copies: a stage's loads are waited for one stage later, behind 16 MFMAs)
+    constexpr int NSTG = TILE / 8;
     f32x4 a0[2], b0[2], a1[2], b1[2];
     auto load = [&](f32x4 (&a4)[2], f32x4 (&b4)[2], int stage) {
+      const int o = (stage >> 1) * 64 + (stage & 1) * 8;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        a4[h] = *reinterpret_cast<const f32x4a*>(&TA[rdA + PS * stage + 4 * h]);
-        b4[h] = *reinterpret_cast<const f32x4a*>(&TB[rdB + PS * stage + 4 * h]);
+        a4[h] = *reinterpret_cast<const f32x4a*>(&pA[o + 4 * h]);
+        b4[h] = *reinterpret_cast<const f32x4a*>(&pB[o + 4 * h]);
       }
     };
     auto compute = [&](const f32x4 (&a4)[2], const f32x4 (&b4)[2]) {
@@ -394,13 +431,15 @@ __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, c
     }
     return;
   }
+  // core tiles: lane (c, g) reads feature position 16m+c; lane group g contracts the points of waves
+  // 2g and 2g+1 (so g and g^1 are 128 floats apart: conflict-free ds_read_b128, rows 4 banks apart)
   const int m = H13::tile_m(wave), n0 = H13::tile_n(wave);
-  const int goff = 64 * (lc.g & 1) + 32 * (lc.g >> 1);         // see wgrad_layer
-  const int rdA = (16 * m + lc.c) * TSW + goff;
-  const int rdB = (16 * n0 + lc.c) * TSW + goff;
-  const int rdC = (16 * 2 + lc.c) * TSW + goff;
-  // a lane group's 32 points are taken in two halves of 16: the shared tile (m,2) only in the first
-  const int base1 = (wave >= NW / 2) ? 16 : 0, base2 = 16 - base1;
+  const int fo = (lc.c & 3) * H13::RS + (lc.c >> 2) * 16 + lc.g * 128;     // + 4m*RS for tile row m
+  const int rdA = 4 * m * H13::RS + fo;
+  const int rdB = 4 * n0 * H13::RS + fo;
+  const int rdC = 4 * 2 * H13::RS + fo;
+  // the shared tile (m,2) is contracted over one of the lane group's two waves only
+  const int base1 = (wave >= NW / 2) ? 64 : 0, base2 = 64 - base1;
   f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA + base1]);
   f32x4 b4 = *reinterpret_cast<const f32x4a*>(&TB[rdB + base1]);
   f32x4 c4 = *reinterpret_cast<const f32x4a*>(&TB[rdC + base1]);
@@ -439,27 +478,32 @@ __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, c
   }
 }
 
-// both rounds of a 50-wide hidden layer
+template <int KS_, int I>
+struct H13Pub {      // unrolled stores with compile-time offsets (inline-asm immediates)
+  static __device__ __forceinline__ void run(int half, const float (&av)[13], const float (&azd)[13], const float (&bv)[13],
+                                             const float (&bt)[13]) {
+    float v = av[I];
+    if (half == 1) {
+      const float x = opaque(av[I]);
+      v = x * (1.f - x) * azd[I];
+    }
+    addtid_store<I * H13::RS * 4>(v);
+    addtid_store<(H13::TA_ROWS + I) * H13::RS * 4>(half == 0 ? bv[I] : bt[I]);
+    if constexpr (I + 1 < KS_) H13Pub<KS_, I + 1>::run(half, av, azd, bv, bt);
+  }
+};
+
+// both rounds of a 50-wide hidden layer; t_base_bytes = byte address of this wave's 64 columns of TA
 __device__ __forceinline__ void h13_wgrad_layer(const float (&av)[13], const float (&azd)[13], const float (&bv)[13],
-                                                const float (&bt)[13], float* TA, float* TB, const LaneC& lc, int wave,
-                                                int lane, f32x4 (&acc)[2] STAMP_PARAMS) {
-  using W = WG<13, 13>;
-  static_assert(W::ONES == H13::ONES, "bias row");
+                                                const float (&bt)[13], float* TA, const LaneC& lc, int wave, int lane,
+                                                unsigned t_base_bytes, f32x4 (&acc)[2] STAMP_PARAMS) {
+  const float* TB = TA + H13::TA_ROWS * H13::RS;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int ks = 0; ks < 13; ++ks) {
-      float v;
-      if (half == 0) v = av[ks];
-      else {
-        const float x = opaque(av[ks]);
-        v = x * (1.f - x) * azd[ks];
-      }
-      t_write<13>(TA, lc, ks, v);
-    }
-    if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 13; ++ks) t_write<13>(TB, lc, ks, (half == 0) ? bv[ks] : bt[ks]);
+    addtid_base(t_base_bytes);
+    H13Pub<13, 0>::run(half, av, azd, bv, bt);
+    addtid_store<13 * H13::RS * 4>((half == 0 && lc.g == 0) ? 1.f : 0.f);      // bias row | zeros
+    addtid_drain();
     WSTAMP(2);
     __syncthreads();
     WSTAMP(3);
@@ -572,6 +616,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
   float* sInt = lds + LY::MISC_OFF;
   float* TA = lds + LY::T_OFF;
   float* TB = TA + t_rows(KS) * TSW;
+  const unsigned t_base_bytes = (unsigned)((LY::T_OFF + wave * 64) * 4);      // lane-major images: this wave's columns
   float* Gacc = lds + LY::T_OFF;
 
   // ------------------------------------------------------------------ prologue: LDS images
@@ -886,6 +931,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
     }
     STAMP(3);
     thin_wgrad_out<KS>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0]);
+    if constexpr (HID13) __syncthreads();    // the lane-major images of the hidden layers overlap other waves' columns
     STAMP(4);
 #pragma unroll
     for (int l = L; l >= 2; --l) {
@@ -904,11 +950,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A)
       if constexpr (HID13) {
         if (l - 2 < LY::NST) {
           f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
-          h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, lane, acc2 STAMP_ARGS);
+          h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, acc2 STAMP_ARGS);
           stash[(l - 2) * ST_L] = acc2[0];
           stash[(l - 2) * ST_L + 64] = acc2[1];
         } else {
-          h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, lane, wacch[l - 2] STAMP_ARGS);
+          h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, wacch[l - 2] STAMP_ARGS);
         }
       }
       else wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
