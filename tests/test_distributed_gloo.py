@@ -38,7 +38,7 @@ def _run(rank, world, port, outdir, batchNum):
                    verbose=False, batchNum=batchNum)
     if rank == 0:
         np.savez(os.path.join(outdir, 'out_w%d_b%s.npz' % (world, batchNum)),
-                 theta=vn.engine.theta, loss=np.array(res.loss), w=res.trainWeight)
+                 theta=vn.engine.theta, loss=np.array(res.lossAll), w=res.trainWeight)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,8 +32,8 @@ def test_train_1dt_end_to_end(tmp_path):
     vn = op1dt([20, 20, 20], 20, 60, cEx=cExact)
     _, _, err0, _ = vn.residual()
     res = vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=600, saveFreq=200, verbose=False)
-    assert abs(res.loss[0] - 1e6) / 1e6 < 1e-3                      # trainWeight normalisation
-    assert res.loss[-1] < 0.7 * res.loss[0]
+    assert abs(res.lossAll[0] - 1e6) / 1e6 < 1e-3                      # trainWeight normalisation
+    assert res.lossAll[-1] < 0.7 * res.lossAll[0]
     r1, resVec, err1, cApp = vn.residual()
     assert np.isfinite(err1) and np.isfinite(err0)
     flat = vn.engine.get_params().astype(np.float64)
@@ -65,7 +65,7 @@ def test_mor_and_minibatch_on_device(tmp_path):
     res = vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=30, saveFreq=100, verbose=False,
                    batchNum=4, shuffleData=True)
     assert vn.engine.step == 30 * 3 * 4
-    assert np.isfinite(res.loss).all() and res.loss[-1] < res.loss[0]
+    assert np.isfinite(res.lossAll).all() and res.lossAll[-1] < res.lossAll[0]
     r, rv, err, ca = vn.residual(fp64=True)
     assert np.isfinite(r)
     vn.engine.close()
@@ -166,12 +166,12 @@ def test_optimal_sampling_on_device(tmp_path, suppFactor):
     vn = op1dt([20, 20], 10, 16, cEx=cExact)
     fd = vn.fixData
     nt0 = fd.nt0
-    res = vn.train(str(tmp_path), weight=[10., 10., 1.], smpScheme='optimal', epochNum=40, saveFreq=20,
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], smpScheme='optimal', epochNum=40, saveFreq=10,
                    verbose=False, trainUpdelay=10, tolUpd=10.0, frac=0.5, suppFactor=suppFactor)
     assert res.inpIter == [10]
     assert fd.nt == nt0 + int(np.ceil(0.5 * nt0)) and fd.detJvec == (suppFactor != 1.0)
-    assert vn.engine.step == 30 and np.isfinite(res.loss).all()
-    assert res.loss[-1] < res.loss[10]
+    assert vn.engine.step == 30 and np.isfinite(res.lossAll).all()
+    assert res.lossAll[-1] < res.lossAll[10]
     # the device loss on the re-drawn set agrees with the oracle on the same arrays
     d = vn.tData.mor[0]
     vn.tData.activate()
@@ -200,7 +200,7 @@ def test_three_point_gauss_on_device(tmp_path):
     fd = vn.fixData
     assert fd.integNum == 36 and vn.lossOpt == {'integWflag': True, 'isSource': True}
     res = vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=50, saveFreq=25, verbose=False)
-    assert res.loss[-1] < res.loss[0]
+    assert res.lossAll[-1] < res.lossAll[0]
     d = vn.tData.mor[0]
     vn.tData.select_mor(0)
     vn.engine.set_weights([1.0, 1.0, 1.0])
@@ -237,6 +237,6 @@ def test_dedup_training_matches_rowwise(tmp_path):
             assert vn.tData.dedup_on
             U = vn.tData._dd_cache[(0, 0)][0].shape[0]
             assert vn.fixData.nT / U > 5.0
-        losses.append(np.array(res.loss))
+        losses.append(np.array(res.lossAll))
         vn.engine.close()
     assert np.max(np.abs(losses[0] - losses[1]) / losses[0]) < 2e-3

@@ -176,6 +176,34 @@ class UF:
                     again = True
         return np.vstack([kept[i][:dof[i], :] for i in range(m)])
 
+    def mat2diffpack(self, filename, fieldname, mat):
+        """Write a vector or matrix as the MATLAB-style m-file Diffpack reads (UtilityFunc.py:829-886):
+        `datatype`, the sizes, a `zeros(...)` allocation and one assignment per entry, column by column."""
+        if not isinstance(filename, str):
+            raise TypeError('\'filename\' must be a string!')
+        if '.m' not in filename:
+            raise ValueError('\'filename\' must end with \'.m\'!')
+        if not isinstance(fieldname, str):
+            raise TypeError('\'fieldname\' must be a string!')
+        if not isinstance(mat, (list, np.ndarray)):
+            raise TypeError('\'mat\' must be an array!')
+        mat = np.asarray(mat)
+        sh = mat.shape
+        if len(sh) > 2:
+            raise ValueError('\'mat\' must be at most 2d!')
+        out = ['datatype = \'real\';\n\n']
+        if len(sh) == 1 or sh[1] == 1:
+            vec = mat.reshape(-1)
+            out.append('length = %d;\n\n%s = zeros(length,1);\n\n%%%% Data:\n\n' % (sh[0], fieldname))
+            out.extend('%s(%d) = \t%s;\n' % (fieldname, i + 1, str(vec[i])) for i in range(sh[0]))
+        else:
+            out.append('nrows = %d; ncolumns = %d;\nnentries = %d;\n\n' % (sh[0], sh[1], sh[0] * sh[1]))
+            out.append('%s = zeros(nrows, ncolumns);\n\n%%%% Data:\n\n' % fieldname)
+            for j in range(sh[1]):
+                out.extend('%s(%d,%d) = \t%s;\n' % (fieldname, i + 1, j + 1, str(mat[i, j])) for i in range(sh[0]))
+        with open(filename, 'w') as f:
+            f.write(''.join(out))
+
     def nodeNum(self, x, val):
         """Index of the entry of x closest to each value in val."""
         x = np.reshape(np.asarray(x, dtype=float), -1)

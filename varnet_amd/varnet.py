@@ -19,6 +19,7 @@ Out of scope here: modelId='RNN', updateWeights, plots.
 import math
 import os
 import pickle
+from datetime import datetime
 import time
 import warnings
 
@@ -189,72 +190,230 @@ class FIXData:
 
 # ======================================================================================
 class TrainResult:
-    """Text log + loss / residual / error histories (lean restatement of
-    /root/reference/VarNetUtility.py:1149-1631; plots are out of scope)."""
+    """
+    Training record on disk with the reference's file formats (/root/reference/VarNetUtility.py:1149-1631),
+    so existing post-processing keeps working:
 
-    def __init__(self, folderpath, cExFlg=False, verbose=True, saveFreq=100):
+      * `<folder>/caseData.txt` -- banner, date, problem header, the sections "Boundary condition
+        information", "Neural Network architecture", "Processor information", "Optimizer information",
+        "Space-time discretization information", "Sampling scheme ...", "Batch-optimization
+        information", "Weighting information", "Stopping criteria", then "Training iterations:" followed
+        by one "Epoch %2d: loss = %2.5f" line per reported epoch (:1217-1464, :1574-1588);
+      * `<folder>/trainData.vn` -- pickle (HIGHEST_PROTOCOL) of the instance `__dict__` with the keys
+        `casepath, plotpath, caseSimline, saveFreq, verbose, pltReplace, trainWeight, loss, lossComp,
+        avgtime0, avgtime, residual, iterSmp, inpIter, error, lossVec, option_stopping,
+        option_trainPoint, option_weighting, option_batchOptim` (:1512-1556);
+      * histories are sampled every `saveFreq` epochs (`iterSmp`), epochs before the first `saveFreq` are
+        only logged (:1577-1583).
+    Plots (`iterPlot`) are out of scope; the `plots` folder is still created.
+    """
+
+    def __init__(self, folderpath, cExFlg=False, verbose=True, saveFreq=100, pltReplace=True):
         self.folderpath = folderpath
-        self.cExFlg, self.verbose, self.saveFreq = cExFlg, verbose, saveFreq
-        self.loss, self.minLoss, self.lossComp = [], [], []
-        self.residual, self.error, self.inpIter = [], [], []
-        self.epochTime = 0.0
+        self.verbose = verbose
+        self.saveFreq = saveFreq
+        self.pltReplace = pltReplace
         self.trainWeight = None
+        self.casepath = None
+        self.plotpath = None
+        self.caseSimline = 0
         if folderpath is not None:
-            os.makedirs(folderpath, exist_ok=True)
+            self.plotpath = os.path.join(folderpath, 'plots')
+            os.makedirs(self.plotpath, exist_ok=True)
+            self.casepath = os.path.join(folderpath, 'caseData.txt')
+        self.loss = []                    # total loss at the sampled epochs
+        self.lossAll = []                 # (extension) total loss of every epoch
+        self.lossComp = []                # [BC, IC, variational] at the sampled epochs
+        self.avgtime0 = None              # reference iteration time from the first saveFreq epochs
+        self.avgtime = 0
+        self.residual = []
+        self.iterSmp = []
+        self.inpIter = []
+        self.error = [] if not uf.isnone(cExFlg) else None      # (always a list: callers pass a bool)
+        self.lossVec = None
+        self.option_stopping = self.option_trainPoint = self.option_weighting = self.option_batchOptim = None
 
-    def writeCase(self, string, mode='a'):
+    # -- case file ------------------------------------------------------------------------------------
+    def initializeCase(self, varNet, trainArg):
+        g = trainArg.get
+        self.option_stopping = {'epochNum': g('epochNum'), 'tol': g('tol')}
+        self.option_trainPoint = {k: g(k) for k in ('smpScheme', 'frac', 'addTrainPts', 'suppFactor', 'multiTrainUpd',
+                                                    'trainUpdelay', 'tolUpd', 'reinitrain')}
+        self.option_weighting = {k: g(k) for k in ('weight', 'updateWeights', 'normalizeW', 'adjustWeight', 'useOriginalW')}
+        self.option_batchOptim = {k: g(k) for k in ('saveMORdata', 'batchNum', 'batchLen', 'shuffleData', 'shuffleFreq')}
         if self.folderpath is None:
             return
-        with open(os.path.join(self.folderpath, 'caseData.txt'), mode) as f:
-            f.write(string)
+        PDE, fd = varNet.PDE, varNet.fixData
+        td, dim = PDE.timeDependent, varNet.dim
+        MORoff = uf.isnone(PDE.MORvar)
+        smp = g('smpScheme')
+        bar = '-' * 79 + '\n'
+        L = [bar, '=' * 31 + ' VarNet Library ' + '=' * 32 + '\n', bar,
+             'MI355X-native engine (varnet_amd); file layout of the VarNet library, arXiv:1912.07443\n\n', bar]
+        d, t = datetime.now().strftime('%d/%m/%Y %H:%M:%S').split()
+        L.append('Simulation date: ' + d + ' - time: ' + t + '\n\n')
+        L.append('%dD %s Advection-Diffusion problem %s model-order-reduction.\n\n'
+                 % (dim, 'time-dependent' if td else 'steady-state', 'without' if MORoff else 'with'))
+        L.append('Boundary condition information:\n')
+        if dim == 1:
+            L.append('\ttype:' + PDE.BCtype[0] + ', ' + PDE.BCtype[1] + '\n')
+        else:
+            geom = PDE.domain.boundryGeom.tolist()
+            for bi in range(PDE.domain.bIndNum):
+                L.append('\tBC%d: %s - vertices: %s\n' % (bi + 1, PDE.BCtype[bi], geom[bi]))
+        L.append('\n')
+        L.append('Neural Network architecture:\n')
+        L.append('\ttype: ' + str(varNet.modelId) + '\n')
+        L.append('\tnumber of inputs: ' + str(varNet.inpDim) + '\n')
+        L.append('\tnumber of layers: ' + str(len(varNet.layerWidth)) + '\n')
+        L.append('\tnumber of nodes in each layer: ' + str(varNet.layerWidth) + '\n')
+        L.append('\tactivation function for each layer: ' + str(varNet.activationFun) + '\n')
+        L.append('\ttotal number of trainable parameters: ' + str(varNet.engine.P) + '\n\n')
+        L.append('Processor information:\n')
+        if varNet.world > 1:
+            L.append('\tparallel replicated training on %d processors\n' % varNet.world)
+            L.append('\tutilized processors: ' + ' and '.join('GPU:%d' % r for r in range(varNet.world)) + '\n')
+            L.append('master controller:GPU:0\n\n')
+        else:
+            L.append('\tutilized processor: GPU:0\n\n')
+        L.append('Optimizer information:\n')
+        L.append('\ttype: Adam stochastic gradient descent algorithm\n')
+        L.append('\tlearning rate: ' + str(varNet.learning_rate) + '\n\n')
+        L.append('Space-time discretization information:\n')
+        L.append('\tspatial domain interior discretization number: ' + str(varNet.discNum) + '\n')
+        L.append('\tspatial domain boundary discretization density: ' + str(varNet.bDiscNum) + '\n')
+        if td:
+            L.append('\ttemporal discretization number: ' + str(varNet.tDiscNum) + '\n')
+        L.append('\tnumber of training points: ' + str(fd.nt) + '\n')
+        L.append('\tnumber of training points for BCs: ' + str(list(fd.biDof)[:-1]) + '\n')
+        L.append('\ttotal number of BC training points: ' + str(fd.bDofsum) + '\n')
+        if td:
+            L.append('\tnumber of training points for IC: ' + str(list(fd.biDof)[-1]) + '\n')
+        L.append('\n')
+        L.append('Sampling scheme for training points: ' + str(smp) + '\n')
+        if smp != 'uniform':
+            L.append('\tfraction of non-uniform points: ' + str(g('frac')) + '\n')
+            if g('addTrainPts'):
+                L.append('\tnon-uniform points are added without replacement\n')
+            if g('multiTrainUpd'):
+                L.append('\tnon-uniform points updated every ' + str(g('trainUpdelay')) + ' epochs ...\n')
+                L.append('\t... if decrease in 5 consecutive loss values is less than ' + str(g('tolUpd')) + '\n')
+            else:
+                L.append('\tnon-uniform points updated once after ' + str(g('trainUpdelay')) + ' epochs\n')
+                L.append('\tif decrease in 5 consecutive loss values is less than ' + str(g('tolUpd')) + '\n')
+            if smp == 'optimal' and np.abs(g('suppFactor') - 1.0) > 1.e-15:
+                L.append('\tsupport of optimal training points is scaled by a factor of ' + str(g('suppFactor')) + '\n')
+            if g('reinitrain'):
+                L.append('\ttrainable variables are re-initialized after update of training points\n')
+            L.append('Note: since for non-uniform grid the training points and possibly weights are updated\n'
+                     '      the loss component plots will not necessarily match total loss plot!\n')
+        L.append('\n')
+        bN, bL = g('batchNum'), g('batchLen')
+        if not (MORoff and uf.isnone(bN) and uf.isnone(bL)):
+            L.append('Batch-optimization information:\n')
+            if not MORoff:
+                L.append('\tnumber of MOR batches: ' + str(fd.MORbatchNum) + '\n')
+                if g('saveMORdata'):
+                    L.append('\tMOR fields are stored for faster training.\n')
+            if not uf.isnone(bN):
+                L.append('\tnumber of training batches: ' + str(bN) + '\n')
+            elif not uf.isnone(bL):
+                L.append('\tlength of training batches: ' + str(bL) + '\n')
+            if g('shuffleData'):
+                L.append('\tshuffle training data every ' + str(g('shuffleFreq')) + ' epochs\n')
+            if not (uf.isnone(bN) and uf.isnone(bL)):
+                L.append('Note: for batch-optimization loss component values will not match total loss\n'
+                         '      since intermediate iterations change total loss unlike loss components!\n')
+            L.append('\n')
+        L.append('Weighting information:\n')
+        L.append('\trequested weights: ' + str(g('weight')) + '\n')
+        if g('updateWeights'):
+            L.append('\tweights updated to maintain the requested balance between terms\n')
+        if g('normalizeW'):
+            L.append('\tweights normalized by values so that weight times values have requested weights\n')
+        if smp != 'uniform' and g('adjustWeight'):
+            L.append('\tweights on boundary-initial conditions updated after addition of non-uniform points\n')
+        if g('useOriginalW'):
+            L.append('\trequested weights applied without any modification\n')
+        L.append('\n')
+        L.append('Stopping criteria:\n')
+        L.append('\tmaximum number of epochs: ' + str(g('epochNum')) + '\n')
+        L.append('\tstopping tolerance: ' + str(g('tol')) + '\n\n')
+        L.append('=' * 58 + '\n')
+        L.append('Training iterations:\n\n')
+        with open(self.casepath, 'w') as f:
+            f.write(''.join(L))
+        with open(self.casepath) as f:
+            self.caseSimline = len(f.readlines()) - 4      # comments are inserted above the iteration header
 
-    writeComment = writeCase
-
-    def initializeCase(self, vn, argDict):
-        fd = vn.fixData
-        s = 'VarNet (MI355X engine) case\n'
-        s += 'dim=%d feDim=%d inpDim=%d layerWidth=%s\n' % (vn.dim, fd.feDim, vn.inpDim, vn.layerWidth)
-        s += 'discNum=%s bDiscNum=%s tDiscNum=%s integPnum=%d\n' % (vn.discNum, vn.bDiscNum, vn.tDiscNum, fd.integPnum)
-        s += 'nt=%d nT=%d integNum=%d biDof=%s detJ=%.10e\n' % (fd.nt, fd.nT, fd.integNum, list(fd.biDof), fd.detJ)
-        s += 'train arguments: %s\n\n' % {k: v for k, v in argDict.items() if k not in ('self',)}
-        self.writeCase(s, mode='w')
-
-    def iterOutput(self, epoch, current_loss, min_loss, epoch_time, resVal, err, lossComp, lossVec):
-        self.loss.append(current_loss)
-        self.epochTime = epoch_time
-        if epoch % self.saveFreq != 0:
+    def writeCase(self, text):
+        if not isinstance(text, str):
+            raise ValueError('the input must be a string!')
+        if self.casepath is None:
             return
-        self.minLoss.append(min_loss)
-        if resVal is not None:
-            self.residual.append(resVal)
-        if err is not None:
-            self.error.append(err)
-        if lossComp is not None:
-            self.lossComp.append(np.reshape(lossComp, -1))
-        s = 'epoch %d: loss %.6e (best %.6e)' % (epoch, current_loss, min_loss)
-        if resVal is not None:
-            s += ' residual %.4e' % resVal
-        if err is not None:
-            s += ' error %.4e' % err
-        s += ' average iteration time: %2.5fs\n' % (epoch_time / epoch)
-        if self.verbose:
-            print(s, end='')
-        self.writeCase(s)
-        self.saveData()
+        with open(self.casepath, 'a+') as f:
+            f.write(text)
 
+    def writeComment(self, text):
+        """Insert `text` above the training iterations (post-simulation notes at the top of the case file)."""
+        if not isinstance(text, str):
+            raise ValueError('the input must be a string!')
+        if self.casepath is None:
+            return
+        lines = [ln + '\n' for ln in text.split('\n')]
+        with open(self.casepath) as f:
+            data = f.readlines()
+        data[self.caseSimline:self.caseSimline] = lines
+        with open(self.casepath, 'w') as f:
+            f.writelines(data)
+
+    # -- pickle ----------------------------------------------------------------------------------------
     def saveData(self):
         if self.folderpath is None:
             return
-        data = dict(loss=self.loss, minLoss=self.minLoss, lossComp=self.lossComp, residual=self.residual,
-                    error=self.error, inpIter=self.inpIter, trainWeight=self.trainWeight)
         with open(os.path.join(self.folderpath, 'trainData.vn'), 'wb') as f:
-            pickle.dump(data, f)
+            pickle.dump(self.__dict__, f, pickle.HIGHEST_PROTOCOL)
 
     def loadData(self):
         with open(os.path.join(self.folderpath, 'trainData.vn'), 'rb') as f:
-            data = pickle.load(f)
-        for k, v in data.items():
-            setattr(self, k, v)
+            dump = pickle.load(f)
+        for key in ('casepath', 'plotpath', 'caseSimline', 'saveFreq', 'verbose', 'pltReplace', 'trainWeight', 'loss',
+                    'lossComp', 'avgtime0', 'avgtime', 'residual', 'iterSmp', 'inpIter', 'error', 'lossVec'):
+            setattr(self, key, dump[key])
+        try:                                                   # files written before the options were stored
+            for key in ('option_stopping', 'option_trainPoint', 'option_weighting', 'option_batchOptim'):
+                setattr(self, key, dump[key])
+        except KeyError:
+            warnings.warn('train() arguments not loaded!')
+
+    # -- per-epoch report ------------------------------------------------------------------------------
+    def iterOutput(self, epoch, current_loss, min_loss, epoch_time, resVal, err, lossSplit, lossVec):
+        saveFreq = self.saveFreq
+        self.lossAll.append(current_loss)
+        if not (epoch < saveFreq or epoch % saveFreq == 0):
+            return
+        line = 'Epoch %2d: loss = %2.5f\n' % (epoch, current_loss)
+        self.writeCase(line)
+        if self.verbose:
+            print(line, end='')
+        if epoch < saveFreq:
+            if epoch == saveFreq - 1:
+                self.avgtime0 = epoch_time / epoch
+            return
+        self.iterSmp.append(epoch)
+        self.loss.append(current_loss)
+        self.lossComp.append(np.reshape(lossSplit, 3))
+        self.residual.append(resVal)
+        if self.error is not None:
+            self.error.append(err)
+        self.avgtime = epoch_time / epoch
+        self.lossVec = lossVec
+        self.saveData()
+        if epoch % (10 * saveFreq) == 0:
+            msg = '\nbest model loss: %2.5f\naverage iteration time: %2.5fs\n\n' % (min_loss, epoch_time / epoch)
+            if self.verbose:
+                print(msg, end='')
+            self.writeCase(msg)
 
 
 # ======================================================================================
@@ -857,7 +1016,7 @@ class VarNet:
         tData = self._build_tdata(batchNum, batchLen)        # first set is always uniform (VarNet.py:1300)
         if dedup and not shuffleData:
             tData.enable_dedup()                                # extension: one evaluation per unique point
-        trainRes = TrainResult(folderpath if self.rank == 0 else None, fd.cEx is not None, verbose, saveFreq)
+        trainRes = TrainResult(folderpath if self.rank == 0 else None, fd.cEx is not None, verbose, saveFreq, pltReplace)
         trainRes.initializeCase(self, argDict)
         self.trainRes = trainRes
 
@@ -914,10 +1073,10 @@ class VarNet:
 
             # regenerate the training set (VarNet.py:1385-1421)
             if smpScheme != 'uniform' and (multiTrainUpd or tp_updates == 0) and (epoch - tp_epoch) >= (trainUpdelay - 1):
-                t_loss = np.array(trainRes.loss[-5:])
+                t_loss = np.array(trainRes.loss[-5:])                # sampled every saveFreq epochs, as the reference
                 tp_conv = t_loss[:-1] - t_loss[1:]
                 tp_conv = np.sum(tp_conv[tp_conv > 0])
-                if tp_conv / t_loss[-1] < tolUpd:
+                if len(t_loss) > 0 and tp_conv / t_loss[-1] < tolUpd:
                     min_loss = float('inf')
                     tp_epoch = epoch
                     tp_updates += 1
@@ -982,19 +1141,47 @@ class VarNet:
                 return n
         raise ValueError('no restorable checkpoint data found!')
 
-    def saveNNparam(self, path=None):
-        """Export the trained kernels / biases (VarNet.py:2179-2260) as an .npz of per-layer arrays."""
+    def saveNNparam(self, dpOut=False, matOut=False, verbose=False, timeFirst=False, path=None):
+        """
+        Trained kernels and biases per layer (VarNet.py:2179-2260): list of `[W, b]` with `W [out,in]`,
+        `b [out,1]` so that `o = W i + b`; `timeFirst` moves the temporal input column in front of the
+        spatial ones in the first layer.  `matOut` writes `NN_parameters/W<n>.mat, B<n>.mat` (MATLAB),
+        `dpOut` the Diffpack-readable `W<n>.m, B<n>.m`; `path` additionally writes one `.npz`.
+        """
         flat = self.engine.get_params()
-        out, off, fan = {}, 0, self.inpDim
+        td = self.PDE.timeDependent
+        if not td:
+            timeFirst = False
+        folder = None
+        if dpOut or matOut:
+            folder = os.path.join(self.trainRes.folderpath, 'NN_parameters')
+            os.makedirs(folder, exist_ok=True)
+        layers, npz, off, fan = [], {}, 0, self.inpDim
         for l, h in enumerate(self.layerWidth + [1]):
-            out['W%d' % l] = flat[off:off + fan * h].reshape(fan, h)
+            W = flat[off:off + fan * h].reshape(fan, h).T.copy()
             off += fan * h
-            out['b%d' % l] = flat[off:off + h]
+            b = flat[off:off + h].reshape(h, 1).copy()
             off += h
             fan = h
+            if l == 0 and timeFirst:
+                dim = self.dim
+                Wt = W.copy()
+                W[:, 0] = Wt[:, dim]
+                W[:, 1:dim + 1] = Wt[:, :dim]
+            layers.append([W, b])
+            npz['W%d' % l], npz['b%d' % l] = W.T.copy(), b[:, 0].copy()
+            if verbose:
+                print('Layer %d: weight %s, bias %s' % (l, W.shape, b.shape))
+            if dpOut:
+                uf.mat2diffpack(os.path.join(folder, 'W%d.m' % (l + 1)), 'W%d' % (l + 1), W)
+                uf.mat2diffpack(os.path.join(folder, 'B%d.m' % (l + 1)), 'B%d' % (l + 1), b)
+            if matOut:
+                import scipy.io as spio
+                spio.savemat(os.path.join(folder, 'W%d.mat' % (l + 1)), {'W%d' % (l + 1): W})
+                spio.savemat(os.path.join(folder, 'B%d.mat' % (l + 1)), {'B%d' % (l + 1): b})
         if path is not None:
-            np.savez(path, **out)
-        return out
+            np.savez(path, **npz)
+        return layers
 
     # -- evaluation -------------------------------------------------------------------------------------
     def _mor_columns(self, batch, n):
