@@ -594,7 +594,15 @@ struct VnFusedArgsD {
 };
 
 template <int L, int KS>
-__global__ __launch_bounds__(NTHREADS, 2) void vn_fused16_kernel(VnFusedArgsD A) {
+// The machine-level load/store optimizer pairs LDS reads into ds_read2_b32, whose 8-bit offsets force a
+// VALU address add per pair; vector instructions share the datapath with the f32 MFMAs here, LDS issue
+// does not, so pairing is switched off for this kernel (device pass only; -0.8 % kernel time).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VN_NO_LDS_PAIRING __attribute__((target("no-load-store-opt")))
+#else
+#define VN_NO_LDS_PAIRING
+#endif
+__global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kernel(VnFusedArgsD A) {
   using LY = Lay<L, KS>;
   constexpr int MT = mtiles(KS);
   // EDGE: the last 16-row tile holds a single k-step (features 4(KS-1) .. 4(KS-1)+3, e.g. 48,49 of a
