@@ -14,7 +14,6 @@ else
   git -C $root archive $rev varnet_amd/csrc include | tar -x -C $tmp/t
 fi
 cd $tmp/t/varnet_amd/csrc
-for f in *.hip; do /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $extra -c $f -o ${f%.hip}.o & done; wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 *.o -o $root/varnet_amd/libvarnet_hip_$name.so
+make -j6 EXTRA="$extra" LIB=$root/varnet_amd/libvarnet_hip_$name.so > $tmp/build.log 2>&1 || { tail -20 $tmp/build.log; exit 1; }
 rm -rf $tmp
 echo built $root/varnet_amd/libvarnet_hip_$name.so
