@@ -70,6 +70,8 @@ CASES = [
     (3, 2, [32, 17],             32,      50,  10,  4,   False, True,  True),
     (2, 1, [20, 20, 20],         36,      41,  25,  9,   True,  True,  False),    # 3-point Gauss, 1D+t
     (3, 2, [50, 50, 50],         36,      17,  12,  5,   False, True,  True),
+    (3, 2, [50, 50, 50],         216,     7,   40,  22,  True,  True,  False),   # 3-point Gauss, 2D+t: two-pass fused
+    (3, 2, [20, 20, 20, 20],     216,     5,   9,   4,   False, True,  True),
 ]
 
 
@@ -78,7 +80,8 @@ def _skip_unsupported(kernel, widths, integNum):
                         (max(widths) > 20 and len(widths) < 2) or (max(widths) > 32 and len(widths) < 3) or
                         len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused32 not instantiated for this shape')
-    if kernel == 3 and (integNum > 128 or max(widths) > 52 or len(widths) < 2 or
+    if kernel == 3 and (max(widths) > 50 or len(widths) < 2 or          # integNum > 128: two-pass fused route
+                       
                         (max(widths) > 32 and len(widths) < 3) or len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused16 not instantiated for this shape')
 

@@ -85,6 +85,8 @@ struct vn_engine {
   int64_t step = 0;
   bool use_fused = false;
   bool use_fused16 = false;
+  bool two_pass = false;             // fused kernel twice around the row-wise seed kernel (integ_num > 128)
+  float* tp_losspart = nullptr; long tp_losspart_cap = 0;
   float* fused_losspart = nullptr;   // [ncu*3]
   unsigned long long* stamps = nullptr;   // 8 counters, diagnostic builds
   // de-duplicated formulation work buffers
@@ -195,6 +197,54 @@ int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* l
   if (lossdst) {
     HIPCHK(vn_reduce_launch(nullptr, 0, 0, h->losspart, grid, h->bDof, h->nB, a.w0, a.w1, a.w2, lossdst, h->stream));
   }
+  return VN_OK;
+}
+
+// Test functions that do not fit one 128-point tile (integNum 216: 3-point Gauss in 2D+t) cannot have their
+// R_k formed inside a tile.  Two launches of the 8-wave fused kernel around the row-wise seed kernel:
+//   1. forward only  -> u, directional derivative per row          (2 F_pt)
+//   2. vn_seed_kernel -> R_k, lossVec, variational loss partials, per-row seeds
+//   3. reverse pass with those seeds (recomputes the forward); BC/IC tiles ride along   (6 F_pt)
+// 8 F_pt per point instead of 6, against 8 F_pt at 0.07 of peak on the generic kernels.
+int run_twopass(vn_engine* h, const Batch& b, float* gradbuf) {
+  const int grid = h->ncu, P = h->net.P, q = h->cfg.integ_num;
+  const long nT = b.n_k * q;
+  const int sgrid = (int)((b.n_k + 255) / 256);
+  if (int rc = ensure(&h->tp_losspart, &h->tp_losspart_cap, (long)(grid + sgrid) * 3)) return rc;
+  float* lp = h->tp_losspart;
+  VnFusedArgs f{};
+  f.net = h->net; f.theta = h->theta; f.X = b.Input; f.G = b.gcoef; f.src = nullptr;
+  f.nT = nT; f.n_k = 0; f.integ_num = q;
+  f.feN = h->feN; f.fedNt = h->fedNt; f.feW = nullptr; f.detJv = nullptr; f.detJ = 0.f;
+  f.time_dependent = h->cfg.time_dependent; f.lossVec = nullptr;
+  f.Xb = h->biInput; f.label = h->biLabel; f.nB = 0; f.bDof = h->bDof; f.biDimVal = (float)h->biDimVal;
+  f.w0 = (float)h->w[0]; f.w1 = (float)h->w[1]; f.w2 = (float)h->w[2];
+  f.partial = h->partial; f.losspart = lp; f.stamps = nullptr;
+  f.dir = -1; f.ostride = 1;
+  f.mode = 1; f.out_u = h->u; f.out_ud = h->ud;
+  HIPCHK(vn_fused16_launch(f, grid, h->stream));
+
+  VnSeedArgs a{};
+  a.u = h->u; a.ud = h->ud; a.source = h->cfg.has_source ? b.source : nullptr;
+  a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
+  a.Nrow = b.Nrow; a.dNtrow = b.dNtrow;
+  a.detJv = b.detJv; a.detJ = (float)b.detJ;
+  a.n_k = b.n_k; a.integ_num = q; a.time_dependent = h->cfg.time_dependent;
+  a.ubar = h->ubar; a.udbar = h->udbar; a.lossVec = nullptr;
+  a.ub = nullptr; a.label = nullptr; a.nB = 0; a.bDof = 0; a.biDimVal = 0.f; a.ubar_b = nullptr;   // BC/IC: step 3
+  a.w0 = f.w0; a.w1 = f.w1; a.w2 = f.w2;
+  a.part = lp + (long)grid * 3;
+  HIPCHK(vn_seed_launch(a, sgrid, h->stream));
+
+  f.mode = 2; f.out_u = nullptr; f.out_ud = nullptr; f.seed_u = h->ubar; f.seed_ud = h->udbar; f.nB = h->nB;
+  const bool rec = h->prof_on && h->prof_n < PROF_CAP;
+  if (rec) {
+    if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
+    HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
+  }
+  HIPCHK(vn_fused16_launch(f, grid, h->stream));
+  if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
+  HIPCHK(vn_reduce_launch(h->partial, grid, P, lp, grid + sgrid, h->bDof, h->nB, f.w0, f.w1, f.w2, gradbuf, h->stream));
   return VN_OK;
 }
 
@@ -316,16 +366,19 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
     vn_destroy(h);
     return fail(VN_EUNSUPPORTED, "fused kernel unsupported for this network / integ_num");
   }
-  if (cfg->kernel == VN_KERNEL_FUSED16 && !vn_fused16_supported(net, cfg->integ_num)) {
+  const bool tp_ok = cfg->integ_num > 128 && vn_fused16_net_supported(net);
+  if (cfg->kernel == VN_KERNEL_FUSED16 && !vn_fused16_supported(net, cfg->integ_num) && !tp_ok) {
     vn_destroy(h);
     return fail(VN_EUNSUPPORTED, "fused16 kernel unsupported for this network / integ_num");
   }
   // AUTO: the 8-wave geometry where instantiated (faster: two waves per SIMD overlap VALU/LDS work
   // with MFMA), else the 4-wave geometry, else the generic kernels
-  h->use_fused16 = cfg->kernel == VN_KERNEL_FUSED16 ||
-                   (cfg->kernel == VN_KERNEL_AUTO && vn_fused16_supported(net, cfg->integ_num));
+  h->use_fused16 = (cfg->kernel == VN_KERNEL_FUSED16 || cfg->kernel == VN_KERNEL_AUTO) &&
+                   vn_fused16_supported(net, cfg->integ_num);
   h->use_fused = h->use_fused16 ||
                  (cfg->kernel != VN_KERNEL_GENERIC && vn_fused_supported(net, cfg->integ_num));
+  h->two_pass = !h->use_fused && tp_ok && (cfg->kernel == VN_KERNEL_FUSED16 || cfg->kernel == VN_KERNEL_AUTO);
+  if (h->two_pass) h->prof_name = "vn_fused16_kernel";
   if (h->use_fused) {
     if (hipMalloc((void**)&h->fused_losspart, (size_t)h->ncu * 3 * sizeof(float)) != hipSuccess) {
       vn_destroy(h);
@@ -346,7 +399,7 @@ int vn_destroy(vn_engine* h) {
   (void)hipSetDevice(h->cfg.device);
   void* ptrs[] = {h->theta, h->m, h->v, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
                   h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart, h->stamps, h->dd_uv, h->dd_ug, h->dd_su, h->dd_sg, h->dd_partial,
-                  h->dd_losspart};
+                  h->dd_losspart, h->tp_losspart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
@@ -557,6 +610,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
   HIPCHK(hipSetDevice(h->cfg.device));
   const Batch& b = h->batches[batch];
   if (b.Xu && h->use_fused16) return run_dedup(h, b, true, nullptr, h->gradbuf);
+  if (h->two_pass) return run_twopass(h, b, h->gradbuf);
   if (h->use_fused) {
     VnFusedArgs a{};
     a.net = h->net; a.theta = h->theta;

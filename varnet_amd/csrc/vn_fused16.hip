@@ -1125,11 +1125,15 @@ size_t vn_fused16_lds_bytes(const VnNet& net) {
   return 0;
 }
 
-bool vn_fused16_supported(const VnNet& net, int integ_num) {
+bool vn_fused16_net_supported(const VnNet& net) {
   if (net.d_in > 4 * KS0) return false;
-  if (integ_num < 1 || integ_num > TILE) return false;   // whole test functions must fit a tile
   const size_t b = vn_fused16_lds_bytes(net);
   return b != 0 && b <= 160 * 1024;
+}
+
+bool vn_fused16_supported(const VnNet& net, int integ_num) {
+  if (integ_num < 1 || integ_num > TILE) return false;   // whole test functions must fit a tile
+  return vn_fused16_net_supported(net);
 }
 
 hipError_t vn_fused16_launch(const VnFusedArgs& h, int grid, hipStream_t s) {

@@ -85,6 +85,7 @@ size_t vn_fused_lds_bytes(const VnNet& net);
 hipError_t vn_fused_launch(const VnFusedArgs& a, int grid, hipStream_t s);
 // 8-wave / 16x16x4 geometry of the same kernel (vn_fused16.hip)
 bool vn_fused16_supported(const VnNet& net, int integ_num);
+bool vn_fused16_net_supported(const VnNet& net);   // network instantiated (any integ_num: two-pass route)
 size_t vn_fused16_lds_bytes(const VnNet& net);
 hipError_t vn_fused16_launch(const VnFusedArgs& a, int grid, hipStream_t s);
 
