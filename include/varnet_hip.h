@@ -44,7 +44,7 @@ enum {
 };
 
 enum { VN_ACT_SIGMOID = 0 };
-enum { VN_OPT_ADAM = 0 };
+enum { VN_OPT_ADAM = 0, VN_OPT_RMSPROP = 1 };   /* tf.train.AdamOptimizer / RMSPropOptimizer (TFModel.py:183-186) */
 enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 /* 4 waves, 32x32x2 */,
        VN_KERNEL_FUSED16 = 3 /* 8 waves, 16x16x4 */ };
 
@@ -62,7 +62,7 @@ typedef struct vn_config {
   int32_t has_source;               /* lossOpt['isSource']  (TFModel.py:656)               */
   int32_t has_integw;               /* lossOpt['integWflag'] (TFModel.py:660)              */
   int32_t device;                   /* HIP device ordinal                                  */
-  int32_t optimizer;                /* VN_OPT_ADAM (TFModel.py:183-184)                    */
+  int32_t optimizer;                /* VN_OPT_ADAM | VN_OPT_RMSPROP (TFModel.py:183-186)   */
   int32_t kernel;                   /* VN_KERNEL_*                                         */
   double  lr, beta1, beta2, eps;    /* TF-1 Adam defaults 1e-3, .9, .999, 1e-8             */
 } vn_config;
@@ -131,7 +131,8 @@ int vn_bind_grad_buffer(vn_engine* h, float* dev);
 /* compute_gradients(loss) (TFModel.py:709): forward, weak-form loss, backward for `batch`;
  * leaves d loss/d theta and the 4 loss scalars in the gradient buffer. */
 int vn_grad(vn_engine* h, int32_t batch);
-/* optimizer.apply_gradients (TFModel.py:313): TF-1 Adam step from the gradient buffer. */
+/* optimizer.apply_gradients (TFModel.py:313): TF-1 Adam (or RMSProp: decay 0.9, momentum 0, eps 1e-10,
+ * mean-square slot initialised to ones) step from the gradient buffer. */
 int vn_apply(vn_engine* h);
 /* sess.run([optMinimize, loss]) (VarNetUtility.py:1044) = vn_grad + vn_apply.  If
  * loss_out_dev != NULL the pre-update loss is copied there (device scalar, async). */

@@ -38,9 +38,10 @@ def synth(seed, d_in, dim, widths, integNum, n_k, nB, bDof, source=False, integW
     return d
 
 
-def make_engine(d_in, dim, widths, integNum, source, integW, kernel=0):
+def make_engine(d_in, dim, widths, integNum, source, integW, kernel=0, optimizer_name='adam'):
     from varnet_amd.engine import VNEngine
-    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel)
+    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel,
+                    optimizer_name=optimizer_name)
 
 
 def oracle_eval(flat, d, d_in, dim, widths, integNum, n_k, bDof, source, integW, detJvec):
@@ -182,6 +183,46 @@ def test_adam_trajectory_parity(kernel):
     eng.import_state(st)
     assert np.array_equal(eng.get_params(), p1) and eng.step == steps
     eng.close()
+
+
+def test_rmsprop_trajectory_parity():
+    """40 TF-1 RMSProp steps (decay 0.9, eps 1e-10, mean-square slot starting at ones; TFModel.py:185-186)
+    against the oracle's restatement of ApplyRMSProp (beyond ~55 steps this problem's RMSProp iteration
+    starts to oscillate and fp32/fp64 trajectories separate); state survives export/import."""
+    d_in, dim, widths, integNum, n_k, nB, bDof = 2, 1, [20, 20], 16, 64, 60, 40
+    d = synth(2, d_in, dim, widths, integNum, n_k, nB, bDof)
+    eng = make_engine(d_in, dim, widths, integNum, False, False, 0, optimizer_name='RMSProp')
+    eng.init_params(seed=1)
+    flat = eng.get_params()
+    eng.set_fe_table(d['N1'], d['dNt1'], None)
+    eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=n_k, detJ=d['detJ'])
+    eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+    eng.set_weights(d['w'])
+    steps = 40
+    losses = torch.zeros(steps, device='cuda')
+    for i in range(steps):
+        eng.train_step(0, losses[i:i + 1])
+    torch.cuda.synchronize()
+    got = losses.cpu().numpy()
+    opt = og.TF1RMSProp(flat.size, lr=1e-3, dtype=np.float64)
+    th = flat.astype(np.float64)
+    ref = []
+    for i in range(steps):
+        r, g = oracle_eval(th, d, d_in, dim, widths, integNum, n_k, bDof, False, False, False)
+        ref.append(r['loss'])
+        th = opt.step(th, g)
+    ref = np.array(ref)
+    assert np.max(np.abs(got - ref) / np.abs(ref)) <= 1e-3
+    assert np.max(np.abs(eng.get_params() - th)) <= 2e-3 * np.max(np.abs(th))
+    st = eng.export_state()
+    p1 = eng.get_params()
+    eng.init_params(seed=9)
+    eng.import_state(st)
+    assert np.array_equal(eng.get_params(), p1) and eng.step == steps
+    eng.train_step(0)
+    eng.close()
+    with pytest.raises(ValueError):
+        make_engine(d_in, dim, widths, integNum, False, False, 0, optimizer_name='sgd')
 
 
 STEADY = [

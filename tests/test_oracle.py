@@ -116,3 +116,17 @@ def test_glorot_limits_and_determinism():
 def test_shard_rule():
     assert [og.shard_rows(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert og.shard_rows(100000, 7, 8) == (87500, 100000)
+
+
+def test_tf1_rmsprop_known_answer():
+    """First steps of TF-1 RMSProp by hand: ms starts at ones, ms1 = 1 + (g^2-1)*0.1, step = lr*g/sqrt(ms1+1e-10)."""
+    opt = og.TF1RMSProp(2, lr=1e-2, dtype=np.float64)
+    th = np.array([1.0, -2.0])
+    g = np.array([3.0, 0.5])
+    th1 = opt.step(th, g)
+    ms1 = 1.0 + (g * g - 1.0) * 0.1
+    np.testing.assert_allclose(opt.ms, ms1, rtol=1e-15)
+    np.testing.assert_allclose(th1, th - 1e-2 * g / np.sqrt(ms1 + 1e-10), rtol=1e-15)
+    th2 = opt.step(th1, g)
+    ms2 = ms1 + (g * g - ms1) * 0.1
+    np.testing.assert_allclose(th2, th1 - 1e-2 * g / np.sqrt(ms2 + 1e-10), rtol=1e-15)

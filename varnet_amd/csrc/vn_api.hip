@@ -110,7 +110,7 @@ int build_net(const vn_config& c, VnNet& net) {
   if (c.dim < 1 || c.dim > c.d_in) return fail(VN_EINVAL, "dim=%d must be in [1,d_in]", c.dim);
   if (c.integ_num < 1) return fail(VN_EINVAL, "integ_num must be positive");
   if (c.activation != VN_ACT_SIGMOID) return fail(VN_EUNSUPPORTED, "only the sigmoid activation is implemented");
-  if (c.optimizer != VN_OPT_ADAM) return fail(VN_EUNSUPPORTED, "only the Adam optimizer is implemented");
+  if (c.optimizer != VN_OPT_ADAM && c.optimizer != VN_OPT_RMSPROP) return fail(VN_EINVAL, "unknown optimizer requested!");
   if (c.lr < 0.0) return fail(VN_EINVAL, "learning rate must be positive!");  // TFModel.py:130
   memset(&net, 0, sizeof net);
   net.d_in = c.d_in;
@@ -436,7 +436,13 @@ int vn_params_init(vn_engine* h, uint64_t seed) {
   }
   HIPCHK(hipMemcpyAsync(h->theta, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemsetAsync(h->m, 0, t.size() * sizeof(float), h->stream));
-  HIPCHK(hipMemsetAsync(h->v, 0, t.size() * sizeof(float), h->stream));
+  if (h->cfg.optimizer == VN_OPT_RMSPROP) {          // TF-1 initialises the mean-square slot to ones
+    std::vector<float> ones(net.P, 1.f);
+    HIPCHK(hipMemcpyAsync(h->v, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  } else {
+    HIPCHK(hipMemsetAsync(h->v, 0, t.size() * sizeof(float), h->stream));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   h->step = 0;
   return VN_OK;
@@ -659,6 +665,10 @@ int vn_apply(vn_engine* h) {
   if (!h) return fail(VN_EINVAL, "null handle");
   HIPCHK(hipSetDevice(h->cfg.device));
   h->step += 1;
+  if (h->cfg.optimizer == VN_OPT_RMSPROP) {
+    HIPCHK(vn_rmsprop_launch(h->theta, h->m, h->v, h->gradbuf, h->net.P, (float)h->cfg.lr, 0.9f, 0.0f, 1e-10f, h->stream));
+    return VN_OK;
+  }
   const double t = (double)h->step;
   const double lr_t = h->cfg.lr * std::sqrt(1.0 - std::pow(h->cfg.beta2, t)) / (1.0 - std::pow(h->cfg.beta1, t));
   HIPCHK(vn_adam_launch(h->theta, h->m, h->v, h->gradbuf, h->net.P, (float)lr_t, (float)h->cfg.beta1,

@@ -442,6 +442,22 @@ __global__ __launch_bounds__(NTHREADS) void vn_adam_kernel(float* __restrict__ t
   }
 }
 
+// TF-1 RMSPropOptimizer update (ApplyRMSProp, not centered): ms += (g^2 - ms)(1 - rho);
+// mom = momentum*mom + lr*g/sqrt(ms + eps); theta -= mom.  Restated in oracle/tf1_graph.py::TF1RMSProp.
+__global__ __launch_bounds__(NTHREADS) void vn_rmsprop_kernel(float* __restrict__ theta, float* __restrict__ mom,
+                                                              float* __restrict__ ms, const float* __restrict__ g,
+                                                              int P, float lr, float rho, float momentum, float eps) {
+  const int p = blockIdx.x * NTHREADS + threadIdx.x;
+  if (p < P) {
+    const float gi = g[p];
+    const float msi = ms[p] + (gi * gi - ms[p]) * (1.f - rho);
+    const float mi = momentum * mom[p] + lr * gi / sqrtf(msi + eps);
+    ms[p] = msi;
+    mom[p] = mi;
+    theta[p] = theta[p] - mi;
+  }
+}
+
 }  // namespace
 
 size_t vn_generic_fwd_lds_bytes(const VnNet& net) {
@@ -499,5 +515,12 @@ hipError_t vn_adam_launch(float* theta, float* m, float* v, const float* grad, i
                           float b2, float eps, hipStream_t s) {
   const int grid = (P + NTHREADS - 1) / NTHREADS;
   hipLaunchKernelGGL(vn_adam_kernel, dim3(grid), dim3(NTHREADS), 0, s, theta, m, v, grad, P, lr_t, b1, b2, eps);
+  return hipGetLastError();
+}
+
+hipError_t vn_rmsprop_launch(float* theta, float* mom, float* ms, const float* grad, int P, float lr, float rho,
+                             float momentum, float eps, hipStream_t s) {
+  const int grid = (P + NTHREADS - 1) / NTHREADS;
+  hipLaunchKernelGGL(vn_rmsprop_kernel, dim3(grid), dim3(NTHREADS), 0, s, theta, mom, ms, grad, P, lr, rho, momentum, eps);
   return hipGetLastError();
 }

@@ -123,7 +123,7 @@ class VNEngine:
             raise ValueError('mixed activation functions are not supported')
         if act != 'sigmoid':
             raise ValueError('only the sigmoid activation is implemented')
-        if optimizer_name.lower() not in ('adam',):
+        if optimizer_name.lower() not in ('adam', 'rmsprop'):
             raise ValueError('unknown optimizer requested!')           # TFModel.py:133-134
         if learning_rate < 0.0:
             raise ValueError('learning rate must be positive!')        # TFModel.py:130
@@ -139,7 +139,7 @@ class VNEngine:
         cfg.has_source = int(bool(isSource))
         cfg.has_integw = int(bool(integWflag))
         cfg.device = int(device)
-        cfg.optimizer = 0
+        cfg.optimizer = 1 if optimizer_name.lower() == 'rmsprop' else 0
         cfg.kernel = kernel
         cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = learning_rate, 0.9, 0.999, 1e-8
         self.cfg = cfg

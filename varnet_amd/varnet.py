@@ -559,8 +559,6 @@ class VarNet:
             optimizer = 'rmsprop'
         if optimizer.lower() not in ('adam', 'rmsprop'):
             raise ValueError('unknown optimizer requested!')
-        if optimizer.lower() == 'rmsprop':
-            raise NotImplementedError('RMSProp is not implemented (Adam is what the operators use)')
 
         inpDim = dim + (1 if timeDependent else 0)
         if MORvar is not None:
