@@ -408,3 +408,34 @@ def test_dedup_formulation_parity(case):
     torch.cuda.synchronize()
     assert np.array_equal(gb.cpu().numpy(), g_rows)
     eng.close()
+
+
+@pytest.mark.parametrize('widths,q,n_k,src', [([50, 50, 50, 50], 16, 20000, True),     # <4,13>: all 3 hidden layers stashed in LDS
+                                               ([50, 50, 50], 64, 5000, False),          # <3,13>
+                                               ([50, 50], 64, 5000, False),              # <2,13>: one hidden layer
+                                               ([30, 30, 30, 30], 16, 20000, False),     # <4,8>: generic cooperative path
+                                               ([50, 50, 50, 50, 50], 216, 1500, True)])  # two-pass route, several tiles per workgroup
+def test_many_tiles_per_workgroup_fused_vs_generic(widths, q, n_k, src):
+    """Each workgroup loops over several 128-point tiles (persistent / LDS-stashed weight-gradient accumulators,
+    fixed-order flush): the fused gradient must equal the generic kernels' (independent implementation) to fp32
+    rounding, and two runs must agree bit for bit."""
+    d_in, dim, nB, bDof = 3, 2, 900, 500
+    d = synth(11, d_in, dim, widths, q, n_k, nB, bDof, src, q == 216, False)
+    grads = []
+    for kernel in (1, 0, 0):
+        eng = make_engine(d_in, dim, widths, q, src, q == 216, kernel)
+        eng.init_params(seed=2)
+        eng.set_fe_table(d['N1'], d['dNt1'], d['integW'])
+        eng.set_interior(0, d['Input'], d['gcoef'], d['source'], n_k=n_k, detJ=d['detJ'])
+        eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+        eng.set_weights(d['w'])
+        gb = eng.bind_grad_buffer()
+        eng.grad(0)
+        torch.cuda.synchronize()
+        grads.append(gb.cpu().numpy().copy())
+        eng.close()
+    g_gen, g_a, g_b = grads
+    assert np.array_equal(g_a, g_b)
+    P = g_gen.size - 4
+    assert abs(g_a[P] - g_gen[P]) <= 2e-5 * abs(g_gen[P])
+    assert np.max(np.abs(g_a[:P] - g_gen[:P])) <= 2e-4 * np.max(np.abs(g_gen[:P]))
