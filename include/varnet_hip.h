@@ -137,6 +137,10 @@ int vn_apply(vn_engine* h);
 /* sess.run([optMinimize, loss]) (VarNetUtility.py:1044) = vn_grad + vn_apply.  If
  * loss_out_dev != NULL the pre-update loss is copied there (device scalar, async). */
 int vn_train_step(vn_engine* h, int32_t batch, float* loss_out_dev);
+/* ManageTrainData.optimIter (VarNetUtility.py:1021-1047) for one process: `n` consecutive steps
+ * (vn_grad + vn_apply) over batches[0..n), the pre-update loss of each step ADDED to the device scalar
+ * *loss_acc_dev (may be NULL).  One host call per epoch instead of four per mini-batch; no sync. */
+int vn_train_epoch(vn_engine* h, const int32_t* batches, int32_t n, float* loss_acc_dev);
 
 /* ManageTrainData.splitLoss (VarNetUtility.py:1080-1088): out = {loss, BCloss, ICloss,
  * varLoss} (host doubles), lossVec_dev [n_k] or NULL.  Synchronises. */

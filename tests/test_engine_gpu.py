@@ -225,6 +225,35 @@ def test_rmsprop_trajectory_parity():
         make_engine(d_in, dim, widths, integNum, False, False, 0, optimizer_name='sgd')
 
 
+def test_train_epoch_equals_single_steps():
+    """vn_train_epoch (one host call for a pass over the mini-batches, VarNetUtility.py:1021-1047) leaves the same
+    parameters as the same steps issued one by one, and adds every pre-update loss to the device scalar."""
+    d_in, dim, widths, integNum, n_k, nB, bDof = 2, 1, [20, 20, 20], 16, 96, 60, 40
+    d = synth(4, d_in, dim, widths, integNum, n_k, nB, bDof)
+    engs = []
+    for _ in range(2):
+        eng = make_engine(d_in, dim, widths, integNum, False, False, 0)
+        eng.init_params(seed=1)
+        eng.set_fe_table(d['N1'], d['dNt1'], None)
+        half = (n_k // 2) * integNum
+        eng.set_interior(0, d['Input'][:half], d['gcoef'][:half], None, n_k=n_k // 2, detJ=d['detJ'])
+        eng.set_interior(1, d['Input'][half:], d['gcoef'][half:], None, n_k=n_k - n_k // 2, detJ=d['detJ'])
+        eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+        eng.set_weights(d['w'])
+        engs.append(eng)
+    order = [0, 1, 1, 0, 1]
+    acc = torch.zeros((), device='cuda')
+    engs[0].train_epoch(order, acc)
+    losses = torch.zeros(len(order), device='cuda')
+    for i, b in enumerate(order):
+        engs[1].train_step(b, losses[i:i + 1])
+    torch.cuda.synchronize()
+    assert np.array_equal(engs[0].get_params(), engs[1].get_params()) and engs[0].step == engs[1].step == len(order)
+    assert abs(float(acc) - float(losses.sum())) <= 1e-5 * float(losses.sum())
+    for e in engs:
+        e.close()
+
+
 STEADY = [
     # d_in dim widths        integNum n_k nB  (time-independent: no IC rows, no dNt term; TFModel.py:537,646-650)
     (1, 1, [20, 20],         4,       37, 2),

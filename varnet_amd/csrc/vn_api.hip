@@ -661,18 +661,32 @@ int vn_grad(vn_engine* h, int32_t batch) {
   return VN_OK;
 }
 
-int vn_apply(vn_engine* h) {
-  if (!h) return fail(VN_EINVAL, "null handle");
+static int apply_impl(vn_engine* h, float* loss_acc) {
   HIPCHK(hipSetDevice(h->cfg.device));
   h->step += 1;
   if (h->cfg.optimizer == VN_OPT_RMSPROP) {
-    HIPCHK(vn_rmsprop_launch(h->theta, h->m, h->v, h->gradbuf, h->net.P, (float)h->cfg.lr, 0.9f, 0.0f, 1e-10f, h->stream));
+    HIPCHK(vn_rmsprop_launch(h->theta, h->m, h->v, h->gradbuf, h->net.P, (float)h->cfg.lr, 0.9f, 0.0f, 1e-10f, loss_acc,
+                             h->stream));
     return VN_OK;
   }
   const double t = (double)h->step;
   const double lr_t = h->cfg.lr * std::sqrt(1.0 - std::pow(h->cfg.beta2, t)) / (1.0 - std::pow(h->cfg.beta1, t));
   HIPCHK(vn_adam_launch(h->theta, h->m, h->v, h->gradbuf, h->net.P, (float)lr_t, (float)h->cfg.beta1,
-                        (float)h->cfg.beta2, (float)h->cfg.eps, h->stream));
+                        (float)h->cfg.beta2, (float)h->cfg.eps, loss_acc, h->stream));
+  return VN_OK;
+}
+
+int vn_apply(vn_engine* h) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  return apply_impl(h, nullptr);
+}
+
+int vn_train_epoch(vn_engine* h, const int32_t* batches, int32_t n, float* loss_acc_dev) {
+  if (!h || (n > 0 && !batches)) return fail(VN_EINVAL, "null argument");
+  for (int32_t i = 0; i < n; ++i) {
+    if (int rc = vn_grad(h, batches[i])) return rc;
+    if (int rc = apply_impl(h, loss_acc_dev)) return rc;
+  }
   return VN_OK;
 }
 

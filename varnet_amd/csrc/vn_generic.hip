@@ -430,8 +430,10 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void vn_reduce_kernel(const float*
 // TF-1 AdamOptimizer update (restated in oracle/tf1_graph.py::TF1Adam); lr_t computed on host.
 __global__ __launch_bounds__(NTHREADS) void vn_adam_kernel(float* __restrict__ theta, float* __restrict__ m,
                                                            float* __restrict__ v, const float* __restrict__ g,
-                                                           int P, float lr_t, float b1, float b2, float eps) {
+                                                           int P, float lr_t, float b1, float b2, float eps,
+                                                           float* __restrict__ loss_acc) {
   const int p = blockIdx.x * NTHREADS + threadIdx.x;
+  if (p == 0 && loss_acc) loss_acc[0] += g[P];          // epoch loss = sum of pre-update losses (g[P] = loss)
   if (p < P) {
     const float gi = g[p];
     const float mi = b1 * m[p] + (1.f - b1) * gi;
@@ -446,8 +448,10 @@ __global__ __launch_bounds__(NTHREADS) void vn_adam_kernel(float* __restrict__ t
 // mom = momentum*mom + lr*g/sqrt(ms + eps); theta -= mom.  Restated in oracle/tf1_graph.py::TF1RMSProp.
 __global__ __launch_bounds__(NTHREADS) void vn_rmsprop_kernel(float* __restrict__ theta, float* __restrict__ mom,
                                                               float* __restrict__ ms, const float* __restrict__ g,
-                                                              int P, float lr, float rho, float momentum, float eps) {
+                                                              int P, float lr, float rho, float momentum, float eps,
+                                                              float* __restrict__ loss_acc) {
   const int p = blockIdx.x * NTHREADS + threadIdx.x;
+  if (p == 0 && loss_acc) loss_acc[0] += g[P];
   if (p < P) {
     const float gi = g[p];
     const float msi = ms[p] + (gi * gi - ms[p]) * (1.f - rho);
@@ -512,15 +516,15 @@ hipError_t vn_reduce_launch(const float* partial, int nparts, int P, const float
 }
 
 hipError_t vn_adam_launch(float* theta, float* m, float* v, const float* grad, int P, float lr_t, float b1,
-                          float b2, float eps, hipStream_t s) {
+                          float b2, float eps, float* loss_acc, hipStream_t s) {
   const int grid = (P + NTHREADS - 1) / NTHREADS;
-  hipLaunchKernelGGL(vn_adam_kernel, dim3(grid), dim3(NTHREADS), 0, s, theta, m, v, grad, P, lr_t, b1, b2, eps);
+  hipLaunchKernelGGL(vn_adam_kernel, dim3(grid), dim3(NTHREADS), 0, s, theta, m, v, grad, P, lr_t, b1, b2, eps, loss_acc);
   return hipGetLastError();
 }
 
 hipError_t vn_rmsprop_launch(float* theta, float* mom, float* ms, const float* grad, int P, float lr, float rho,
-                             float momentum, float eps, hipStream_t s) {
+                             float momentum, float eps, float* loss_acc, hipStream_t s) {
   const int grid = (P + NTHREADS - 1) / NTHREADS;
-  hipLaunchKernelGGL(vn_rmsprop_kernel, dim3(grid), dim3(NTHREADS), 0, s, theta, mom, ms, grad, P, lr, rho, momentum, eps);
+  hipLaunchKernelGGL(vn_rmsprop_kernel, dim3(grid), dim3(NTHREADS), 0, s, theta, mom, ms, grad, P, lr, rho, momentum, eps, loss_acc);
   return hipGetLastError();
 }

@@ -56,9 +56,9 @@ hipError_t vn_reduce_launch(const float* partial, int nparts, int P, const float
                             int nlossparts, long bDof, long nB, float w0, float w1, float w2,
                             float* gradbuf, hipStream_t s);
 hipError_t vn_adam_launch(float* theta, float* m, float* v, const float* grad, int P, float lr_t,
-                          float b1, float b2, float eps, hipStream_t s);
+                          float b1, float b2, float eps, float* loss_acc, hipStream_t s);
 hipError_t vn_rmsprop_launch(float* theta, float* mom, float* ms, const float* grad, int P, float lr, float rho,
-                              float momentum, float eps, hipStream_t s);
+                              float momentum, float eps, float* loss_acc, hipStream_t s);
 
 // ---- fused forward+epilogue+backward kernel (vn_fused.hip) --------------------------------
 struct VnFusedArgs {

@@ -56,6 +56,7 @@ _SIGS = {
     'vn_grad': (C.c_int, [C.c_void_p, C.c_int32]),
     'vn_apply': (C.c_int, [C.c_void_p]),
     'vn_train_step': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    'vn_train_epoch': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),
     'vn_eval_loss': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
     'vn_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'vn_forward_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -297,6 +298,12 @@ class VNEngine:
 
     def train_step(self, batch=0, loss_out=None):
         self._ck(self.lib.vn_train_step(self.h, batch, _ptr(loss_out)))
+
+    def train_epoch(self, batches, loss_acc=None):
+        """len(batches) optimizer steps in one host call; each step's pre-update loss is added to the
+        device scalar `loss_acc` (VarNetUtility.py:1043-1045)."""
+        arr = (C.c_int32 * len(batches))(*[int(b) for b in batches])
+        self._ck(self.lib.vn_train_epoch(self.h, arr, len(batches), _ptr(loss_acc)))
 
     def eval_loss(self, batch=0, lossVec=False):
         out = (C.c_double * 4)()

@@ -969,6 +969,10 @@ class VarNet:
         device scalar `loss_acc`."""
         eng = self.engine
         P = eng.P
+        if self.world == 1 and hasattr(eng, 'train_epoch'):
+            # one process: the whole pass in one host call (no per-mini-batch Python / launch-queue gaps)
+            eng.train_epoch([tData.engine_batch(mb, bi) for bi in range(tData.batchNum)], loss_acc)
+            return
         gb = eng.bind_grad_buffer()
         for bi in range(tData.batchNum):
             eng.grad(tData.engine_batch(mb, bi))
