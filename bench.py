@@ -171,7 +171,7 @@ def main():
     # ---- extra, separately reported: de-duplicated formulation (one network evaluation per unique
     # quadrature point; SURVEY.md 8d "honest accounting").  Never mixed into `value`.
     dd = None
-    if not args.no_dedup:
+    if not args.no_dedup and world == 1:          # the scaling runs time the headline formulation only
         U_local = tdata.enable_dedup()
         if U_local:
             for _ in range(args.warmup):
