@@ -515,7 +515,8 @@ __device__ __forceinline__ void h13_wgrad_layer(const float (&av)[13], const flo
 }
 
 template <int GS>
-__device__ __forceinline__ void h13_flush(const f32x4 (&acc)[2], float* Gl, const LaneC& lc, int wave, int lane) {
+__device__ __forceinline__ void h13_flush(const f32x4 (&acc)[2], float* Gl, const LaneC& lc, int wave, int lane,
+                                          int slot_lo, int slot_hi) {   // tile waves: slots [slot_lo, slot_hi)
   const int role = H13::role(wave);
   if (role == 1) {                                   // rows 48, 49, bias x every column position
     const int pos = lane;                            // 4b + j
@@ -541,6 +542,7 @@ __device__ __forceinline__ void h13_flush(const f32x4 (&acc)[2], float* Gl, cons
   const int m = H13::tile_m(wave), n0 = H13::tile_n(wave);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
+    if (t < slot_lo || t >= slot_hi) continue;
     const int col = vfeat(16 * (t ? 2 : n0) + lc.c);           // slot 1: this wave's share of tile (m,2)
     if (col < GS) {
 #pragma unroll
@@ -1039,24 +1041,46 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   __syncthreads();
   for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
   __syncthreads();
-  for (int w = 0; w < NW; ++w) {                     // fixed order: bitwise reproducible sums
-    if (wave == w) {
-      if (thin_in) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
-      else wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
+  // Accumulators -> LDS gradient image, every sum in a fixed order (bitwise reproducible).
+  if constexpr (HID13) {
+    // 50-wide hidden layers: a tile wave's first slot and the two border jobs own their image elements
+    // exclusively (one parallel phase); the shared tile (m,2) gets its two halves in two phases.
+    auto flush_hidden = [&](int slot_lo, int slot_hi) {
 #pragma unroll
-      for (int l = 2; l <= L; ++l)
-        if constexpr (HID13) {
-          if (l - 2 < LY::NST) {
-            const f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
-            h13_flush<LY::HP>(acc2, Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, lane);
-          } else {
-            h13_flush<LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, lane);
-          }
-        }
-        else wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
-      thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
-    }
+      for (int l = 2; l <= L; ++l) {
+        f32x4 acc2[2];
+        if (l - 2 < LY::NST) { acc2[0] = stash[(l - 2) * ST_L]; acc2[1] = stash[(l - 2) * ST_L + 64]; }
+        else { acc2[0] = wacch[l - 2][0]; acc2[1] = wacch[l - 2][1]; }
+        h13_flush<LY::HP>(acc2, Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, lane, slot_lo, slot_hi);
+      }
+    };
+    const bool border = H13::role(wave) != 0;
+    flush_hidden(0, border ? 2 : 1);
     __syncthreads();
+    if (!border && wave < NW / 2) flush_hidden(1, 2);
+    __syncthreads();
+    if (!border && wave >= NW / 2) flush_hidden(1, 2);
+    __syncthreads();
+    for (int w = 0; w < NW; ++w) {                   // thin layers: all eight waves hold partial sums
+      if (wave == w) {
+        if (thin_in) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
+        else wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
+        thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int w = 0; w < NW; ++w) {
+      if (wave == w) {
+        if (thin_in) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
+        else wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
+#pragma unroll
+        for (int l = 2; l <= L; ++l)
+          wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
+        thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
+      }
+      __syncthreads();
+    }
   }
   float* out = A.partial + (long)blockIdx.x * P;
 #pragma unroll
@@ -1065,9 +1089,11 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     const int gs = (l == L + 1) ? 1 : LY::HP;
     const int brow = (l == 1) ? 4 * KS0 : LY::HP;
     const float* Gl = Gacc + ((l == 1) ? 0 : (l == L + 1) ? LY::GO_OFF : LY::G1_SZ + (l - 2) * LY::GH_SZ);
-    for (int i = tid; i < (Hin + 1) * Hout; i += NTHREADS) {
-      const int r = i / Hout, cc = i % Hout;
-      out[net.woff[l] + i] = Gl[(r < Hin ? r : brow) * gs + cc];
+    // 64 consecutive threads write one row of the [Hin+1, Hout] block (coalesced, no integer division)
+    const int cc = tid & 63;
+    if (cc < Hout) {
+      for (int r = tid >> 6; r <= Hin; r += NTHREADS / 64)
+        out[net.woff[l] + r * Hout + cc] = Gl[(r < Hin ? r : brow) * gs + cc];
     }
   }
   float v0 = loss_var, v1 = loss_bc, v2 = loss_ic;
