@@ -1,15 +1,25 @@
 // Fused gfx950 kernel, 8-wave geometry: the same algorithm as vn_fused.hip (forward with one
-// tangent, weak-form epilogue, full reverse pass in one persistent launch) laid out for
-// TWO waves per SIMD so that one wave's VALU / LDS / barrier phases run under the other wave's
-// MFMAs.  (Measured on gfx950: a wave's own f32 MFMAs and its VALU work do not overlap -- kernel
-// time with one wave per SIMD is the SUM of MFMA cycles and all other issue cycles.)
+// tangent, weak-form epilogue, full reverse pass in one persistent launch), two waves per SIMD.
+//
+// Cost model that shaped it (measured, tools/micro/*.hip): on gfx950 the f32 MFMA and the
+// f32 VALU share one datapath -- kernel time ~ sum of MFMA cycles + sum of vector-instruction issue
+// cycles + exposed waits, whatever the interleaving; a second wave per SIMD only hides latencies.  So the
+// kernel minimises matrix cycles (padding), vector instructions and barrier phases, not "overlap".
 //
 // Geometry: workgroup = 8 waves (512 threads), 128-point tiles, 16 points per wave,
 // v_mfma_f32_16x16x4_f32.  Feature f lives in k-step ks = f/4, lane group g = f%4 (lane = 16g+c,
-// c = point), accumulator row pos(ks,g) = 16(ks>>2) + 4g + (ks&3).  Everything else (register
-// chaining of layers, LDS weight images with stride 65, cooperative LDS-transposed weight
-// gradients with persistent accumulators, fixed summation order) is as documented in vn_fused.hip.
-// Register budget: <= 256 VGPR+AGPR per wave (stored activations 2*KS*L = 130 at 5x50).
+// c = point), accumulator row ("position") pos(ks,g) = 16(ks>>2) + 4g + (ks&3).  Layers are chained in
+// registers (the accumulator tile of layer l is the B operand of layer l+1); weights sit in LDS images
+// with row stride 65.
+//   * H = 50 (KS = 13): rows 48, 49 of every GEMM are accumulated on the VALU instead of a 4th MFMA tile.
+//   * Weight gradients: operands are transposed through LDS images; 50-wide hidden layers use lane-major
+//     images written with ds_write_addtid_b32, 3x3 core tiles + two v_mfma_f32_4x4x1 border jobs (H13);
+//     output and (d_in <= 3) input layer are contracted per wave with 4x4x1 MFMAs, no workgroup barrier;
+//     other shapes use the generic cooperative tiles (wgrad_layer).
+//   * Accumulators persist across tiles in registers, those of up to three hidden layers in an LDS stash
+//     (registers are short while the forward pass stores 2*KS*L activation values; scratch spills would go
+//     through L2 to HBM).  Fixed summation order everywhere: results are bitwise reproducible.
+// Register budget: 256 VGPRs per wave (stored activations 2*KS*L = 130 at 5x50; 18 spilled at 5x50).
 #include "vn_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
