@@ -1,3 +1,5 @@
+"""Diagnostic (not collected by pytest): per-layer gradient errors of the AUTO kernel against the oracle.
+   python tests/diag_fused.py [1]   -- lives under tests/ because only tests may use oracle/."""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from tests.test_engine_gpu import synth, make_engine, oracle_eval
