@@ -3,7 +3,28 @@ generic kernels: random depth, widths (uniform and ragged), d_in, dim, integNum,
 per-row tables, sizes from one tile to several tiles per workgroup.   python tools/fuzz_parity.py [cases] [seed]"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
-from tests.test_engine_gpu import synth, make_engine
+from varnet_amd.engine import VNEngine
+
+
+def synth(seed, d_in, dim, widths, integNum, n_k, nB, bDof, source=False, integW=False, detJvec=False):
+    rng = np.random.default_rng(seed)
+    n = n_k * integNum
+    d = dict(Input=rng.uniform(-1, 1, (n, d_in)).astype(np.float32), gcoef=rng.standard_normal((n, dim)).astype(np.float32),
+             source=rng.standard_normal((n, 1)).astype(np.float32) if source else None,
+             N1=rng.uniform(0, 1, integNum).astype(np.float32), dNt1=rng.standard_normal(integNum).astype(np.float32),
+             integW=rng.uniform(0.5, 1.0, (1, integNum)).astype(np.float32) if integW else None,
+             detJ=(rng.uniform(0.1, 0.2, (n_k, 1)).astype(np.float32) if detJvec else np.float32(0.137)),
+             biInput=rng.uniform(-1, 1, (nB, d_in)).astype(np.float32), biLabel=rng.standard_normal((nB, 1)).astype(np.float32),
+             w=np.array([3.0, 2.0, 5.0]))
+    d['N'] = np.tile(d['N1'], n_k).reshape(n, 1)
+    d['dNt'] = np.tile(d['dNt1'], n_k).reshape(n, 1)
+    return d
+
+
+def make_engine(d_in, dim, widths, integNum, source, integW, kernel=0):
+    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel)
+
+
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = 0.0
