@@ -1127,9 +1127,15 @@ template <int L, int KS>
 hipError_t launch_one(const VnFusedArgsD& a, int grid, hipStream_t s) {
   using LY = Lay<L, KS>;
   const size_t bytes = (size_t)LY::TOTAL * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)vn_fused16_kernel<L, KS>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return e;
+  static int attr_dev = -1;                      // the attribute is per device and sticky: set it once
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (attr_dev != dev) {
+    hipError_t e = hipFuncSetAttribute((const void*)vn_fused16_kernel<L, KS>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    attr_dev = dev;
+  }
   hipLaunchKernelGGL((vn_fused16_kernel<L, KS>), dim3(grid), dim3(NTHREADS), bytes, s, a);
   return hipGetLastError();
 }
