@@ -85,6 +85,7 @@ struct vn_engine {
   int64_t step = 0;
   bool use_fused = false;
   bool use_fused16 = false;
+  VnOptArgs fuse;                    // optimizer step to fold into the next gradient reduction (kind -1: none)
   bool two_pass = false;             // fused kernel twice around the row-wise seed kernel (integ_num > 128)
   float* tp_losspart = nullptr; long tp_losspart_cap = 0;
   float* fused_losspart = nullptr;   // [ncu*3]
@@ -244,7 +245,7 @@ int run_twopass(vn_engine* h, const Batch& b, float* gradbuf) {
   }
   HIPCHK(vn_fused16_launch(f, grid, h->stream));
   if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
-  HIPCHK(vn_reduce_launch(h->partial, grid, P, lp, grid + sgrid, h->bDof, h->nB, f.w0, f.w1, f.w2, gradbuf, h->stream));
+  HIPCHK(vn_reduce_launch(h->partial, grid, P, lp, grid + sgrid, h->bDof, h->nB, f.w0, f.w1, f.w2, gradbuf, h->stream, h->fuse));
   return VN_OK;
 }
 
@@ -302,7 +303,7 @@ int run_dedup(vn_engine* h, const Batch& b, bool with_grad, float* lossVec, floa
     if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
   }
   HIPCHK(vn_reduce_launch(h->dd_partial, dim * grid, P, lp, dim * grid + sblk, h->bDof, h->nB, f.w0, f.w1, f.w2,
-                          gradbuf, h->stream));
+                          gradbuf, h->stream, h->fuse));
   return VN_OK;
 }
 
@@ -639,7 +640,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
     else HIPCHK(vn_fused_launch(a, grid, h->stream));
     if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
     HIPCHK(vn_reduce_launch(h->partial, grid, h->net.P, h->fused_losspart, grid, h->bDof, h->nB, a.w0, a.w1, a.w2,
-                            h->gradbuf, h->stream));
+                            h->gradbuf, h->stream, h->fuse));
     return VN_OK;
   }
   if (int rc = run_forward_and_seed(h, b, true, nullptr, nullptr)) return rc;
@@ -657,7 +658,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
   const long nthreads = b.n_k > h->nB ? b.n_k : h->nB;
   const int lgrid = (int)((nthreads + 255) / 256);
   HIPCHK(vn_reduce_launch(h->partial, h->bwd_grid, h->net.P, h->losspart, lgrid, h->bDof, h->nB, (float)h->w[0],
-                          (float)h->w[1], (float)h->w[2], h->gradbuf, h->stream));
+                          (float)h->w[1], (float)h->w[2], h->gradbuf, h->stream, h->fuse));
   return VN_OK;
 }
 
@@ -681,20 +682,38 @@ int vn_apply(vn_engine* h) {
   return apply_impl(h, nullptr);
 }
 
+// gradient + optimizer step with the update folded into the gradient reduction (no collective in between)
+static int step_fused(vn_engine* h, int32_t batch, float* loss_acc) {
+  h->step += 1;
+  VnOptArgs o;
+  o.kind = h->cfg.optimizer; o.theta = h->theta; o.m = h->m; o.v = h->v; o.loss_acc = loss_acc;
+  if (h->cfg.optimizer == VN_OPT_RMSPROP) {
+    o.lr = (float)h->cfg.lr; o.b1 = 0.9f; o.b2 = 0.0f; o.eps = 1e-10f;          // decay, momentum, epsilon
+  } else {
+    const double t = (double)h->step;
+    o.lr = (float)(h->cfg.lr * std::sqrt(1.0 - std::pow(h->cfg.beta2, t)) / (1.0 - std::pow(h->cfg.beta1, t)));
+    o.b1 = (float)h->cfg.beta1; o.b2 = (float)h->cfg.beta2; o.eps = (float)h->cfg.eps;
+  }
+  h->fuse = o;
+  const int rc = vn_grad(h, batch);
+  h->fuse = VnOptArgs();
+  if (rc) h->step -= 1;
+  return rc;
+}
+
 int vn_train_epoch(vn_engine* h, const int32_t* batches, int32_t n, float* loss_acc_dev) {
   if (!h || (n > 0 && !batches)) return fail(VN_EINVAL, "null argument");
-  for (int32_t i = 0; i < n; ++i) {
-    if (int rc = vn_grad(h, batches[i])) return rc;
-    if (int rc = apply_impl(h, loss_acc_dev)) return rc;
-  }
+  for (int32_t i = 0; i < n; ++i)
+    if (int rc = step_fused(h, batches[i], loss_acc_dev)) return rc;
   return VN_OK;
 }
 
 int vn_train_step(vn_engine* h, int32_t batch, float* loss_out_dev) {
-  if (int rc = vn_grad(h, batch)) return rc;
+  if (!h) return fail(VN_EINVAL, "null handle");
+  if (int rc = step_fused(h, batch, nullptr)) return rc;
   if (loss_out_dev)
     HIPCHK(hipMemcpyAsync(loss_out_dev, h->gradbuf + h->net.P, sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  return vn_apply(h);
+  return VN_OK;
 }
 
 int vn_eval_loss(vn_engine* h, int32_t batch, double out[4], float* lossVec_dev) {

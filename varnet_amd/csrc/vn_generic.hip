@@ -384,7 +384,7 @@ constexpr int RED_GROUPS = 16;
 __global__ __launch_bounds__(64 * RED_GROUPS) void vn_reduce_kernel(const float* __restrict__ partial, int nparts,
                                                                   int P, const float* __restrict__ losspart,
                                                                   int nlp, long bDof, long nB, float w0, float w1,
-                                                                  float w2, float* __restrict__ gradbuf) {
+                                                                  float w2, float* __restrict__ gradbuf, VnOptArgs opt) {
   __shared__ float sub[RED_GROUPS][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
@@ -399,6 +399,19 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void vn_reduce_kernel(const float*
 #pragma unroll
     for (int j = 1; j < RED_GROUPS; ++j) t += sub[j][lane];
     gradbuf[p] = t;
+    if (opt.kind == VN_OPT_ADAM) {                   // same arithmetic as vn_adam_kernel
+      const float mi = opt.b1 * opt.m[p] + (1.f - opt.b1) * t;
+      const float vi = opt.b2 * opt.v[p] + (1.f - opt.b2) * t * t;
+      opt.m[p] = mi;
+      opt.v[p] = vi;
+      opt.theta[p] = opt.theta[p] - opt.lr * mi / (sqrtf(vi) + opt.eps);
+    } else if (opt.kind == VN_OPT_RMSPROP) {         // same arithmetic as vn_rmsprop_kernel
+      const float msi = opt.v[p] + (t * t - opt.v[p]) * (1.f - opt.b1);
+      const float mi = opt.b2 * opt.m[p] + opt.lr * t / sqrtf(msi + opt.eps);
+      opt.v[p] = msi;
+      opt.m[p] = mi;
+      opt.theta[p] = opt.theta[p] - mi;
+    }
   }
   // loss scalars: wave 1 of block 0 folds the per-workgroup partials (lane-strided, then a fixed
   // shuffle tree, in fp64)
@@ -419,7 +432,9 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void vn_reduce_kernel(const float*
       const double var = t0;
       const double bc = bDof > 0 ? t1 / (double)bDof : 0.0;               // reduce_mean, TFModel.py:645
       const double ic = (nB - bDof) > 0 ? t2 / (double)(nB - bDof) : 0.0; // TFModel.py:648
-      gradbuf[P + 0] = (float)(w0 * bc + w1 * ic + w2 * var);             // TFModel.py:666
+      const float loss = (float)(w0 * bc + w1 * ic + w2 * var);           // TFModel.py:666
+      gradbuf[P + 0] = loss;
+      if (opt.loss_acc) opt.loss_acc[0] += loss;
       gradbuf[P + 1] = (float)bc;
       gradbuf[P + 2] = (float)ic;
       gradbuf[P + 3] = (float)var;
@@ -508,10 +523,11 @@ hipError_t vn_seed_launch(const VnSeedArgs& a, int grid, hipStream_t s) {
 }
 
 hipError_t vn_reduce_launch(const float* partial, int nparts, int P, const float* losspart, int nlossparts,
-                            long bDof, long nB, float w0, float w1, float w2, float* gradbuf, hipStream_t s) {
+                            long bDof, long nB, float w0, float w1, float w2, float* gradbuf, hipStream_t s,
+                            VnOptArgs opt) {
   const int grid = (P + 63) / 64;
   hipLaunchKernelGGL(vn_reduce_kernel, dim3(grid > 0 ? grid : 1), dim3(64 * RED_GROUPS), 0, s, partial, nparts, P,
-                     losspart, nlossparts, bDof, nB, w0, w1, w2, gradbuf);
+                     losspart, nlossparts, bDof, nB, w0, w1, w2, gradbuf, opt);
   return hipGetLastError();
 }
 

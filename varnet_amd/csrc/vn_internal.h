@@ -51,10 +51,18 @@ hipError_t vn_generic_forward(const VnNet& net, const float* theta, VnRows seg0,
 hipError_t vn_generic_backward(const VnNet& net, const float* theta, VnRows seg0, VnRows seg1,
                                float* partial, int grid, hipStream_t s);
 hipError_t vn_seed_launch(const VnSeedArgs& a, int grid, hipStream_t s);
+// Optional optimizer step fused into the reduction (one launch less per training step when no collective
+// sits between gradient and update): kind -1 = none, VN_OPT_ADAM (lr = lr_t), VN_OPT_RMSPROP.
+struct VnOptArgs {
+  int kind = -1;
+  float* theta = nullptr; float* m = nullptr; float* v = nullptr;
+  float lr = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f;
+  float* loss_acc = nullptr;          // += loss (device scalar) or nullptr
+};
 // grad[p] = sum_g partial[g*P+p]; tail[0..3] = loss, BC, IC, var from the seed partials.
 hipError_t vn_reduce_launch(const float* partial, int nparts, int P, const float* losspart,
                             int nlossparts, long bDof, long nB, float w0, float w1, float w2,
-                            float* gradbuf, hipStream_t s);
+                            float* gradbuf, hipStream_t s, VnOptArgs opt = VnOptArgs());
 hipError_t vn_adam_launch(float* theta, float* m, float* v, const float* grad, int P, float lr_t,
                           float b1, float b2, float eps, float* loss_acc, hipStream_t s);
 hipError_t vn_rmsprop_launch(float* theta, float* mom, float* ms, const float* grad, int P, float lr, float rho,
