@@ -1080,15 +1080,23 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       __syncthreads();
     }
   } else {
-    for (int w = 0; w < NW; ++w) {
-      if (wave == w) {
-        if (thin_in) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
-        else wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
+    // generic tiles: waves with the same point-split index own distinct tiles, so round r serves all waves
+    // of split r at once (one round when a layer has >= 8 tiles); the thin layers need all eight rounds
+    using W1 = WG<KS0, KS>;
+    const int s1 = (W1::NT >= NW) ? 0 : wave / W1::NT;
+    const int sh = (WHG::NT >= NW) ? 0 : wave / WHG::NT;
+    for (int r = 0; r < NW; ++r) {
+      if (thin_in) {
+        if (wave == r) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
+      } else if (s1 == r) {
+        wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
+      }
+      if (sh == r) {
 #pragma unroll
         for (int l = 2; l <= L; ++l)
           wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
-        thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
       }
+      if (wave == r) thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
       __syncthreads();
     }
   }
