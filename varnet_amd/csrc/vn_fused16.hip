@@ -641,20 +641,42 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 
   // ------------------------------------------------------------------ prologue: LDS images
   {
+    // every thread first issues ALL its parameter loads (L2 latency ~1 us each if taken one by one), then
+    // scatters them into the images
     const int d_in = net.d_in, H1 = net.H[1];
-    for (int i = tid; i < 8 * WS; i += NTHREADS) {
+    constexpr int N1IT = (8 * WS + NTHREADS - 1) / NTHREADS;
+    constexpr int NHIT = (LY::HP * WS + NTHREADS - 1) / NTHREADS;
+    float v1[N1IT], vh[L > 1 ? L - 1 : 1][NHIT];
+#pragma unroll
+    for (int it = 0; it < N1IT; ++it) {
+      const int i = tid + it * NTHREADS;
       const int k = i / WS, pos = i % WS;
       const int f = vfeat(pos & 63);
-      W1[i] = (k < d_in && pos < 64 && f < H1) ? A.theta[net.woff[1] + k * H1 + f] : 0.f;
+      v1[it] = (i < 8 * WS && k < d_in && pos < 64 && f < H1) ? A.theta[net.woff[1] + k * H1 + f] : 0.f;
     }
 #pragma unroll
     for (int l = 2; l <= L; ++l) {
       const int Hin = net.H[l - 1], Hout = net.H[l];
-      float* Wl = WH + (l - 2) * LY::HPWS;
-      for (int i = tid; i < LY::HP * WS; i += NTHREADS) {
+#pragma unroll
+      for (int it = 0; it < NHIT; ++it) {
+        const int i = tid + it * NTHREADS;
         const int k = i / WS, pos = i % WS;
         const int f = vfeat(pos & 63);
-        Wl[i] = (k < Hin && pos < 64 && f < Hout) ? A.theta[net.woff[l] + k * Hout + f] : 0.f;
+        vh[l - 2][it] = (i < LY::HP * WS && k < Hin && pos < 64 && f < Hout) ? A.theta[net.woff[l] + k * Hout + f] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < N1IT; ++it) {
+      const int i = tid + it * NTHREADS;
+      if (i < 8 * WS) W1[i] = v1[it];
+    }
+#pragma unroll
+    for (int l = 2; l <= L; ++l) {
+      float* Wl = WH + (l - 2) * LY::HPWS;
+#pragma unroll
+      for (int it = 0; it < NHIT; ++it) {
+        const int i = tid + it * NTHREADS;
+        if (i < LY::HP * WS) Wl[i] = vh[l - 2][it];
       }
     }
     for (int i = tid; i < L * 64; i += NTHREADS) {
