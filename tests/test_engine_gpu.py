@@ -82,8 +82,7 @@ def _skip_unsupported(kernel, widths, integNum):
                         len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused32 not instantiated for this shape')
     if kernel == 3 and (max(widths) > 50 or len(widths) < 2 or          # integNum > 128: two-pass fused route
-                       
-                        (max(widths) > 32 and len(widths) < 3) or len(widths) > (5 if max(widths) > 32 else 4)):
+                        len(widths) > (5 if max(widths) > 32 else 6)):
         pytest.skip('fused16 not instantiated for this shape')
 
 

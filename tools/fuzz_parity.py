@@ -29,7 +29,7 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = 0.0
 for case in range(ncases):
-    L = int(rng.integers(1, 6))
+    L = int(rng.integers(1, 7))
     if rng.random() < 0.5:
         widths = [int(rng.choice([7, 10, 20, 30, 32, 33, 40, 48, 49, 50]))] * L
     else:

@@ -1185,9 +1185,9 @@ int pick_ks(int hmax) {
 }  // namespace
 
 #define VN_FUSED16_CASES(X) \
-  X(2, 5) X(3, 5) X(4, 5)   \
-  X(2, 8) X(3, 8) X(4, 8)   \
-  X(3, 13) X(4, 13) X(5, 13)
+  X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(6, 5)   \
+  X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8)   \
+  X(2, 13) X(3, 13) X(4, 13) X(5, 13)
 
 size_t vn_fused16_lds_bytes(const VnNet& net) {
   const int ks = pick_ks(net.hmax);
