@@ -36,7 +36,7 @@ for case in range(ncases):
         widths = [int(rng.integers(1, 51)) for _ in range(L)]
     dim = int(rng.integers(1, 4)); td = True
     d_in = dim + 1 + int(rng.integers(0, 2))
-    q = int(rng.choice([4, 8, 16, 27, 32, 36, 64, 128, 216]))
+    q = int(rng.choice([4, 8, 16, 27, 32, 36, 64, 128, 216, 256, 1296]))     # 256: 3D+t 2-point, 1296: 3D+t 3-point Gauss
     big = rng.random() < 0.25
     n_k = int(rng.integers(1, 40)) if not big else int(rng.integers(300, 2500) * 128 // q + 1)
     nB = int(rng.integers(2, 300)); bDof = int(rng.integers(1, nB))
