@@ -3,6 +3,7 @@
 bench.py -- training-points/sec of the VarNet variational-loss step on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--no-cpu-baseline]
+        (N > 1: starts its own N ranks, one per GPU, before anything touches the GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -51,47 +52,117 @@ def build_problem(cfg):
     return vn, name
 
 
-def cpu_baseline(vn, tdata, budget_s=20.0):
-    """The oracle (fp32 PyTorch-CPU autograd restatement of the reference graph) timed on this
-    host's cores on a bounded sample of the same workload: the first n_s test functions."""
+def host_cores():
+    """(physical cores lscpu reports, cores this job may actually use).  A one-GPU box exposes every core of
+    the host but grants a share (cgroup cpu.max / affinity); threads beyond the share only thrash."""
+    import subprocess
+    phys = None
+    try:
+        out = subprocess.run(['lscpu', '-p=core,socket'], capture_output=True, text=True, timeout=10).stdout
+        phys = len({ln for ln in out.splitlines() if ln and not ln.startswith('#')}) or None
+    except Exception:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    for f in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(f).read().split()
+            if f.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    usable = min(usable, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    usable = min(usable, max(1, q // int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())))
+            break
+        except Exception:
+            continue
+    if phys is None:
+        phys = usable
+    return phys, usable
+
+
+def cpu_baseline(vn, tdata, budget_s=25.0):
+    """
+    The oracle (fp32 PyTorch-CPU autograd restatement of the reference graph + TF-1 Adam, oracle/tf1_graph.py)
+    timed on this host's cores on a bounded sample of the same workload -- the first n_s test functions and
+    all BC/IC points -- as a TRAINING run from the bench's theta_0: >= 20 timed steps after 5 warm-up steps
+    at the full thread count, 2 timed steps at one thread.  The HIP engine then trains on exactly that sample
+    from the same theta_0 and the per-step loss trajectories are compared.
+    """
     import torch
     from oracle import tf1_graph as og
-    fd = vn.fixData
+    fd, eng = vn.fixData, vn.engine
     q = fd.integNum
     d = tdata.mor[0]
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    # a one-GPU box exposes every host core but grants a share of 16 (more threads only thrash)
-    cores = int(os.environ.get('VN_CPU_THREADS', min(cores, 16)))
-    torch.set_num_threads(cores)
-    flat = vn.engine.get_params()
+    phys, usable = host_cores()
+    # a one-GPU box grants a share of 16 host cores whatever the affinity mask says
+    cores = int(os.environ.get('VN_CPU_THREADS', min(phys, usable, 16)))
+    n_s = min(int(os.environ.get('VN_CPU_SAMPLE', 2000)), fd.nt)
+    rows = n_s * q
+    nB = d['biInput'].shape[0]
     w = np.array([1.0, 1.0, 1.0])
+    kw = dict(Input=d['Input'][:rows].cpu().numpy(), gcoef=d['gcoef'][:rows].cpu().numpy(),
+              source=None if d['source'] is None else d['source'][:rows].cpu().numpy().reshape(rows, 1),
+              N=np.tile(fd.N, n_s).reshape(rows, 1).astype(np.float32),
+              dNt=np.tile(fd.dNt, n_s).reshape(rows, 1).astype(np.float32), integW=None,
+              intShape=[n_s, q], detJ=float(fd.detJ), detJvec=False,
+              biInput=d['biInput'].cpu().numpy(), biLabel=d['biLabel'].cpu().numpy().reshape(-1, 1),
+              bDof=fd.bDofsum, biDimVal=float(fd.biDimVal), w=w, dim=vn.dim, time_dependent=vn.PDE.timeDependent,
+              is_source=vn.lossOpt['isSource'], integWflag=False)
+    eng.init_params(seed=0)
+    theta0 = eng.get_params()
 
-    def step(n_s):
-        rows = n_s * q
-        kw = dict(Input=d['Input'][:rows].cpu().numpy(), gcoef=d['gcoef'][:rows].cpu().numpy(), source=None,
-                  N=np.tile(fd.N, n_s).reshape(rows, 1).astype(np.float32),
-                  dNt=np.tile(fd.dNt, n_s).reshape(rows, 1).astype(np.float32), integW=None,
-                  intShape=[n_s, q], detJ=float(fd.detJ), detJvec=False,
-                  biInput=d['biInput'].cpu().numpy(), biLabel=d['biLabel'].cpu().numpy().reshape(-1, 1),
-                  bDof=fd.bDofsum, biDimVal=float(fd.biDimVal), w=w, dim=vn.dim, time_dependent=True,
-                  is_source=False, integWflag=False)
-        t0 = time.perf_counter()
-        og.loss_and_grad(flat, vn.inpDim, vn.layerWidth, torch.float32, **kw)
-        return time.perf_counter() - t0
+    def run(nsteps, threads):
+        torch.set_num_threads(threads)
+        theta = theta0.copy()
+        adam = og.TF1Adam(theta.size, lr=vn.learning_rate, dtype=np.float32)
+        losses, times = [], []
+        for _ in range(nsteps):
+            t0 = time.perf_counter()
+            res, g = og.loss_and_grad(theta, vn.inpDim, vn.layerWidth, torch.float32, **kw)
+            theta = adam.step(theta, g)
+            times.append(time.perf_counter() - t0)
+            losses.append(res['loss'])
+        return np.array(losses), np.array(times)
 
-    n_s = min(10000, fd.nt)
-    step(n_s)                                   # warm-up
-    t1 = step(n_s)
-    reps = max(1, min(8, int(budget_s / max(t1, 1e-3))))
-    ts = [step(n_s) for _ in range(reps)]
-    dt = float(np.median(ts))
-    return {"value": n_s * q / dt, "unit": "training-points/s", "cores": cores, "kind": "port",
-            "sample": "%d of %d test functions (%d points) + all %d BC/IC points per step, %d timed steps, "
-                      "fp32 PyTorch-CPU autograd restatement of TFModel.py:515-714 (oracle/tf1_graph.py)"
-                      % (n_s, fd.nt, n_s * q, d['biInput'].shape[0], reps)}
+    warm = 5
+    _, t_w = run(2, cores)                                     # page-in + thread pool start
+    per = float(np.min(t_w))
+    n_timed = int(max(20, min(60, budget_s / max(per, 1e-3) - warm)))
+    if per * (20 + warm) > 3 * budget_s:                       # very slow host: keep the run bounded, say so
+        n_timed = max(3, int(budget_s / per))
+    losses, times = run(warm + n_timed, cores)
+    dt = float(np.mean(times[warm:]))
+    _, t1 = run(3, 1)
+    dt1 = float(np.mean(t1[1:]))
+
+    # the same training run on the HIP engine: same sample, same theta_0, same optimizer
+    eng.set_interior(1, d['Input'][:rows], d['gcoef'][:rows], None if d['source'] is None else d['source'][:rows],
+                     n_k=n_s, detJ=float(fd.detJ))
+    eng.set_weights(w)
+    eng.init_params(seed=0)
+    lg = torch.zeros(1, dtype=torch.float32, device=eng.device)
+    gl = []
+    for _ in range(warm + n_timed):
+        eng.train_step(1, lg)
+        gl.append(float(lg.item()))
+    gl = np.array(gl)
+    dev = np.abs(gl - losses) / np.abs(losses)
+    return {"value": rows / dt, "unit": "training-points/s", "cores": cores, "kind": "port",
+            "value_1_thread": rows / dt1,
+            "physical_cores_lscpu": phys, "cores_usable_by_this_job": usable,
+            "timed_steps": n_timed, "warmup_steps": warm, "ms_per_step": dt * 1e3,
+            "loss_traj_max_rel_dev": float(dev.max()), "loss_traj_rel_dev_last": float(dev[-1]),
+            "loss_first_last_cpu": [float(losses[0]), float(losses[-1])],
+            "loss_first_last_gpu": [float(gl[0]), float(gl[-1])],
+            "sample": "%d of %d test functions (%d points) + all %d BC/IC points per step, %d timed Adam steps after %d "
+                      "warm-up at %d threads (host has %d physical cores, this job may use %d), 2 timed steps at 1 "
+                      "thread; fp32 PyTorch-CPU autograd restatement of TFModel.py:515-714 + TF-1 Adam "
+                      "(oracle/tf1_graph.py); loss_traj_*: HIP engine vs this CPU run, same sample, same theta_0"
+                      % (n_s, fd.nt, rows, nB, n_timed, warm, cores, phys, usable)}
 
 
 def main():
@@ -104,29 +175,37 @@ def main():
     ap.add_argument('--no-dedup', action='store_true', help='skip the extra de-duplicated-formulation timing')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, as fresh children, BEFORE anything in this
+        # process touches the GPU (this parent never imports torch); rank 0 prints the JSON line.
+        from varnet_amd.launch import spawn_ranks
+        raise SystemExit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)          # several ranks may share a GPU only in the gloo rehearsal below
+    # backend 'nccl' IS RCCL on ROCm; VN_DIST_BACKEND=gloo rehearses the N>1 path with ranks sharing a GPU
+    backend = os.environ.get('VN_DIST_BACKEND', 'nccl')
+    if world > 1 and backend == 'nccl' and ndev < world:
+        raise SystemExit('--gpus %d needs %d GPUs, %d visible (VN_DIST_BACKEND=gloo rehearses the N>1 path on fewer)'
+                         % (world, world, ndev))
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     os.environ['LOCAL_RANK'] = str(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # backend 'nccl' IS RCCL on ROCm; VN_DIST_BACKEND=gloo rehearses the N>1 path on one GPU
-        backend = os.environ.get('VN_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    vn, wname = build_problem(args.config)
+    vn, wname = build_problem(args.config)        # joins the engine's RCCL communicator when world > 1
     fd, eng = vn.fixData, vn.engine
     tdata = vn._build_tdata()                     # shards by rank when world > 1
     tdata.select_mor(0)
@@ -139,12 +218,20 @@ def main():
     rows_local = (n1 - n0) * fd.integNum
     nB = tdata.mor[0]['biInput'].shape[0]
     nT_total = fd.nT
+    in_engine = world == 1 or vn.comm == 'rccl'
+    ar_ev = []
 
     def step():
-        eng.grad(0)
-        if world > 1:
+        if in_engine:
+            eng.train_epoch([0], None)            # gradient (+ RCCL SUM) + TF-1 Adam: one host call, one stream
+        else:
+            eng.grad(0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             dist.all_reduce(gb)
-        eng.apply()
+            e1.record()
+            ar_ev.append((e0, e1))
+            eng.apply()
 
     for _ in range(args.warmup):
         step()
@@ -152,6 +239,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ar_ev.clear()
     eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -161,12 +249,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    comm_ms = None
+    if world > 1:
+        comm_ms = eng.profile_comm()[0] if in_engine else float(np.mean([a.elapsed_time(b) for a, b in ar_ev]))
     kms, klaunches, kname = eng.profile_end()
     loss_after = float(gb[P].item())
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "rows": int(rows_local), "kernel_ms": kms, "allreduce_ms": comm_ms})
+        n_ranks = eng.comm_size()[0] if vn.comm == 'rccl' else dist.get_world_size()
+    else:
+        n_ranks = 1
 
     # ---- extra, separately reported: de-duplicated formulation (one network evaluation per unique
     # quadrature point; SURVEY.md 8d "honest accounting").  Never mixed into `value`.
@@ -177,37 +274,24 @@ def main():
             for _ in range(args.warmup):
                 step()
             torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 step()
             torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
             dtd = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([dtd, float(U_local)], dtype=torch.float64, device='cuda')
-                tm = t.clone()
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                dtd, U_tot = float(tm[0].item()), int(t[1].item())
-            else:
-                U_tot = int(U_local)
-            dd = (dtd, U_tot, float(gb[P].item()))
+            dd = (dtd, int(U_local), float(gb[P].item()))
 
     if rank == 0:
         F_pt = 2 * (vn.inpDim * vn.layerWidth[0] + sum(a * b for a, b in zip(vn.layerWidth[:-1], vn.layerWidth[1:]))
                     + vn.layerWidth[-1])
-        flop_launch = 6.0 * F_pt * rows_local + 3.0 * F_pt * nB
+        flop_of = lambda rows: 6.0 * F_pt * rows + 3.0 * F_pt * nB
+        flop_launch = flop_of(rows_local)
         achieved = flop_launch / (kms * 1e-3) / 1e12 if kms > 0 else None
         # HBM bytes per launch come from the separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the
         # gfx950 correction, WRITE_SIZE as is) committed under profiles/; only quoted for the exact
         # workload and kernel they were collected on.
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if args.config == 3 and world == 1 and kname.startswith('vn_fused') and os.path.exists(tfile):
             traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
         out = {
@@ -215,7 +299,7 @@ def main():
             else "training-points/sec (test-funcs x quad-pts), 1D+t AD-PDE",
             "value": nT_total * args.steps / dt,
             "unit": "training-points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": int(n_ranks), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
@@ -232,8 +316,22 @@ def main():
                          "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
                          "kernel": kname, "kernel_ms": kms, "launches_timed": klaunches,
                          "algorithmic_flop_per_launch": flop_launch,
-                         "note": "6*F_pt per interior point + 3*F_pt per BC/IC point, F_pt=%d; HIP events on the engine stream" % F_pt},
+                         "note": "rank 0's launch: 6*F_pt per interior point + 3*F_pt per BC/IC point, F_pt=%d; "
+                                 "HIP events on the engine stream" % F_pt},
         }
+        if world > 1:
+            out["comm"] = {
+                "backend": ("RCCL communicator inside the engine (vn_comm_init / vn_allreduce_grad)" if vn.comm == 'rccl'
+                            else "torch.distributed " + dist.get_backend()),
+                "ranks_reported": int(n_ranks), "payload_bytes": (P + 4) * 4,
+                "allreduce_ms": comm_ms,
+                "note": "HIP events around the collective on the engine stream (includes waiting for the slowest rank)"}
+            for r in per_rank:
+                fl = flop_of(r["rows"])
+                r["roofline_frac"] = (fl / (r["kernel_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if r["kernel_ms"] else None
+            out["per_rank"] = per_rank
+            if backend != 'nccl':
+                out["rehearsal"] = "ranks share %d GPU(s) over %s: a plumbing check, not a scaling number" % (ndev, backend)
         if dd is not None:
             dtd, U_tot, loss_dd = dd
             # formulation actually run: per unique point dim forward passes (2 F_pt) + dim reverse passes (6 F_pt)
@@ -249,9 +347,11 @@ def main():
                         "(tests/test_engine_gpu.py::test_dedup_formulation_parity)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vn, tdata)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if vn.comm == 'rccl':
+            eng.comm_destroy()
         dist.destroy_process_group()
 
 

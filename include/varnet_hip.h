@@ -40,7 +40,8 @@ enum {
   VN_EHIP = 2,     /* a HIP runtime call failed                                */
   VN_ESTATE = 3,   /* call order violated (e.g. step before data registered)   */
   VN_ENOMEM = 4,
-  VN_EUNSUPPORTED = 5
+  VN_EUNSUPPORTED = 5,
+  VN_ECOMM = 6     /* an RCCL call failed                                      */
 };
 
 enum { VN_ACT_SIGMOID = 0 };
@@ -101,7 +102,9 @@ int vn_set_fe_table(vn_engine* h, const float* N, const float* dNt, const float*
  * [n_k*integ_num, dim], source [n_k*integ_num] or NULL.  detJ_dev: per-test-function
  * determinants [n_k] (the reference's detJvec=True case) or NULL to use the scalar `detJ`.
  * N_rows/dNt_rows: per-row basis arrays [n_k*integ_num] (non-uniform supports) or NULL to use
- * the table of vn_set_fe_table. */
+ * the table of vn_set_fe_table.  n_k == 0 registers an empty tower feed (the reference slices past the end
+ * of the set when batchLen*towers > nt, VarNetUtility.py:830-838): the pointers may then be NULL, only the
+ * BC/IC rows contribute and the rank still joins the gradient SUM. */
 int vn_set_interior(vn_engine* h, int32_t batch, const float* Input_dev, const float* gcoef_dev,
                     const float* source_dev, int64_t n_k, const float* detJ_dev, double detJ,
                     const float* N_rows_dev, const float* dNt_rows_dev);
@@ -159,8 +162,38 @@ int vn_residual_f64(vn_engine* h, const double* X_dev, const double* diff_dev,
                     const double* vel_dev, const double* source_dev, const double* diff_dx_dev,
                     int64_t n, double* u_dev, double* res_dev);
 
+/* ---- towers: one process per GPU, gradient SUM over RCCL --------------------------------------------
+ * Replaces TFNN.towerSetup / sum_grads (TFModel.py:253-289, 342-377): the reference builds one NNModel per
+ * device in ONE process and reduces the per-tower gradients with tf.reduce_sum on a controller device.
+ * Here every GPU has its own process and handle; the handles are joined into one RCCL communicator and the
+ * only collective per step is a SUM all-reduce of the P+4 floats of the gradient buffer
+ * (gradient | loss, BC, IC, var -- the tower loss sums of TFModel.py:315-319 ride along).
+ *   rank 0:    vn_comm_unique_id(id)            -> 128 opaque bytes (ncclUniqueId), host memory
+ *   host:      ship `id` to every rank (any side channel: MPI, a TCP store, torch.distributed ...)
+ *   all ranks: vn_comm_init(h, rank, world, id) -> collective; returns when every rank has joined
+ * With a communicator attached, vn_train_step / vn_train_epoch run gradient -> all-reduce -> optimizer on
+ * the engine stream without a host round trip; vn_grad + vn_allreduce_grad + vn_apply is the same step in
+ * three calls.  RCCL is loaded at run time (librccl.so.1 by SONAME, or $VN_RCCL_LIB); without it these four
+ * entry points return VN_EUNSUPPORTED and everything else works. */
+#define VN_COMM_ID_BYTES 128
+int vn_comm_unique_id(void* id_out_host);
+int vn_comm_init(vn_engine* h, int32_t rank, int32_t world, const void* unique_id_host);
+/* Ranks RCCL reports for the attached communicator (1 if none); rank_out may be NULL. */
+int vn_comm_size(const vn_engine* h, int32_t* world_out, int32_t* rank_out);
+int vn_comm_destroy(vn_engine* h);
+/* In-place SUM all-reduce of the gradient buffer over the communicator, on the engine stream. */
+int vn_allreduce_grad(vn_engine* h);
+
 /* Adam step counter (global_step, TFModel.py:312). */
 int vn_get_step(const vn_engine* h, int64_t* step);
+
+/* Mean duration (ms, HIP events on the engine stream) of the vn_allreduce_grad calls recorded since
+ * vn_profile_begin (call before vn_profile_end; synchronises). */
+int vn_profile_comm(vn_engine* h, double* mean_ms, int64_t* calls);
+
+/* Which kernel family VN_KERNEL_AUTO resolved to for this network (VN_KERNEL_GENERIC / _FUSED / _FUSED16);
+ * *two_pass = 1 when integ_num > 128 runs the fused kernel twice around the row-wise epilogue. */
+int vn_kernel_path(const vn_engine* h, int32_t* kernel_out, int32_t* two_pass_out);
 
 /* Name / mean duration (ms, HIP events on the engine's stream) of the dominant kernel of the
  * last `vn_profile_begin` .. `vn_profile_end` window: used by bench.py for the roofline

@@ -1,0 +1,81 @@
+"""
+Rank body shared by the multi-process tests (CPU: gloo + oracle-backed engine; GPU: the real
+VNEngine, ranks sharing one GPU over gloo or one GPU each over RCCL).  Importable by name so that
+`multiprocessing` start methods that pickle by reference (spawn / forkserver) can run it.
+"""
+import os
+
+import numpy as np
+
+
+def run_rank(rank, world, port, outdir, backend, engine, problem, train_kw, tag):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['RANK'], os.environ['WORLD_SIZE'] = str(rank), str(world)
+    import torch
+    import torch.distributed as dist
+    from tests.test_varnet_host import op1dt, op2dt
+    from varnet_amd.varnet import VarNet
+
+    torch.set_num_threads(1)
+    if engine == 'hip':
+        ndev = torch.cuda.device_count()
+        local = rank % max(ndev, 1)
+        torch.cuda.set_device(local)
+        os.environ['LOCAL_RANK'] = str(local)
+    else:
+        from tests.oracle_engine import OracleEngine
+
+        def make(self, processors):
+            fd = self.fixData
+            return OracleEngine(self.dim, self.inpDim, self.layerWidth, self.PDE.timeDependent, fd.integNum,
+                                isSource=self.lossOpt['isSource'], integWflag=self.lossOpt['integWflag'],
+                                learning_rate=self.learning_rate)
+        VarNet._make_engine = make
+    if world > 1:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', int(os.environ['LOCAL_RANK'])))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    np.random.seed(1000 + rank)            # ranks start from DIFFERENT NumPy streams: sampling must still agree
+    kind, pk = problem
+    vn = (op1dt if kind == '1dt' else op2dt)(**pk)
+    res = vn.train(os.path.join(outdir, '%s_w%d' % (tag, world)), **train_kw)
+    theta = vn.engine.theta if engine != 'hip' else vn.engine.get_params()
+    td = vn.tData
+    inp = td.mor[0]['Input']
+    inp = inp.cpu().numpy() if hasattr(inp, 'cpu') else np.asarray(inp)
+    np.savez(os.path.join(outdir, '%s_w%d_r%d.npz' % (tag, world, rank)), theta=np.asarray(theta, dtype=np.float64),
+             loss=np.array(res.lossAll), w=np.asarray(res.trainWeight), Input=inp, comm=np.array(vn.comm),
+             block=np.array(td.block(0)))
+    if world > 1:
+        dist.barrier()
+        if vn.comm == 'rccl':
+            vn.engine.comm_destroy()
+        dist.destroy_process_group()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(ctx, world, outdir, backend, engine, problem, train_kw, tag, timeout=600):
+    """Start `world` ranks from the multiprocessing context `ctx`, wait, assert they all succeeded."""
+    port = free_port()
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, outdir, backend, engine, problem, train_kw, tag))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+    bad = [p.exitcode for p in procs if p.exitcode != 0]
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    assert not bad, 'rank exit codes %s' % [p.exitcode for p in procs]

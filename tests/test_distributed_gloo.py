@@ -68,3 +68,56 @@ def test_world2_matches_world1(tmp_path, batchNum):
         # with mini-batches the (batch, tower) blocks differ between world sizes
         # (block j = bi*puNum + rank), so only the first epoch's first loss is comparable in size
         assert np.isfinite(b['loss']).all() and b['loss'][-1] < b['loss'][0] * 1.5
+
+
+# ---- cases the round-1 review asked for ------------------------------------------------------------
+import multiprocessing
+from tests import rank_worker as rw
+
+
+def _spawn_ctx():
+    return multiprocessing.get_context('spawn')
+
+
+def test_world2_with_an_empty_shard(tmp_path):
+    """nt < batchLen * world: rank 1's tower block is empty (the reference slices past the end,
+    VarNetUtility.py:830-838).  The empty rank must still join every collective, and the run must equal
+    the one-process run."""
+    out = str(tmp_path)
+    prob = ('1dt', dict(layerWidth=[6, 5], discNum=5, tDiscNum=7))            # nt = 35
+    kw = dict(weight=[10., 10., 1.], epochNum=3, saveFreq=100, verbose=False, batchLen=35)
+    rw.launch(_spawn_ctx(), 1, out, 'gloo', 'oracle', prob, kw, 'e')
+    rw.launch(_spawn_ctx(), 2, out, 'gloo', 'oracle', prob, kw, 'e')
+    a = np.load(os.path.join(out, 'e_w1_r0.npz'))
+    b0 = np.load(os.path.join(out, 'e_w2_r0.npz'))
+    b1 = np.load(os.path.join(out, 'e_w2_r1.npz'))
+    assert list(b1['block']) == [35, 35] and list(b0['block']) == [0, 35]
+    np.testing.assert_allclose(b0['loss'], a['loss'], rtol=1e-9)
+    np.testing.assert_allclose(b0['theta'], a['theta'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(b1['theta'], b0['theta'], rtol=0, atol=0)
+
+
+def test_world1_with_an_empty_minibatch(tmp_path):
+    """nt = 9, batchNum = 4 -> batchLen 3, the 4th mini-batch of a 2-tower run is empty for both towers."""
+    out = str(tmp_path)
+    prob = ('1dt', dict(layerWidth=[4], discNum=3, tDiscNum=3))               # nt = 9
+    kw = dict(weight=[10., 10., 1.], epochNum=2, saveFreq=100, verbose=False, batchNum=4)
+    rw.launch(_spawn_ctx(), 2, out, 'gloo', 'oracle', prob, kw, 'm')
+    b0 = np.load(os.path.join(out, 'm_w2_r0.npz'))
+    assert np.isfinite(b0['loss']).all()
+
+
+def test_world2_optimal_sampling_draws_one_training_set(tmp_path):
+    """smpScheme='optimal' at world 2: every rank must hold the SAME re-drawn training set (the reference
+    samples once and slices per tower) although the ranks' NumPy streams start differently."""
+    out = str(tmp_path)
+    prob = ('1dt', dict(layerWidth=[6], discNum=5, tDiscNum=6))
+    kw = dict(weight=[10., 10., 1.], smpScheme='optimal', epochNum=6, saveFreq=1, verbose=False, trainUpdelay=2,
+              tolUpd=1e9, frac=0.5)
+    rw.launch(_spawn_ctx(), 2, out, 'gloo', 'oracle', prob, kw, 'o')
+    b0 = np.load(os.path.join(out, 'o_w2_r0.npz'))
+    b1 = np.load(os.path.join(out, 'o_w2_r1.npz'))
+    assert b0['Input'].shape[0] > 5 * 6 * 16                                  # the set was re-drawn (points added)
+    np.testing.assert_array_equal(b0['Input'], b1['Input'])
+    np.testing.assert_allclose(b1['theta'], b0['theta'], rtol=0, atol=0)
+    np.testing.assert_allclose(b1['w'], b0['w'], rtol=1e-12)

@@ -1,0 +1,165 @@
+"""
+N > 1 path on the real HIP engine (the twin of tests/test_distributed_gloo.py, which runs the same
+host logic on the CPU oracle engine):
+
+  * in-engine RCCL communicator through the C ABI at world size 1 (vn_comm_unique_id / vn_comm_init /
+    vn_allreduce_grad / vn_train_epoch with a communicator) -- runs on any GPU box;
+  * two ranks sharing ONE GPU over gloo: contiguous test-function shards, BC/IC replicated with
+    weights / puNum, gradient SUM, must reproduce the one-rank trajectory to fp32 rounding -- runs on any GPU
+    box;
+  * two ranks on two GPUs over RCCL (`nccl` backend + the engine's own communicator) -- skipped unless
+    the box has >= 2 GPUs.
+Ranks are started from the fork server created in conftest.py before this process touched the GPU.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import conftest
+from tests import rank_worker as rw
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem():
+    return ('1dt', dict(layerWidth=[20, 20, 20], discNum=20, tDiscNum=30))      # 600 test functions x 16
+
+
+def _ndev():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_in_engine_rccl_world1_matches_plain_step():
+    """C ABI: a communicator of one rank.  gradient -> RCCL all-reduce -> Adam must equal the plain step."""
+    import torch
+    from tests.test_engine_gpu import synth
+    from varnet_amd.engine import VNEngine
+    d = synth(5, 3, 2, [50] * 5, 64, 40, 60, 25)
+    outs = []
+    for use_comm in (False, True):
+        eng = VNEngine(2, 3, [50] * 5, True, 64)
+        eng.init_params(seed=3)
+        eng.set_fe_table(d['N1'], d['dNt1'], None)
+        eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=40, detJ=d['detJ'])
+        eng.set_bic(d['biInput'], d['biLabel'], 25, 2.0)
+        eng.set_weights(d['w'])
+        if use_comm:
+            uid = VNEngine.comm_unique_id()
+            assert len(uid) == 128
+            eng.comm_init(0, 1, uid)
+            assert eng.comm_size() == (1, 0)
+            with pytest.raises(Exception):
+                eng.comm_init(0, 1, uid)                     # already initialised
+        acc = torch.zeros((), dtype=torch.float32, device='cuda')
+        for _ in range(5):
+            eng.train_epoch([0], acc)
+        if use_comm:
+            eng.bind_grad_buffer()
+            eng.grad(0)
+            g0 = eng.gradbuf.clone()
+            eng.allreduce_grad()                             # SUM over one rank: identity
+            torch.cuda.synchronize()
+            assert torch.equal(g0, eng.gradbuf)
+            eng.comm_destroy()
+            assert eng.comm_size() == (1, 0)
+        torch.cuda.synchronize()
+        outs.append((eng.get_params(), float(acc.item()), eng.step))
+        eng.close()
+    (t0, l0, s0), (t1, l1, s1) = outs
+    assert s0 == s1 == 5
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    np.testing.assert_allclose(t1, t0, rtol=1e-6, atol=1e-7)
+
+
+def _compare(out, tag, rtol_loss, atol_theta):
+    a = np.load(os.path.join(out, '%s_w1_r0.npz' % tag))
+    b0 = np.load(os.path.join(out, '%s_w2_r0.npz' % tag))
+    b1 = np.load(os.path.join(out, '%s_w2_r1.npz' % tag))
+    np.testing.assert_allclose(b0['w'], a['w'], rtol=1e-4)
+    np.testing.assert_allclose(b0['loss'], a['loss'], rtol=rtol_loss)
+    np.testing.assert_allclose(b0['theta'], a['theta'], rtol=0, atol=atol_theta)
+    np.testing.assert_array_equal(b1['theta'], b0['theta'])          # replicas stay bitwise in sync
+    return a, b0, b1
+
+
+@pytest.mark.parametrize('batchNum', [None])
+def test_two_ranks_share_one_gpu_gloo(tmp_path, batchNum):
+    """Real VNEngine, world 2, gloo (both ranks on GPU 0): vn_grad -> all_reduce -> vn_apply reproduces
+    the one-rank run (fp32 kernels: the shard partial sums are added in a different order)."""
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    out = str(tmp_path)
+    kw = dict(weight=[10., 10., 1.], epochNum=30, saveFreq=1000, verbose=False, batchNum=batchNum)
+    rw.launch(conftest.FORKSERVER, 1, out, 'gloo', 'hip', _problem(), kw, 'g')
+    rw.launch(conftest.FORKSERVER, 2, out, 'gloo', 'hip', _problem(), kw, 'g')
+    a, b0, b1 = _compare(out, 'g', 2e-4, 2e-4)
+    assert str(b0['comm']) == 'torch' and list(b0['block']) == [0, 300] and list(b1['block']) == [300, 600]
+
+
+def test_two_ranks_with_an_empty_shard_gloo(tmp_path):
+    """HIP engine with n_k == 0 on rank 1 (nt < batchLen * world): the BC/IC tiles still run there and the
+    rank joins the collective."""
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    out = str(tmp_path)
+    kw = dict(weight=[10., 10., 1.], epochNum=10, saveFreq=1000, verbose=False, batchLen=600)
+    rw.launch(conftest.FORKSERVER, 1, out, 'gloo', 'hip', _problem(), kw, 'e')
+    rw.launch(conftest.FORKSERVER, 2, out, 'gloo', 'hip', _problem(), kw, 'e')
+    a, b0, b1 = _compare(out, 'e', 2e-4, 2e-4)
+    assert list(b1['block']) == [600, 600]
+
+
+def test_two_ranks_two_gpus_rccl(tmp_path):
+    """The production N > 1 path: one process per GPU, `nccl` (= RCCL) process group for bootstrap, the engine's
+    own RCCL communicator for the gradient SUM inside vn_train_epoch."""
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    if _ndev() < 2:
+        pytest.skip('needs >= 2 GPUs (this box has %d)' % _ndev())
+    out = str(tmp_path)
+    kw = dict(weight=[10., 10., 1.], epochNum=30, saveFreq=1000, verbose=False)
+    rw.launch(conftest.FORKSERVER, 1, out, 'nccl', 'hip', _problem(), kw, 'n')
+    rw.launch(conftest.FORKSERVER, 2, out, 'nccl', 'hip', _problem(), kw, 'n')
+    a, b0, b1 = _compare(out, 'n', 2e-4, 2e-4)
+    assert str(b0['comm']) == 'rccl'
+    os.environ['VN_COMM'] = 'torch'
+    try:
+        rw.launch(conftest.FORKSERVER, 2, out, 'nccl', 'hip', _problem(), kw, 't')
+    finally:
+        del os.environ['VN_COMM']
+    t0 = np.load(os.path.join(out, 't_w2_r0.npz'))
+    assert str(t0['comm']) == 'torch'
+    np.testing.assert_allclose(t0['theta'], b0['theta'], rtol=0, atol=1e-6)
+
+
+def test_bench_self_launch_two_ranks_gloo(tmp_path):
+    """`python bench.py --gpus 2` starts its own ranks (here sharing the GPU over gloo) and prints one JSON line."""
+    import json
+    import subprocess
+    import sys
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    # this process has initialised the GPU: the bench parent is started by the clean fork server, not by us
+    q = conftest.FORKSERVER.Queue()
+    p = conftest.FORKSERVER.Process(target=_bench_child, args=(q,))
+    p.start()
+    rc, text = q.get(timeout=900)
+    p.join(60)
+    assert rc == 0, text[-2000:]
+    line = [ln for ln in text.splitlines() if ln.startswith('{')][-1]
+    js = json.loads(line)
+    assert js['n_gpus'] == 2 and js['value'] > 0 and len(js['per_rank']) == 2
+    assert js['comm']['allreduce_ms'] > 0 and 'rehearsal' in js
+    assert js['per_rank'][0]['rows'] + js['per_rank'][1]['rows'] == js['config']['training_points_per_step']
+
+
+def _bench_child(q):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VN_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, env=env, timeout=800)
+    q.put((r.returncode, r.stdout + '\n' + r.stderr))

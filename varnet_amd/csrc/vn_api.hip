@@ -2,6 +2,9 @@
 // reference call sites each entry point replaces).
 #include "vn_internal.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen'ed by vn_comm_*, never linked
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -95,10 +98,16 @@ struct vn_engine {
         *dd_losspart = nullptr;
   long dd_capU = 0, dd_cap_lp = 0;
 
+  // tower gradient SUM over RCCL (vn_comm_init); nullptr = single process or host-side collective
+  ncclComm_t comm = nullptr;
+  int comm_world = 1, comm_rank = 0;
+
   // profiling of the dominant kernel
   bool prof_on = false;
   int prof_n = 0;
   std::vector<hipEvent_t> ev0, ev1;
+  std::vector<hipEvent_t> cev0, cev1;   // around the all-reduce
+  int cprof_n = 0;
   const char* prof_name = "vn_generic_bwd_kernel";
 };
 
@@ -180,7 +189,7 @@ int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* l
   HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));
 
   const long nthreads = b.n_k > h->nB ? b.n_k : h->nB;
-  const int grid = (int)((nthreads + 255) / 256);
+  const int grid = (int)(((nthreads > 0 ? nthreads : 1) + 255) / 256);      // an empty set still zeroes its partials
   if (int rc = ensure(&h->losspart, &h->losspart_cap, (long)grid * 3)) return rc;
   VnSeedArgs a{};
   a.u = h->u; a.ud = h->ud; a.source = h->cfg.has_source ? b.source : nullptr;
@@ -307,6 +316,55 @@ int run_dedup(vn_engine* h, const Batch& b, bool with_grad, float* lossVec, floa
   return VN_OK;
 }
 
+// ---- RCCL, loaded at run time -------------------------------------------------------------
+// librccl.so.1 is resolved by SONAME, so a process that already carries RCCL (PyTorch-ROCm does) shares that
+// copy; VN_RCCL_LIB names another file.  Nothing here is touched unless vn_comm_* is called, so the library
+// loads (and every other entry point works) on a machine without RCCL.
+struct Rccl {
+  void* dl = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.dl) return VN_OK;
+  const char* names[] = {getenv("VN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* dl = nullptr;
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (dl) break;
+  }
+  if (!dl) return fail(VN_EUNSUPPORTED, "RCCL not found (%s): set VN_RCCL_LIB", dlerror());
+  Rccl r;
+  r.dl = dl;
+#define VN_SYM(field, name)                                                          \
+  r.field = (decltype(r.field))dlsym(dl, name);                                      \
+  if (!r.field) { dlclose(dl); return fail(VN_EUNSUPPORTED, "RCCL symbol %s missing", name); }
+  VN_SYM(GetUniqueId, "ncclGetUniqueId")
+  VN_SYM(CommInitRank, "ncclCommInitRank")
+  VN_SYM(CommDestroy, "ncclCommDestroy")
+  VN_SYM(CommCount, "ncclCommCount")
+  VN_SYM(AllReduce, "ncclAllReduce")
+  VN_SYM(GetErrorString, "ncclGetErrorString")
+  VN_SYM(GetVersion, "ncclGetVersion")
+#undef VN_SYM
+  g_rccl = r;
+  return VN_OK;
+}
+
+#define RCCLCHK(expr)                                                                        \
+  do {                                                                                       \
+    ncclResult_t r_ = (expr);                                                                \
+    if (r_ != ncclSuccess) return fail(VN_ECOMM, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
+  } while (0)
+
 }  // namespace
 
 extern "C" {
@@ -330,11 +388,7 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
     return fail(VN_EUNSUPPORTED, "network needs %zu B of LDS per tile (> 160 KiB): reduce depth/width",
                 vn_generic_bwd_lds_bytes(net));
   vn_engine* h = new vn_engine();
-  h->cfg = *cfg;
-  if (h->cfg.lr == 0.0) h->cfg.lr = 1e-3;
-  if (h->cfg.beta1 == 0.0) h->cfg.beta1 = 0.9;
-  if (h->cfg.beta2 == 0.0) h->cfg.beta2 = 0.999;
-  if (h->cfg.eps == 0.0) h->cfg.eps = 1e-8;
+  h->cfg = *cfg;              // taken literally (lr = 0 is a legal, if useless, TF learning rate: TFModel.py:130)
   h->net = net;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->ncu = prop.multiProcessorCount;
@@ -391,6 +445,8 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
   }
   h->ev0.resize(PROF_CAP, nullptr);
   h->ev1.resize(PROF_CAP, nullptr);
+  h->cev0.resize(PROF_CAP, nullptr);
+  h->cev1.resize(PROF_CAP, nullptr);
   *out = h;
   return VN_OK;
 }
@@ -398,6 +454,7 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
 int vn_destroy(vn_engine* h) {
   if (!h) return VN_OK;
   (void)hipSetDevice(h->cfg.device);
+  if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->theta, h->m, h->v, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
                   h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart, h->stamps, h->dd_uv, h->dd_ug, h->dd_su, h->dd_sg, h->dd_partial,
                   h->dd_losspart, h->tp_losspart};
@@ -405,6 +462,8 @@ int vn_destroy(vn_engine* h) {
     if (p) (void)hipFree(p);
   for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
   for (auto e : h->ev1) if (e) (void)hipEventDestroy(e);
+  for (auto e : h->cev0) if (e) (void)hipEventDestroy(e);
+  for (auto e : h->cev1) if (e) (void)hipEventDestroy(e);
   delete h;
   return VN_OK;
 }
@@ -523,10 +582,13 @@ int vn_set_fe_table(vn_engine* h, const float* N, const float* dNt, const float*
 
 int vn_set_interior(vn_engine* h, int32_t batch, const float* Input, const float* gcoef, const float* source,
                     int64_t n_k, const float* detJ_dev, double detJ, const float* N_rows, const float* dNt_rows) {
-  if (!h || !Input || !gcoef) return fail(VN_EINVAL, "null argument");
+  if (!h) return fail(VN_EINVAL, "null handle");
   if (batch < 0 || batch > 65535) return fail(VN_EINVAL, "batch index %d out of range", batch);
   if (n_k < 0) return fail(VN_EINVAL, "negative number of test functions");
-  if (h->cfg.has_source && !source) return fail(VN_EINVAL, "config has a source term but source is NULL");
+  // n_k == 0 is a legal, empty tower feed (VarNetUtility.py:830-838 slices past the end): only the BC/IC rows
+  // contribute, and the rank still takes part in the gradient SUM.
+  if (n_k > 0 && (!Input || !gcoef)) return fail(VN_EINVAL, "null argument");
+  if (n_k > 0 && h->cfg.has_source && !source) return fail(VN_EINVAL, "config has a source term but source is NULL");
   if ((N_rows == nullptr) != (dNt_rows == nullptr)) return fail(VN_EINVAL, "N_rows and dNt_rows must be given together");
   HIPCHK(hipSetDevice(h->cfg.device));
   if ((int)h->batches.size() <= batch) h->batches.resize(batch + 1);
@@ -684,6 +746,12 @@ int vn_apply(vn_engine* h) {
 
 // gradient + optimizer step with the update folded into the gradient reduction (no collective in between)
 static int step_fused(vn_engine* h, int32_t batch, float* loss_acc) {
+  if (h->comm) {
+    // towers: gradient -> SUM over ranks -> update, all on the engine stream, no host round trip
+    if (int rc = vn_grad(h, batch)) return rc;
+    if (int rc = vn_allreduce_grad(h)) return rc;
+    return apply_impl(h, loss_acc);
+  }
   h->step += 1;
   VnOptArgs o;
   o.kind = h->cfg.optimizer; o.theta = h->theta; o.m = h->m; o.v = h->v; o.loss_acc = loss_acc;
@@ -766,9 +834,95 @@ int vn_residual_f64(vn_engine* h, const double* X, const double* diff, const dou
   return VN_OK;
 }
 
+
+// ---- tower gradient SUM over RCCL (TFModel.py:342-377) ------------------------------------
+int vn_comm_unique_id(void* id_out) {
+  if (!id_out) return fail(VN_EINVAL, "null argument");
+  if (int rc = load_rccl()) return rc;
+  static_assert(sizeof(ncclUniqueId) == VN_COMM_ID_BYTES, "RCCL unique id size");
+  ncclUniqueId id;
+  RCCLCHK(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof id);
+  return VN_OK;
+}
+
+int vn_comm_init(vn_engine* h, int32_t rank, int32_t world, const void* unique_id) {
+  if (!h || !unique_id) return fail(VN_EINVAL, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(VN_EINVAL, "need 0 <= rank < world (got %d of %d)", rank, world);
+  if (h->comm) return fail(VN_ESTATE, "communicator already initialised (call vn_comm_destroy first)");
+  if (int rc = load_rccl()) return rc;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof id);
+  ncclComm_t c = nullptr;
+  RCCLCHK(g_rccl.CommInitRank(&c, world, id, rank));
+  int cnt = 0;
+  RCCLCHK(g_rccl.CommCount(c, &cnt));
+  if (cnt != world) { (void)g_rccl.CommDestroy(c); return fail(VN_ECOMM, "RCCL reports %d ranks, expected %d", cnt, world); }
+  h->comm = c; h->comm_world = world; h->comm_rank = rank;
+  return VN_OK;
+}
+
+int vn_comm_size(const vn_engine* h, int32_t* world, int32_t* rank) {
+  if (!h || !world) return fail(VN_EINVAL, "null argument");
+  int cnt = 1;
+  if (h->comm) RCCLCHK(g_rccl.CommCount(h->comm, &cnt));
+  *world = cnt;
+  if (rank) *rank = h->comm ? h->comm_rank : 0;
+  return VN_OK;
+}
+
+int vn_comm_destroy(vn_engine* h) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  if (!h->comm) return VN_OK;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  ncclComm_t c = h->comm;
+  h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0;
+  RCCLCHK(g_rccl.CommDestroy(c));
+  return VN_OK;
+}
+
+int vn_allreduce_grad(vn_engine* h) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  if (!h->comm) return fail(VN_ESTATE, "no communicator (call vn_comm_init first)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  // one collective per step: P gradient floats + (loss, BC, IC, var), in place, on the engine stream
+  const bool rec = h->prof_on && h->cprof_n < PROF_CAP;
+  if (rec) {
+    if (!h->cev0[h->cprof_n]) { HIPCHK(hipEventCreate(&h->cev0[h->cprof_n])); HIPCHK(hipEventCreate(&h->cev1[h->cprof_n])); }
+    HIPCHK(hipEventRecord(h->cev0[h->cprof_n], h->stream));
+  }
+  RCCLCHK(g_rccl.AllReduce(h->gradbuf, h->gradbuf, (size_t)h->net.P + 4, ncclFloat32, ncclSum, h->comm, h->stream));
+  if (rec) { HIPCHK(hipEventRecord(h->cev1[h->cprof_n], h->stream)); h->cprof_n++; }
+  return VN_OK;
+}
+
 int vn_get_step(const vn_engine* h, int64_t* step) {
   if (!h || !step) return fail(VN_EINVAL, "null argument");
   *step = h->step;
+  return VN_OK;
+}
+
+int vn_profile_comm(vn_engine* h, double* mean_ms, int64_t* calls) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double tot = 0.0;
+  for (int i = 0; i < h->cprof_n; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->cev0[i], h->cev1[i]));
+    tot += ms;
+  }
+  if (mean_ms) *mean_ms = h->cprof_n ? tot / h->cprof_n : 0.0;
+  if (calls) *calls = h->cprof_n;
+  return VN_OK;
+}
+
+int vn_kernel_path(const vn_engine* h, int32_t* kernel, int32_t* two_pass) {
+  if (!h || !kernel) return fail(VN_EINVAL, "null argument");
+  *kernel = h->use_fused16 ? VN_KERNEL_FUSED16 : h->use_fused ? VN_KERNEL_FUSED : h->two_pass ? VN_KERNEL_FUSED16 : VN_KERNEL_GENERIC;
+  if (two_pass) *two_pass = h->two_pass ? 1 : 0;
   return VN_OK;
 }
 
@@ -784,6 +938,7 @@ int vn_profile_begin(vn_engine* h) {
   if (!h) return fail(VN_EINVAL, "null handle");
   h->prof_on = true;
   h->prof_n = 0;
+  h->cprof_n = 0;
   return VN_OK;
 }
 

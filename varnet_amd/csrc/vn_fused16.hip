@@ -22,6 +22,8 @@
 // Register budget: 256 VGPRs per wave (stored activations 2*KS*L = 130 at 5x50; 18 spilled at 5x50).
 #include "vn_internal.h"
 
+#include <atomic>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4a __attribute__((may_alias));
 
@@ -1157,14 +1159,17 @@ template <int L, int KS>
 hipError_t launch_one(const VnFusedArgsD& a, int grid, hipStream_t s) {
   using LY = Lay<L, KS>;
   const size_t bytes = (size_t)LY::TOTAL * sizeof(float);
-  static int attr_dev = -1;                      // the attribute is per device and sticky: set it once
+  // the attribute is per device and sticky: set it once per device (bit mask; engines on different devices may
+  // be driven from different threads)
+  static std::atomic<unsigned long long> attr_done{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (attr_dev != dev) {
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
     hipError_t e = hipFuncSetAttribute((const void*)vn_fused16_kernel<L, KS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
-    attr_dev = dev;
+    attr_done.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((vn_fused16_kernel<L, KS>), dim3(grid), dim3(NTHREADS), bytes, s, a);
   return hipGetLastError();

@@ -19,6 +19,7 @@ VN_MAX_LAYERS = 6
 VN_MAX_WIDTH = 64
 VN_MAX_DIN = 8
 VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED, VN_KERNEL_FUSED16 = 0, 1, 2, 3
+VN_COMM_ID_BYTES = 128
 
 
 class VnConfig(C.Structure):
@@ -62,7 +63,14 @@ _SIGS = {
     'vn_forward_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'vn_residual': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_residual_f64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
+    'vn_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'vn_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    'vn_comm_size': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'vn_comm_destroy': (C.c_int, [C.c_void_p]),
+    'vn_allreduce_grad': (C.c_int, [C.c_void_p]),
     'vn_get_step': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    'vn_profile_comm': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'vn_kernel_path': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'vn_debug_stamps': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     'vn_profile_begin': (C.c_int, [C.c_void_p]),
     'vn_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
@@ -342,6 +350,53 @@ class VNEngine:
         self._ck(fn(self.h, _ptr(X), _ptr(diff), _ptr(vel), _ptr(source), _ptr(diff_dx), n, _ptr(u), _ptr(r)))
         return u, r
 
+    # -- towers: RCCL communicator inside the engine (TFModel.py:253-289, 342-377) ---------------
+    @staticmethod
+    def comm_unique_id():
+        """128 opaque bytes (ncclUniqueId) made on ONE rank; ship them to every rank, then `comm_init`."""
+        lib = load_library()
+        buf = C.create_string_buffer(VN_COMM_ID_BYTES)
+        rc = lib.vn_comm_unique_id(buf)
+        if rc != 0:
+            raise VNError('varnet_hip error %d: %s' % (rc, lib.vn_last_error().decode()))
+        return bytes(buf.raw)
+
+    def comm_init(self, rank, world, unique_id):
+        """Join the RCCL communicator (collective over all ranks).  Afterwards `train_step` /
+        `train_epoch` run gradient -> SUM all-reduce -> optimizer on the engine stream."""
+        assert len(unique_id) == VN_COMM_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), VN_COMM_ID_BYTES)
+        self._ck(self.lib.vn_comm_init(self.h, int(rank), int(world), buf))
+
+    def comm_init_from_torch(self, dist):
+        """Bootstrap through an initialised torch.distributed group: rank 0 makes the id, everyone
+        receives it as an ordinary object broadcast."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [self.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        self.comm_init(rank, world, box[0])
+
+    def comm_size(self):
+        w, r = C.c_int32(), C.c_int32()
+        self._ck(self.lib.vn_comm_size(self.h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def comm_destroy(self):
+        self._ck(self.lib.vn_comm_destroy(self.h))
+
+    def allreduce_grad(self):
+        self._ck(self.lib.vn_allreduce_grad(self.h))
+
+    def kernel_path(self):
+        """(VN_KERNEL_* the engine resolved to, two-pass route flag)."""
+        k, tp = C.c_int32(), C.c_int32()
+        self._ck(self.lib.vn_kernel_path(self.h, C.byref(k), C.byref(tp)))
+        return k.value, bool(tp.value)
+
+    def dedup_supported(self):
+        k, tp = self.kernel_path()
+        return k == VN_KERNEL_FUSED16 and not tp
+
     def debug_stamps(self):
         out = (C.c_uint64 * 8)()
         self._ck(self.lib.vn_debug_stamps(self.h, out))
@@ -350,6 +405,11 @@ class VNEngine:
     # -- profiling -----------------------------------------------------------------------
     def profile_begin(self):
         self._ck(self.lib.vn_profile_begin(self.h))
+
+    def profile_comm(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.lib.vn_profile_comm(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def profile_end(self):
         ms, n = C.c_double(), C.c_int64()

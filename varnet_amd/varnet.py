@@ -277,7 +277,8 @@ class TrainResult:
         else:
             L.append('\tutilized processor: GPU:0\n\n')
         L.append('Optimizer information:\n')
-        L.append('\ttype: Adam stochastic gradient descent algorithm\n')
+        L.append('\ttype: %s stochastic gradient descent algorithm\n'
+                 % ('RMSProp' if str(varNet.optimizer).lower() == 'rmsprop' else 'Adam'))
         L.append('\tlearning rate: ' + str(varNet.learning_rate) + '\n\n')
         L.append('Space-time discretization information:\n')
         L.append('\tspatial domain interior discretization number: ' + str(varNet.discNum) + '\n')
@@ -498,23 +499,25 @@ class ManageTrainData:
         """
         vn = self.vn
         fd = vn.fixData
-        if self.shuffled or fd.detJvec or not hasattr(vn.engine, 'set_dedup'):
+        if self.shuffled or fd.detJvec or not hasattr(vn.engine, 'set_dedup') or self.vn.dim > 3:
+            return 0
+        if not getattr(vn.engine, 'dedup_supported', lambda: True)():
             return 0
         q, total = self.integNum, 0
         cache = getattr(self, '_dd_cache', {})
         for mb, d in enumerate(self.mor):
             for bi in range(self.batchNum):
                 n0, n1 = self.block(bi)
+                if n1 == n0:
+                    continue
                 key = (mb, bi)
                 if key not in cache:
                     blk = d['Input_host'][n0 * q:n1 * q]
                     first, uid, rowptr, rowidx = unique_points(blk, fd.feDim, fd.hVec)
                     cache[key] = (vn.engine.dev(blk[first]), uid, rowptr, rowidx)
                 Xu, uid, rowptr, rowidx = cache[key]
-                try:
-                    vn.engine.set_dedup(self.engine_batch(mb, bi), Xu, uid, rowptr, rowidx)
-                except Exception:
-                    return 0
+                # not applicable was decided above; an engine error here is a real failure and propagates
+                vn.engine.set_dedup(self.engine_batch(mb, bi), Xu, uid, rowptr, rowidx)
                 total += Xu.shape[0]
         self._dd_cache = cache
         self.dedup_on = True
@@ -588,6 +591,17 @@ class VarNet:
         self._rng = np.random.default_rng(12345)
         self.engine = self._make_engine(processors)
         self.engine.init_params(seed=0)
+        # tower gradient SUM (TFModel.py:342-377): by default an RCCL communicator inside the engine, so a
+        # step is gradient -> all-reduce -> optimizer on one stream with one host call; VN_COMM=torch keeps the
+        # collective in torch.distributed (three host calls per step)
+        self.comm = 'none'
+        if self.world > 1:
+            self.comm = 'torch'
+            mode = os.environ.get('VN_COMM', 'auto')      # auto: in-engine RCCL whenever the ranks own distinct GPUs
+            if hasattr(self.engine, 'comm_init_from_torch') and \
+                    (mode == 'rccl' or (mode == 'auto' and self.dist.get_backend() == 'nccl')):
+                self.engine.comm_init_from_torch(self.dist)
+                self.comm = 'rccl'
         fd = self.fixData
         self.engine.set_fe_table(fd.N, fd.dNt, None if fd.integW is None else fd.integW)
         self.tfData = self.engine       # name kept for scripts that poke at `VarNet.tfData`
@@ -598,8 +612,19 @@ class VarNet:
         device = 0
         if isinstance(processors, (list, tuple)):
             if len(processors) > 1:
-                raise ValueError('one process drives one GPU: launch one rank per GPU with torchrun')
-            processors = processors[0]
+                # deliberate divergence (INTEGRATION.md "Multi-GPU"): TF-1 drives all towers from ONE process
+                # (TFModel.py:120-165, 253-289); here every GPU has its own process.  Inside a launched rank the
+                # list is accepted and this rank takes its own entry.
+                if self.world > 1 and len(processors) == self.world:
+                    processors = processors[self.rank]
+                else:
+                    raise ValueError('processors=%s asks for %d towers in one process; this engine runs one '
+                                     'process per GPU: start %d ranks (python -m torch.distributed.run '
+                                     '--nproc-per-node %d --master-addr 127.0.0.1 script.py, or varnet_amd.launch) '
+                                     'and pass the same list on every rank' % (processors, len(processors),
+                                                                              len(processors), len(processors)))
+            else:
+                processors = processors[0]
         if isinstance(processors, str):
             kind, _, idx = processors.partition(':')
             if kind.upper() != 'GPU':
@@ -893,9 +918,20 @@ class VarNet:
                     N_rows=N_rows, dNt_rows=dNt_rows,
                     detJ=eng.dev(np.reshape(fd.detJ, -1)) if fd.detJvec else None)
 
+    def _sync_sampling(self):
+        """Towers must draw ONE training set (the reference samples once and slices it per tower,
+        VarNetUtility.py:819-857): rank 0 draws a seed from its NumPy stream, every rank re-seeds with it."""
+        if self.world == 1 or self.dist is None:
+            return
+        box = [int(np.random.randint(0, 2 ** 31 - 1)) if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        np.random.seed(box[0])
+
     def _build_tdata(self, batchNum=None, batchLen=None, smpScheme='uniform', frac=0.5, addTrainPts=True,
                      suppFactor=1.0):
         fd = self.fixData
+        if smpScheme != 'uniform':
+            self._sync_sampling()
         Input, _, biInput, biDof = self.trainingPoints(smpScheme, frac, addTrainPts, suppFactor)
         if smpScheme == 'optimal' and not addTrainPts:
             fd.biDof = [int(b) for b in biDof]
@@ -969,8 +1005,9 @@ class VarNet:
         device scalar `loss_acc`."""
         eng = self.engine
         P = eng.P
-        if self.world == 1 and hasattr(eng, 'train_epoch'):
-            # one process: the whole pass in one host call (no per-mini-batch Python / launch-queue gaps)
+        if (self.world == 1 or self.comm == 'rccl') and hasattr(eng, 'train_epoch'):
+            # the whole pass in one host call (no per-mini-batch Python / launch-queue gaps); with towers the
+            # engine's own RCCL communicator sums the gradient between the two kernels
             eng.train_epoch([tData.engine_batch(mb, bi) for bi in range(tData.batchNum)], loss_acc)
             return
         gb = eng.bind_grad_buffer()
