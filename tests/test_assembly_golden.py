@@ -1,0 +1,169 @@
+"""
+Host data assembly against the REFERENCE's own output: every array
+`varnet_amd` would hand to the device -- Input, biInput, biDof, biLabel, gcoef, source, the FE tables, the
+(mini-batch, tower) slices with their intShape, the BC/IC weight rule and `trainWeight`'s three branches --
+must equal what /root/reference/VarNet.py + VarNetUtility.py produce for the same problem.  The fixture
+tests/golden/assembly.npz was written by oracle/gen_golden_assembly.py, which runs the reference's NumPy code
+unmodified (rows a5-a8, a14 of the scope table).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from varnet_amd.domain import Domain1D, PolygonDomain2D
+from varnet_amd.adpde import ADPDE
+from varnet_amd.varnet import VarNet
+from tests.oracle_engine import OracleEngine
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'assembly.npz'))
+TOL = dict(rtol=1e-13, atol=1e-13)
+
+
+@pytest.fixture(autouse=True)
+def cpu_engine(monkeypatch):
+    def make(self, processors):
+        fd = self.fixData
+        return OracleEngine(self.dim, self.inpDim, self.layerWidth, self.PDE.timeDependent, fd.integNum,
+                            isSource=self.lossOpt['isSource'], integWflag=self.lossOpt['integWflag'],
+                            learning_rate=self.learning_rate)
+    monkeypatch.setattr(VarNet, '_make_engine', make)
+
+
+def pde1(td=True):
+    if td:
+        return ADPDE(Domain1D(), diff=0.1 / np.pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                     IC=lambda x: -np.sin(np.pi * x))
+    return ADPDE(Domain1D(), diff=0.1 / np.pi, vel=1.0, source=lambda x: 1.0 + x ** 2, timeDependent=False,
+                 BCs=[[0., 1., 0.5], [0., 2., 1.0]])
+
+
+def pde2(source=False):
+    verts = np.array([[0.0, -0.5], [0.0, -0.2], [0.0, 0.2], [0.0, 0.5], [2.0, 0.5], [2.0, -0.5]])
+    BC = [[], [0.0, 1.0, 1.0], [], [], [], []]
+    kw = {}
+    if source:
+        kw['source'] = lambda x, t: np.sin(x[:, 0:1]) * (1.0 + t)
+        kw['diff'] = lambda x, t: 1e-3 * (1.0 + x[:, 1:2] ** 2)
+        kw['vel'] = lambda x, t: np.hstack([1.0 + 0.0 * t, 0.1 * x[:, 0:1]])
+    else:
+        kw['diff'], kw['vel'] = 1e-3, [1., 0.]
+    return ADPDE(PolygonDomain2D(verts), tInterval=[0, 1.5], BCs=BC, IC=0.0, **kw)
+
+
+def build(kind, ip):
+    if kind == '1dt':
+        return VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=ip)
+    if kind == '2dt':
+        return VarNet(pde2(), layerWidth=[5], discNum=[4, 3], bDiscNum=3, tDiscNum=4, integPnum=ip)
+    if kind == '2dt_var':
+        return VarNet(pde2(source=True), layerWidth=[5], discNum=[4, 3], bDiscNum=3, tDiscNum=4, integPnum=2)
+    return VarNet(pde1(td=False), layerWidth=[5], discNum=7, bDiscNum=None, tDiscNum=[], integPnum=2)
+
+
+def npy(t):
+    return None if t is None else (t.numpy() if hasattr(t, 'numpy') else np.asarray(t))
+
+
+def check_case(key, vn, bn, bl, pu):
+    g = key + '_'
+    fd = vn.fixData
+    sc = G[g + 'scalars']
+    # towers: rank r of world pu plays the reference's tower r
+    per_rank = []
+    for r in range(pu):
+        vn.world, vn.rank = pu, r
+        td = vn._build_tdata(batchNum=bn, batchLen=bl)
+        per_rank.append((td, dict(vn.engine.batches)))
+    td = per_rank[0][0]
+    d = td.mor[0]
+    assert (fd.nt, fd.nT, fd.integNum, fd.bDofsum) == tuple(int(v) for v in sc[[0, 1, 2, 4]])
+    np.testing.assert_allclose(float(np.reshape(fd.detJ, -1)[0]), sc[3], rtol=1e-14)
+    assert float(fd.biDimVal) == sc[5]
+    assert (td.batchNum, td.batchLen, td.puNum) == tuple(int(v) for v in sc[6:9])
+    np.testing.assert_allclose(np.reshape(fd.hVec, -1), G[g + 'hVec'], **TOL)
+    # whole-set arrays
+    np.testing.assert_allclose(d['Input_host'], G[g + 'Input'], **TOL)
+    np.testing.assert_allclose(npy(d['biInput']), G[g + 'biInput'], **TOL)
+    np.testing.assert_allclose(npy(d['biLabel']).reshape(-1, 1), G[g + 'biLabel'], **TOL)
+    np.testing.assert_allclose(npy(d['gcoef']), G[g + 'gcoef'], **TOL)
+    assert [int(b) for b in fd.biDof] == [int(b) for b in G[g + 'biDof']]
+    if vn.lossOpt['isSource']:
+        np.testing.assert_allclose(npy(d['source']).reshape(-1, 1), G[g + 'source'], **TOL)
+    else:
+        assert not np.any(G[g + 'source'])                          # the reference feeds zeros it never uses
+    # FE tables: the reference tiles to nT rows, the build keeps one period
+    Nr, dNxr, dNtr = fd.rows()
+    np.testing.assert_allclose(Nr, G[g + 'N'], **TOL)
+    np.testing.assert_allclose(dNxr, G[g + 'dNx'], **TOL)
+    if vn.PDE.timeDependent:
+        np.testing.assert_allclose(dNtr, G[g + 'dNt'], **TOL)
+    if G[g + 'integW'].size:
+        np.testing.assert_allclose(np.reshape(fd.integW, -1), np.reshape(G[g + 'integW'], -1), **TOL)
+    else:
+        assert fd.integW is None
+    np.testing.assert_allclose(fd.uniform_input, G[g + 'uniform_input'], **TOL)
+    # (mini-batch, tower) feeds
+    q = fd.integNum
+    for bi in range(td.batchNum):
+        for r in range(pu):
+            tdr, batches = per_rank[r]
+            h = g + 'b%d_t%d_' % (bi, r)
+            Inp, gco, src, n_k, detJ, _, _ = batches[tdr.engine_batch(0, bi)]
+            assert [n_k, q] == [int(v) for v in G[h + 'intShape']], (h, n_k)
+            np.testing.assert_allclose(Inp.reshape(-1, vn.inpDim), G[h + 'Input'], **TOL)
+            np.testing.assert_allclose(gco.reshape(-1, vn.dim), G[h + 'gcoef'], **TOL)
+            np.testing.assert_allclose(detJ, float(G[h + 'detJ']), rtol=1e-14)
+            np.testing.assert_allclose(np.tile(fd.N, n_k).reshape(-1, 1), G[h + 'N'].reshape(-1, 1), **TOL)
+    np.testing.assert_allclose(td.towerWeights([3.0, 2.0, 5.0]), G[g + 'trainW_fed'], rtol=1e-15)
+    vn.world, vn.rank = 1, 0
+
+
+CASES = [(kind, ip, bn, bl, pu) for kind in ('1dt', '2dt') for ip in (2, 3)
+         for (bn, bl, pu) in ((None, None, 1), (3, None, 1), (None, None, 2), (3, None, 2), (None, 7, 2))]
+
+
+@pytest.mark.parametrize('kind,ip,bn,bl,pu', CASES)
+def test_assembly_matches_reference(kind, ip, bn, bl, pu):
+    check_case('%s_ip%d_bn%s_bl%s_pu%d' % (kind, ip, bn, bl, pu), build(kind, ip), bn, bl, pu)
+
+
+def test_variable_coefficients_and_source_match_reference():
+    check_case('2dt_var', build('2dt_var', 2), None, None, 1)
+
+
+def test_steady_problem_matches_reference():
+    check_case('1d_steady', build('1d_steady', 2), None, None, 1)
+
+
+@pytest.mark.parametrize('name', ['td', 'steady'])
+def test_train_weight_matches_reference(name):
+    """trainWeight's three branches on fixed loss triples (VarNet.py:1094-1146)."""
+    vn = build('1dt' if name == 'td' else '1d_steady', 2)
+
+    class Log:
+        verbose = False
+
+        def writeCase(self, s):
+            pass
+    vn.trainRes = Log()
+    n_nan = 0
+    for i, trip in enumerate(G['tw_triples']):
+        for j, wt in enumerate(G['tw_weights']):
+            for branch, (nw, uo) in (('default', (False, False)), ('normalize', (True, False)), ('original', (False, True))):
+                comp = np.reshape(trip, [3, 1]).copy()
+                wts = list(wt)
+                if name == 'steady':
+                    comp[1, 0] = 0.0
+                    wts = wts[:2]
+                vn.splitLoss = lambda tData, W=None, _c=comp: (_c.copy(), tData, None)
+                trainW, _, lossVal = vn.trainWeight(wts, None, nw, uo)
+                ref = G['tw_%s_%s_t%d_w%d' % (name, branch, i, j)]
+                if np.isnan(ref).any():
+                    # the reference raises here (normalizeW on a time-dependent problem hands uf.vstack an ndarray,
+                    # VarNet.py:1127): nothing to compare with; the build returns the formula's value instead
+                    assert name == 'td' and branch == 'normalize' and np.isfinite(trainW).all()
+                    n_nan += 1
+                    continue
+                np.testing.assert_allclose(trainW, ref, rtol=1e-14)
+    assert n_nan == (9 if name == 'td' else 0)

@@ -467,3 +467,52 @@ def test_many_tiles_per_workgroup_fused_vs_generic(widths, q, n_k, src):
     P = g_gen.size - 4
     assert abs(g_a[P] - g_gen[P]) <= 2e-5 * abs(g_gen[P])
     assert np.max(np.abs(g_a[:P] - g_gen[:P])) <= 2e-4 * np.max(np.abs(g_gen[:P]))
+
+
+# ---- reference-generated inputs (tests/golden/assembly.npz, written by oracle/gen_golden_assembly.py from the
+# reference's own VarNet.py / VarNetUtility.py) through the HIP engine, against the oracle -------------------
+@pytest.mark.parametrize('key,widths', [
+    ('2dt_ip2_bnNone_blNone_pu1', [50] * 5),
+    ('2dt_ip3_bnNone_blNone_pu1', [50, 50, 50]),          # integNum 216: two-pass fused route, integW
+    ('1dt_ip2_bnNone_blNone_pu1', [50] * 4),
+    ('1dt_ip3_bnNone_blNone_pu1', [20, 20, 20]),          # integNum 36, integW
+    ('2dt_var', [32, 17]),                                # variable kappa / v, source term
+])
+def test_reference_assembled_inputs_through_engine(key, widths):
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'assembly.npz'))
+    g = key + '_'
+    sc = G[g + 'scalars']
+    nt, nT, q, detJ, bDof, biDimVal = int(sc[0]), int(sc[1]), int(sc[2]), float(sc[3]), int(sc[4]), float(sc[5])
+    Input, gcoef = G[g + 'Input'], G[g + 'gcoef']
+    d_in, dim = Input.shape[1], gcoef.shape[1]
+    source = bool(np.any(G[g + 'source']))
+    integW = G[g + 'integW']
+    has_w = integW.size > 0
+    eng = make_engine(d_in, dim, widths, q, source, has_w)
+    eng.init_params(seed=11)
+    flat = eng.get_params()
+    eng.set_fe_table(G[g + 'N'][:q], G[g + 'dNt'][:q], integW.reshape(-1) if has_w else None)
+    eng.set_interior(0, Input, gcoef, G[g + 'source'] if source else None, n_k=nt, detJ=detJ)
+    eng.set_bic(G[g + 'biInput'], G[g + 'biLabel'], bDof, biDimVal)
+    w = np.array([3.0, 2.0, 5.0])
+    eng.set_weights(w)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)       # what the device is fed (TFModel.py:531)
+    kw = dict(Input=f32(Input), gcoef=f32(gcoef), source=f32(G[g + 'source']) if source else None,
+              N=f32(G[g + 'N']), dNt=f32(G[g + 'dNt']), integW=f32(integW.reshape(1, -1)) if has_w else None,
+              intShape=[nt, q], detJ=float(np.float32(detJ)), detJvec=False, biInput=f32(G[g + 'biInput']),
+              biLabel=f32(G[g + 'biLabel']), bDof=bDof, biDimVal=biDimVal, w=w, dim=dim, time_dependent=True,
+              is_source=source, integWflag=has_w)
+    ref, gref = og.loss_and_grad(flat.astype(np.float64), d_in, widths, torch.float64, **kw)
+    out, lv = eng.eval_loss(0, lossVec=True)
+    for got, k in zip(out, ['loss', 'BCloss', 'ICloss', 'varLoss']):
+        assert abs(got - ref[k]) <= 4 * LOSS_RTOL * abs(ref[k]) + 1e-7, (k, got, ref[k])
+    lref = ref['lossVec'].reshape(-1)
+    assert np.max(np.abs(lv.cpu().numpy() - lref)) <= LVEC_RTOL * np.max(np.abs(lref))
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    gg = gb.cpu().numpy()
+    assert abs(gg[eng.P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+    assert np.max(np.abs(gg[:eng.P] - gref)) / np.max(np.abs(gref)) <= GRAD_RTOL
+    eng.close()

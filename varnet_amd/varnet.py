@@ -458,6 +458,13 @@ class ManageTrainData:
     def engine_batch(self, mor_b, bi):
         return mor_b * self.batchNum + bi
 
+    def towerWeights(self, trainW):
+        """Weights one tower is fed: BC/IC terms divided by batchNum*puNum because every (mini-batch, tower)
+        feed repeats the whole BC/IC set (updateDictFields('trainW'), VarNetUtility.py:900-901)."""
+        w = np.array(trainW, dtype=float)
+        w[:-1] = w[:-1] / self.batchNum / self.puNum
+        return w
+
     def _register(self):
         eng, q = self.vn.engine, self.integNum
         torch = eng.torch
@@ -1062,8 +1069,7 @@ class VarNet:
         def set_train_weights(tD, wts):
             eng.set_weights([1.0, 1.0, 1.0])
             tW, tD, lv = self.trainWeight(wts, tD, normalizeW, useOriginalW)
-            w_e = tW.copy()
-            w_e[:-1] = w_e[:-1] / tD.batchNum / tD.puNum              # VarNetUtility.py:900-901
+            w_e = tD.towerWeights(tW)                                 # VarNetUtility.py:900-901
             eng.set_weights(w_e)
             return tW, w_e, lv
 
