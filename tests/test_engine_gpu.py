@@ -17,6 +17,24 @@ LOSS_RTOL = 1e-5
 GRAD_RTOL = 1e-4
 LVEC_RTOL = 1e-4
 
+# measured worst-case deviations per parity case, written to gpurun_out/parity_errors.json at the end of the
+# module (copied to profiles/ when a round's numbers are recorded)
+ERRORS = {}
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _dump_errors():
+    yield
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_errors.json'), 'w') as f:
+            json.dump(ERRORS, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
 
 def synth(seed, d_in, dim, widths, integNum, n_k, nB, bDof, source=False, integW=False, detJvec=False):
     rng = np.random.default_rng(seed)
@@ -106,18 +124,24 @@ def test_loss_and_grad_parity(case, kernel):
     ref, gref = oracle_eval(flat, d, d_in, dim, widths, integNum, n_k, bDof, source, integW, detJvec)
 
     out, lv = eng.eval_loss(0, lossVec=True)
+    rec = {}
     for got, key in zip(out, ['loss', 'BCloss', 'ICloss', 'varLoss']):
-        assert abs(got - ref[key]) <= LOSS_RTOL * 4 * abs(ref[key]) + 1e-7, (key, got, ref[key])
+        rec['eval_' + key] = abs(got - ref[key]) / max(abs(ref[key]), 1e-300)
+        assert abs(got - ref[key]) <= LOSS_RTOL * abs(ref[key]) + 1e-7, (key, got, ref[key])
     lv = lv.cpu().numpy()
     lref = ref['lossVec'].reshape(-1)
+    rec['lossVec'] = float(np.max(np.abs(lv - lref)) / np.max(np.abs(lref)))
     assert np.max(np.abs(lv - lref)) <= LVEC_RTOL * np.max(np.abs(lref))
 
     gb = eng.bind_grad_buffer()
     eng.grad(0)
     torch.cuda.synchronize()
     g = gb.cpu().numpy()
-    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * 4 * abs(ref['loss'])
+    rec['grad_loss'] = float(abs(g[eng.P] - ref['loss']) / abs(ref['loss']))
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
     err = np.max(np.abs(g[:eng.P] - gref)) / np.max(np.abs(gref))
+    rec['grad'] = float(err)
+    ERRORS['case%d_%s' % (CASES.index(case), ['auto', 'generic', 'fused32', 'fused16'][kernel])] = rec
     assert err <= GRAD_RTOL, err
     eng.close()
 
@@ -295,7 +319,7 @@ def test_steady_problem_parity(case, kernel):
     eng.grad(0)
     torch.cuda.synchronize()
     g = gb.cpu().numpy()
-    assert abs(g[eng.P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
     assert abs(g[eng.P + 2]) == 0.0                                  # ICloss is the constant 0
     assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
     eng.close()
@@ -353,13 +377,13 @@ def test_per_row_tables_and_detjvec_parity(q, widths, kernel):
         biLabel=biLabel.astype(np.float64), bDof=bDof, biDimVal=2.0, w=w, dim=dim, time_dependent=True,
         is_source=True, integWflag=integW is not None)
     out, lv = eng.eval_loss(0, lossVec=True)
-    assert abs(out[0] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+    assert abs(out[0] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
     assert np.max(np.abs(lv.cpu().numpy() - ref['lossVec'].reshape(-1))) <= LVEC_RTOL * np.max(np.abs(ref['lossVec']))
     gb = eng.bind_grad_buffer()
     eng.grad(0)
     torch.cuda.synchronize()
     g = gb.cpu().numpy()
-    assert abs(g[eng.P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
     assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
     eng.close()
 
@@ -424,7 +448,7 @@ def test_dedup_formulation_parity(case):
         dim=dim, time_dependent=True, is_source=source, integWflag=integW)
     P = eng.P
     for g in (g_rows, g_dd):
-        assert abs(g[P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+        assert abs(g[P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
         assert np.max(np.abs(g[:P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
     assert np.allclose(g_dd[P + 1:P + 4], g_rows[P + 1:P + 4], rtol=1e-5)
     # bitwise reproducible, and switching it off restores the row-wise path
@@ -506,13 +530,22 @@ def test_reference_assembled_inputs_through_engine(key, widths):
     ref, gref = og.loss_and_grad(flat.astype(np.float64), d_in, widths, torch.float64, **kw)
     out, lv = eng.eval_loss(0, lossVec=True)
     for got, k in zip(out, ['loss', 'BCloss', 'ICloss', 'varLoss']):
-        assert abs(got - ref[k]) <= 4 * LOSS_RTOL * abs(ref[k]) + 1e-7, (k, got, ref[k])
+        assert abs(got - ref[k]) <= LOSS_RTOL * abs(ref[k]) + 1e-7, (k, got, ref[k])
     lref = ref['lossVec'].reshape(-1)
-    assert np.max(np.abs(lv.cpu().numpy() - lref)) <= LVEC_RTOL * np.max(np.abs(lref))
+    # On real PDE inputs R_k is a sum of integNum terms that cancel to ~1e-4 of their size (the weak residual is
+    # small), so detJ*R_k^2 carries the fp32 rounding of that cancellation: the reference graph itself, evaluated
+    # in fp32 (what TF-1 runs), deviates from fp64 by the same amount.  Bar: 1e-4 of the largest entry, or 4x the
+    # fp32 restatement's own deviation from fp64, whichever is larger.
+    kw32 = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k, v in kw.items()}
+    ref32, _ = og.loss_and_grad(flat, d_in, widths, torch.float32, **kw32)
+    own = float(np.max(np.abs(ref32['lossVec'].reshape(-1).astype(np.float64) - lref)))
+    dv = float(np.max(np.abs(lv.cpu().numpy() - lref)))
+    ERRORS['golden_' + key] = {'lossVec_abs': dv, 'lossVec_fp32_oracle_abs': own, 'lossVec_scale': float(np.max(np.abs(lref)))}
+    assert dv <= max(LVEC_RTOL * np.max(np.abs(lref)), 4 * own), (dv, own)
     gb = eng.bind_grad_buffer()
     eng.grad(0)
     torch.cuda.synchronize()
     gg = gb.cpu().numpy()
-    assert abs(gg[eng.P] - ref['loss']) <= 4 * LOSS_RTOL * abs(ref['loss'])
+    assert abs(gg[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
     assert np.max(np.abs(gg[:eng.P] - gref)) / np.max(np.abs(gref)) <= GRAD_RTOL
     eng.close()
