@@ -702,6 +702,16 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     if (fin >= LY::HP) fin = 0;
     lc.offB[m] = fin * WS + 4 * lc.g;
   }
+  // Diagnostic ablations (-DVN_ABL_FWD_W / -DVN_ABL_BWD_W; results are WRONG, only counters and time matter):
+  // the weight-fragment reads of the forward / backward GEMMs become bank-conflict-free (32 lanes of a half on
+  // 32 distinct banks), to attribute SQ_LDS_BANK_CONFLICT (profiles/r2_lds_conflict_ablation.md).
+#ifdef VN_ABL_FWD_W
+  lc.offF = (lane & 31);
+#endif
+#ifdef VN_ABL_BWD_W
+#pragma unroll
+  for (int m = 0; m < 4; ++m) lc.offB[m] = (lane & 31) + 64 * m;
+#endif
   lc.twr = 4 * lc.g * TSW + wave * CW + lc.c;
 
   // persistent weight-gradient accumulators
