@@ -44,7 +44,7 @@ enum {
   VN_ECOMM = 6     /* an RCCL call failed                                      */
 };
 
-enum { VN_ACT_SIGMOID = 0 };
+enum { VN_ACT_SIGMOID = 0, VN_ACT_TANH = 1 };   /* activationFun options of the constructor (VarNet.py:97) */
 enum { VN_OPT_ADAM = 0, VN_OPT_RMSPROP = 1 };   /* tf.train.AdamOptimizer / RMSPropOptimizer (TFModel.py:183-186) */
 enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 /* 4 waves, 32x32x2 */,
        VN_KERNEL_FUSED16 = 3 /* 8 waves, 16x16x4 */ };
@@ -57,7 +57,7 @@ typedef struct vn_config {
   int32_t d_in;                     /* network inputs (VarNet.py:174-180)                  */
   int32_t n_layers;                 /* hidden layers L                                     */
   int32_t widths[VN_MAX_LAYERS];    /* layerWidth                                          */
-  int32_t activation;               /* VN_ACT_SIGMOID                                      */
+  int32_t activation;               /* VN_ACT_SIGMOID | VN_ACT_TANH, all hidden layers alike */
   int32_t integ_num;                /* quadrature points per test function (FiniteElement.py:416) */
   int32_t time_dependent;           /* TFModel.py:537,646,655                              */
   int32_t has_source;               /* lossOpt['isSource']  (TFModel.py:656)               */

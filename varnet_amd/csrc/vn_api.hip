@@ -119,11 +119,13 @@ int build_net(const vn_config& c, VnNet& net) {
   if (c.d_in < 1 || c.d_in > VN_MAX_DIN) return fail(VN_EINVAL, "d_in=%d outside [1,%d]", c.d_in, VN_MAX_DIN);
   if (c.dim < 1 || c.dim > c.d_in) return fail(VN_EINVAL, "dim=%d must be in [1,d_in]", c.dim);
   if (c.integ_num < 1) return fail(VN_EINVAL, "integ_num must be positive");
-  if (c.activation != VN_ACT_SIGMOID) return fail(VN_EUNSUPPORTED, "only the sigmoid activation is implemented");
+  if (c.activation != VN_ACT_SIGMOID && c.activation != VN_ACT_TANH)
+    return fail(VN_EUNSUPPORTED, "activation must be sigmoid or tanh (VarNet.py:97)");
   if (c.optimizer != VN_OPT_ADAM && c.optimizer != VN_OPT_RMSPROP) return fail(VN_EINVAL, "unknown optimizer requested!");
   if (c.lr < 0.0) return fail(VN_EINVAL, "learning rate must be positive!");  // TFModel.py:130
   memset(&net, 0, sizeof net);
   net.d_in = c.d_in;
+  net.act = c.activation;
   net.dim = c.dim;
   net.L = c.n_layers;
   net.H[0] = c.d_in;

@@ -687,6 +687,7 @@ size_t vn_fused_lds_bytes(const VnNet& net) {
 }
 
 bool vn_fused_supported(const VnNet& net, int integ_num) {
+  if (net.act != VN_ACT_SIGMOID) return false;            // tanh: 8-wave kernel or generic path
   if (net.d_in > 2 * KS0) return false;
   if (integ_num < 1 || integ_num > TILE) return false;   // whole test functions must fit a tile
   const size_t b = vn_fused_lds_bytes(net);

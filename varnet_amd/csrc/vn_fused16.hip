@@ -91,6 +91,22 @@ __device__ __forceinline__ float opaque(float x) {
   return x;
 }
 
+// Activation (uniform over the hidden layers): sigmoid, or tanh = 2*sigmoid(2z) - 1 (VarNet.py:97).  Everything the
+// kernel needs is a function of the stored activation a:  sigma' = a(1-a) | 1-a^2,  sigma''/sigma' = 1-2a | -2a.
+template <bool TANH>
+__device__ __forceinline__ float act_exp(float z) {      // the exponential inside the sigmoid
+  return __builtin_amdgcn_exp2f((TANH ? -2.8853900817779268f : -1.4426950408889634f) * z);
+}
+template <bool TANH>
+__device__ __forceinline__ float act_fin(float e) {      // e = exp(-z) | exp(-2z)  ->  activation
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);
+  return TANH ? __builtin_fmaf(2.f, s, -1.f) : s;
+}
+template <bool TANH>
+__device__ __forceinline__ float act_d1(float a) { return TANH ? __builtin_fmaf(-a, a, 1.f) : a * (1.f - a); }
+template <bool TANH>
+__device__ __forceinline__ float act_d2r(float a) { return TANH ? -2.f * a : 1.f - 2.f * a; }
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -175,7 +191,7 @@ __device__ __forceinline__ void t_write(float* T, const LaneC& lc, int ks, float
 // Cooperative weight gradient (see vn_fused.hip): all waves publish their 16 point-columns of
 // the transposed operands, then each wave contracts its output tile(s) over its share of the
 // 128 points into persistent accumulators.
-template <int KSA, int KSB, bool RAWA, int NACC>
+template <int KSA, int KSB, bool RAWA, bool TANH, int NACC>
 __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float (&azd)[KSA],
                                             const float (&bv)[KSB], const float (&bt)[KSB], float* TA,
                                             float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC] STAMP_PARAMS) {
@@ -201,7 +217,7 @@ __device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float 
       else if (RAWA) v = azd[ks];
       else {
         const float x = opaque(av[ks]);
-        v = x * (1.f - x) * azd[ks];
+        v = act_d1<TANH>(x) * azd[ks];
       }
       t_write<KSA>(TA, lc, ks, v);
     }
@@ -283,7 +299,7 @@ __device__ __forceinline__ void thin_contract(const float* TA, const float* TB, 
 
 // output layer: rows = the KS*4 positions of a (and the bias row), one column ubar (lanes g == 0 publish it
 // into row 0, the other lane groups publish zeros into rows 4, 8, 12)
-template <int KS>
+template <int KS, bool TANH>
 __device__ __forceinline__ void thin_wgrad_out(const float (&av)[KS], const float (&azd)[KS], float ubar, float udbar,
                                                float* TA, float* TB, const LaneC& lc, int wave, int lane, f32x4& acc) {
   using W = WG<KS, 1>;
@@ -294,7 +310,7 @@ __device__ __forceinline__ void thin_wgrad_out(const float (&av)[KS], const floa
       float v = av[ks];
       if (half == 1) {
         const float x = opaque(av[ks]);
-        v = x * (1.f - x) * azd[ks];
+        v = act_d1<TANH>(x) * azd[ks];
       }
       t_write<KS>(TA, lc, ks, v);
     }
@@ -490,22 +506,23 @@ __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, c
   }
 }
 
-template <int KS_, int I>
+template <int KS_, int I, bool TANH>
 struct H13Pub {      // unrolled stores with compile-time offsets (inline-asm immediates)
   static __device__ __forceinline__ void run(int half, const float (&av)[13], const float (&azd)[13], const float (&bv)[13],
                                              const float (&bt)[13]) {
     float v = av[I];
     if (half == 1) {
       const float x = opaque(av[I]);
-      v = x * (1.f - x) * azd[I];
+      v = act_d1<TANH>(x) * azd[I];
     }
     addtid_store<I * H13::RS * 4>(v);
     addtid_store<(H13::TA_ROWS + I) * H13::RS * 4>(half == 0 ? bv[I] : bt[I]);
-    if constexpr (I + 1 < KS_) H13Pub<KS_, I + 1>::run(half, av, azd, bv, bt);
+    if constexpr (I + 1 < KS_) H13Pub<KS_, I + 1, TANH>::run(half, av, azd, bv, bt);
   }
 };
 
 // both rounds of a 50-wide hidden layer; t_base_bytes = byte address of this wave's 64 columns of TA
+template <bool TANH>
 __device__ __forceinline__ void h13_wgrad_layer(const float (&av)[13], const float (&azd)[13], const float (&bv)[13],
                                                 const float (&bt)[13], float* TA, const LaneC& lc, int wave, int lane,
                                                 unsigned t_base_bytes, f32x4 (&acc)[2] STAMP_PARAMS) {
@@ -513,7 +530,7 @@ __device__ __forceinline__ void h13_wgrad_layer(const float (&av)[13], const flo
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     addtid_base(t_base_bytes);
-    H13Pub<13, 0>::run(half, av, azd, bv, bt);
+    H13Pub<13, 0, TANH>::run(half, av, azd, bv, bt);
     addtid_store<13 * H13::RS * 4>((half == 0 && lc.g == 0) ? 1.f : 0.f);      // bias row | zeros
     addtid_drain();
     WSTAMP(2);
@@ -607,7 +624,7 @@ struct VnFusedArgsD {
   const float* seed_u; const float* seed_ud;
 };
 
-template <int L, int KS>
+template <int L, int KS, bool TANH>
 // The machine-level load/store optimizer pairs LDS reads into ds_read2_b32, whose 8-bit offsets force a
 // VALU address add per pair; vector instructions share the datapath with the f32 MFMAs here, LDS issue
 // does not, so pairing is switched off for this kernel (device pass only; -0.8 % kernel time).
@@ -817,8 +834,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       }
       auto zin = [&](int j) { return pv[j >> 2][j & 3]; };
       auto zdin = [&](int j) { return ptn[j >> 2][j & 3]; };
-      auto stA = [&](int j) { return __builtin_amdgcn_exp2f(-1.4426950408889634f * zin(j)); };
-      auto stB = [&](float e) { return __builtin_amdgcn_rcpf(1.0f + e); };
+      auto stA = [&](int j) { return act_exp<TANH>(zin(j)); };
+      auto stB = [&](float e) { return act_fin<TANH>(e); };
       float wf[MTM], we[NVE], ev[NVE], et[NVE];
 #pragma unroll
       for (int m = 0; m < MTM; ++m) wf[m] = Wl[lc.offF + 16 * m];
@@ -829,7 +846,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         et[v] = 0.f;
       }
       float cs = stB(stA(0));
-      float cq = cs * (1.f - cs) * zdin(0);
+      float cq = act_d1<TANH>(cs) * zdin(0);
       a[l - 2][0] = cs;
       zd[l - 2][0] = zdin(0);
       float s1 = (KS > 1) ? stB(stA(1)) : 0.f;
@@ -857,7 +874,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         if (ks + 2 < KS) s2 = stB(e2);
         if (ks + 1 < KS) {
           const float zz = zdin(ks + 1);
-          q1 = s1 * (1.f - s1) * zz;
+          q1 = act_d1<TANH>(s1) * zz;
           a[l - 2][ks + 1] = s1;
           zd[l - 2][ks + 1] = zz;
         }
@@ -886,7 +903,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      a[L - 1][ks] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * pv[ks >> 2][ks & 3]));
+      a[L - 1][ks] = act_fin<TANH>(act_exp<TANH>(pv[ks >> 2][ks & 3]));
       zd[L - 1][ks] = ptn[ks >> 2][ks & 3];
     }
     STAMP(1);
@@ -897,7 +914,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       const float wv = WO[4 * ks + lc.g];
       const float av = a[L - 1][ks];
       u += wv * av;
-      ud += wv * (av * (1.f - av) * zd[L - 1][ks]);
+      ud += wv * (act_d1<TANH>(av) * zd[L - 1][ks]);
     }
     u += __shfl_xor(u, 16, 64);  ud += __shfl_xor(ud, 16, 64);
     u += __shfl_xor(u, 32, 64);  ud += __shfl_xor(ud, 32, 64);
@@ -978,13 +995,13 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     for (int ks = 0; ks < KS; ++ks) {
       const float wv = WO[4 * ks + lc.g];
       const float av = opaque(a[L - 1][ks]);
-      const float sp = av * (1.f - av);
+      const float sp = act_d1<TANH>(av);
       const float ab = ubar * wv, adb = udbar * wv;
       zdb[ks] = adb * sp;
-      zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[L - 1][ks];
+      zb[ks] = ab * sp + adb * sp * act_d2r<TANH>(av) * zd[L - 1][ks];
     }
     STAMP(3);
-    thin_wgrad_out<KS>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0]);
+    thin_wgrad_out<KS, TANH>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0]);
     if constexpr (HID13) __syncthreads();    // the lane-major images of the hidden layers overlap other waves' columns
     STAMP(4);
 #pragma unroll
@@ -997,21 +1014,21 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         layer1_raw(xr, gr, rv, rt);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          a[0][ks] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * rv[ks >> 2][ks & 3]));
+          a[0][ks] = act_fin<TANH>(act_exp<TANH>(rv[ks >> 2][ks & 3]));
           zd[0][ks] = rt[ks >> 2][ks & 3];
         }
       }
       if constexpr (HID13) {
         if (l - 2 < LY::NST) {
           f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
-          h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, acc2 STAMP_ARGS);
+          h13_wgrad_layer<TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, acc2 STAMP_ARGS);
           stash[(l - 2) * ST_L] = acc2[0];
           stash[(l - 2) * ST_L + 64] = acc2[1];
         } else {
-          h13_wgrad_layer(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, wacch[l - 2] STAMP_ARGS);
+          h13_wgrad_layer<TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, wacch[l - 2] STAMP_ARGS);
         }
       }
-      else wgrad_layer<KS, KS, false>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
+      else wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
       STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
       f32x4 accv[MT], acct[MT];
@@ -1065,15 +1082,15 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const float av = opaque(a[l - 2][ks]);
-        const float sp = av * (1.f - av);
+        const float sp = act_d1<TANH>(av);
         const float ab = accv[ks >> 2][ks & 3], adb = acct[ks >> 2][ks & 3];
         zdb[ks] = adb * sp;
-        zb[ks] = ab * sp + adb * sp * (1.f - 2.f * av) * zd[l - 2][ks];
+        zb[ks] = ab * sp + adb * sp * act_d2r<TANH>(av) * zd[l - 2][ks];
       }
       STAMP(6);
     }
     if (thin_in) thin_wgrad_in<KS>(xin, gin, zb, zdb, TA, TB, lc, wave, lane, wacc1[0]);
-    else wgrad_layer<KS0, KS, true>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1 STAMP_ARGS);
+    else wgrad_layer<KS0, KS, true, TANH>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1 STAMP_ARGS);
     STAMP(7);
   }
 
@@ -1165,7 +1182,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   }
 }
 
-template <int L, int KS>
+template <int L, int KS, bool TANH>
 hipError_t launch_one(const VnFusedArgsD& a, int grid, hipStream_t s) {
   using LY = Lay<L, KS>;
   const size_t bytes = (size_t)LY::TOTAL * sizeof(float);
@@ -1176,12 +1193,12 @@ hipError_t launch_one(const VnFusedArgsD& a, int grid, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
   if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute((const void*)vn_fused16_kernel<L, KS>,
+    hipError_t e = hipFuncSetAttribute((const void*)vn_fused16_kernel<L, KS, TANH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     attr_done.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL((vn_fused16_kernel<L, KS>), dim3(grid), dim3(NTHREADS), bytes, s, a);
+  hipLaunchKernelGGL((vn_fused16_kernel<L, KS, TANH>), dim3(grid), dim3(NTHREADS), bytes, s, a);
   return hipGetLastError();
 }
 
@@ -1233,7 +1250,9 @@ hipError_t vn_fused16_launch(const VnFusedArgs& h, int grid, hipStream_t s) {
   a.mode = h.mode; a.dir = h.mode ? h.dir : -1; a.ostride = h.ostride; a.out_u = h.out_u; a.out_ud = h.out_ud;
   a.seed_u = h.seed_u; a.seed_ud = h.seed_ud;
   const int ks = pick_ks(h.net.hmax);
-#define X(LL, KK) if (h.net.L == LL && ks == KK) return launch_one<LL, KK>(a, grid, s);
+#define X(LL, KK)                                                                              \
+  if (h.net.L == LL && ks == KK)                                                                \
+    return h.net.act == VN_ACT_TANH ? launch_one<LL, KK, true>(a, grid, s) : launch_one<LL, KK, false>(a, grid, s);
   VN_FUSED16_CASES(X)
 #undef X
   return hipErrorInvalidValue;

@@ -18,9 +18,14 @@ constexpr int LDW = 81;       // LDS row stride (floats): 81 = 17 mod 32 keeps b
                               // and the transposed (weight-gradient) accesses conflict-free
 constexpr int NTHREADS = 256;
 
-__device__ __forceinline__ float vn_sigmoid(float z) {
+// activation and its derivatives as functions of the activation value a (runtime flag: these kernels are the
+// coverage path, not the fast one):  sigma' = a(1-a) | 1-a^2,  sigma''/sigma' = 1-2a | -2a
+__device__ __forceinline__ float vn_act(float z, int act) {
+  if (act == VN_ACT_TANH) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * z)) - 1.0f;
   return __builtin_amdgcn_rcpf(1.0f + __expf(-z));
 }
+__device__ __forceinline__ float vn_d1(float a, int act) { return act == VN_ACT_TANH ? 1.f - a * a : a * (1.f - a); }
+__device__ __forceinline__ float vn_d2r(float a, int act) { return act == VN_ACT_TANH ? -2.f * a : 1.f - 2.f * a; }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -107,10 +112,10 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_fwd_kernel(VnNet net, con
       __syncthreads();
       for (int i = tid; i < Hout * TP; i += NTHREADS) {
         const int m = i / TP, c = i % TP;
-        const float a = vn_sigmoid(nxt[m * LDW + c] + bias[m]);
+        const float a = vn_act(nxt[m * LDW + c] + bias[m], net.act);
         const float zd = nxt[m * LDW + TP + c];
         nxt[m * LDW + c] = a;
-        nxt[m * LDW + TP + c] = a * (1.f - a) * zd;
+        nxt[m * LDW + TP + c] = vn_d1(a, net.act) * zd;
       }
       __syncthreads();
       float* t = cur; cur = nxt; nxt = t;
@@ -183,13 +188,13 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
                     const float v = cur[k * LDW + c];
                     if (raw || c < TP) return v;
                     const float a = cur[k * LDW + c - TP];
-                    return a * (1.f - a) * v;
+                    return vn_d1(a, net.act) * v;
                   },
                   [&](int r, int c, float v) { nxt[r * LDW + c] = v; });
       __syncthreads();
       for (int i = tid; i < Hout * TP; i += NTHREADS) {
         const int m = i / TP, c = i % TP;
-        nxt[m * LDW + c] = vn_sigmoid(nxt[m * LDW + c] + bias[m]);
+        nxt[m * LDW + c] = vn_act(nxt[m * LDW + c] + bias[m], net.act);
       }
       __syncthreads();
     }
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
         float acc = 0.f;
         for (int c = 0; c < TP; ++c) {
           const float a = SL[tid * LDW + c], zd = SL[tid * LDW + TP + c];
-          acc += sub[c] * a + sudb[c] * (a * (1.f - a) * zd);
+          acc += sub[c] * a + sudb[c] * (vn_d1(a, net.act) * zd);
         }
         woacc += acc;
       }
@@ -215,10 +220,10 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
       for (int i = tid; i < HL * TP; i += NTHREADS) {
         const int n = i / TP, c = i % TP;
         const float a = SL[n * LDW + c], zd = SL[n * LDW + TP + c];
-        const float sp = a * (1.f - a);
+        const float sp = vn_d1(a, net.act);
         const float ab = sub[c] * wo[n], adb = sudb[c] * wo[n];
         T[n * LDW + TP + c] = adb * sp;
-        T[n * LDW + c] = ab * sp + adb * sp * (1.f - 2.f * a) * zd;
+        T[n * LDW + c] = ab * sp + adb * sp * vn_d2r(a, net.act) * zd;
       }
     }
     __syncthreads();
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
                 av = prev[m * LDW + c];
                 if (!raw && c >= TP) {
                   const float a = prev[m * LDW + c - TP];
-                  av = a * (1.f - a) * av;
+                  av = vn_d1(a, net.act) * av;
                 }
               }
               if (n < Hout) bv = T[n * LDW + c];
@@ -275,10 +280,10 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
           for (int i = tid; i < Hin * TP; i += NTHREADS) {
             const int n = i / TP, c = i % TP;
             const float a = prev[n * LDW + c], zd = prev[n * LDW + TP + c];
-            const float sp = a * (1.f - a);
+            const float sp = vn_d1(a, net.act);
             const float ab = dst[n * LDW + c], adb = dst[n * LDW + TP + c];
             T[n * LDW + TP + c] = adb * sp;
-            T[n * LDW + c] = ab * sp + adb * sp * (1.f - 2.f * a) * zd;
+            T[n * LDW + c] = ab * sp + adb * sp * vn_d2r(a, net.act) * zd;
           }
         }
         __syncthreads();

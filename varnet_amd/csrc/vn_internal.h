@@ -8,6 +8,7 @@
 // (sigmoid) layers, l = L+1 is the linear output layer; H[0] = d_in, H[L+1] = 1.
 struct VnNet {
   int d_in, dim, L, P, hmax;
+  int act;                       // VN_ACT_SIGMOID | VN_ACT_TANH, uniform over the hidden layers
   int H[VN_MAX_LAYERS + 2];
   int woff[VN_MAX_LAYERS + 2];   // offset of W_l (row-major [H[l-1], H[l]]) in the flat vector
   int boff[VN_MAX_LAYERS + 2];   // offset of b_l

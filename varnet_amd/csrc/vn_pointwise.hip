@@ -10,9 +10,13 @@ namespace {
 constexpr int PT = 64;   // threads per workgroup
 constexpr int HM = VN_MAX_WIDTH > VN_MAX_DIN ? VN_MAX_WIDTH : VN_MAX_DIN;
 
-template <typename T> __device__ __forceinline__ T sig(T z);
-template <> __device__ __forceinline__ float sig<float>(float z) { return 1.0f / (1.0f + expf(-z)); }
-template <> __device__ __forceinline__ double sig<double>(double z) { return 1.0 / (1.0 + exp(-z)); }
+template <typename T> __device__ __forceinline__ T sig(T z, int act);
+template <> __device__ __forceinline__ float sig<float>(float z, int act) {
+  return act == VN_ACT_TANH ? tanhf(z) : 1.0f / (1.0f + expf(-z));
+}
+template <> __device__ __forceinline__ double sig<double>(double z, int act) {
+  return act == VN_ACT_TANH ? tanh(z) : 1.0 / (1.0 + exp(-z));
+}
 
 template <typename T>
 __global__ __launch_bounds__(PT) void vn_pw_forward(VnNet net, const T* __restrict__ theta,
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(PT) void vn_pw_forward(VnNet net, const T* __restri
       const T ak = a[k];
       for (int j = 0; j < Hout; ++j) z[j] += ak * W[k * Hout + j];
     }
-    for (int j = 0; j < Hout; ++j) a[j] = sig<T>(z[j]);
+    for (int j = 0; j < Hout; ++j) a[j] = sig<T>(z[j], net.act);
   }
   const T* wo = theta + net.woff[net.L + 1];
   T acc = theta[net.boff[net.L + 1]];
@@ -77,9 +81,9 @@ __global__ __launch_bounds__(PT) void vn_pw_residual(VnNet net, const T* __restr
       }
     }
     for (int j = 0; j < Hout; ++j) {
-      const T s = sig<T>(z[j]);
-      const T s1 = s * (T(1) - s);
-      const T s2 = s1 * (T(1) - T(2) * s);
+      const T s = sig<T>(z[j], net.act);
+      const T s1 = net.act == VN_ACT_TANH ? T(1) - s * s : s * (T(1) - s);
+      const T s2 = net.act == VN_ACT_TANH ? s1 * (T(-2) * s) : s1 * (T(1) - T(2) * s);
       a[j] = s;
       for (int d = 0; d < dim; ++d) d2[d][j] = s2 * z1[d][j] * z1[d][j] + s1 * z2[d][j];
       for (int d = 0; d < nd1; ++d) d1[d][j] = s1 * z1[d][j];

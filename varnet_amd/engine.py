@@ -129,9 +129,10 @@ class VNEngine:
             raise VNError('no GPU visible: the VarNet HIP engine has no CPU fallback')
         act = activationFun[0] if isinstance(activationFun, (list, tuple)) else activationFun
         if isinstance(activationFun, (list, tuple)) and any(a != act for a in activationFun):
-            raise ValueError('mixed activation functions are not supported')
-        if act != 'sigmoid':
-            raise ValueError('only the sigmoid activation is implemented')
+            raise ValueError('one activation function for all hidden layers: per-layer lists must be uniform')
+        act = str(act).lower()
+        if act not in ('sigmoid', 'tanh'):
+            raise ValueError('activation function must be \'sigmoid\' or \'tanh\' (VarNet.py:97)')
         if optimizer_name.lower() not in ('adam', 'rmsprop'):
             raise ValueError('unknown optimizer requested!')           # TFModel.py:133-134
         if learning_rate < 0.0:
@@ -142,7 +143,7 @@ class VNEngine:
         cfg.dim, cfg.d_in, cfg.n_layers = dim, inpDim, len(layerWidth)
         for i, wd in enumerate(layerWidth):
             cfg.widths[i] = int(wd)
-        cfg.activation = 0
+        cfg.activation = 1 if act == 'tanh' else 0
         cfg.integ_num = int(integNum)
         cfg.time_dependent = int(bool(timeDependent))
         cfg.has_source = int(bool(isSource))
