@@ -21,8 +21,8 @@ def synth(seed, d_in, dim, widths, integNum, n_k, nB, bDof, source=False, integW
     return d
 
 
-def make_engine(d_in, dim, widths, integNum, source, integW, kernel=0):
-    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel)
+def make_engine(d_in, dim, widths, integNum, source, integW, kernel=0, act='sigmoid'):
+    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel, activationFun=act)
 
 
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -30,10 +30,11 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = 0.0
 for case in range(ncases):
     L = int(rng.integers(1, 7))
+    act = 'tanh' if rng.random() < 0.3 else 'sigmoid'
     if rng.random() < 0.5:
-        widths = [int(rng.choice([7, 10, 20, 30, 32, 33, 40, 48, 49, 50]))] * L
+        widths = [int(rng.choice([7, 10, 20, 30, 32, 33, 40, 48, 49, 50, 51, 56, 60, 63, 64]))] * L
     else:
-        widths = [int(rng.integers(1, 51)) for _ in range(L)]
+        widths = [int(rng.integers(1, 65)) for _ in range(L)]
     dim = int(rng.integers(1, 4)); td = True
     d_in = dim + 1 + int(rng.integers(0, 2))
     q = int(rng.choice([4, 8, 16, 27, 32, 36, 64, 128, 216, 256, 1296]))     # 256: 3D+t 2-point, 1296: 3D+t 3-point Gauss
@@ -45,7 +46,7 @@ for case in range(ncases):
     rows = bool(rng.random() < 0.2)
     grads = []
     for kernel in (1, 0):
-        eng = make_engine(d_in, dim, widths, q, src, iw, kernel)
+        eng = make_engine(d_in, dim, widths, q, src, iw, kernel, act)
         eng.init_params(seed=case)
         flat = eng.get_params() + 0.05 * np.random.default_rng(case).standard_normal(eng.P).astype(np.float32)
         eng.set_params(flat)
@@ -61,7 +62,7 @@ for case in range(ncases):
     lerr = abs(g1[P] - g0[P]) / max(abs(g0[P]), 1e-30)
     worst = max(worst, err, lerr)
     flag = '' if (err < 3e-4 and lerr < 5e-5) else '   <<<<<<<< MISMATCH'
-    print('case %3d L=%d widths=%s d_in=%d dim=%d q=%d n_k=%d nB=%d src=%d iw=%d djv=%d rows=%d: grad %.1e loss %.1e%s'
-          % (case, L, widths, d_in, dim, q, n_k, nB, src, iw, djv, rows, err, lerr, flag), flush=True)
+    print('case %3d %s L=%d widths=%s d_in=%d dim=%d q=%d n_k=%d nB=%d src=%d iw=%d djv=%d rows=%d: grad %.1e loss %.1e%s'
+          % (case, act, L, widths, d_in, dim, q, n_k, nB, src, iw, djv, rows, err, lerr, flag), flush=True)
     if flag: sys.exit(1)
 print('all %d cases agree; worst relative deviation %.2e' % (ncases, worst))

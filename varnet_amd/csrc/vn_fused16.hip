@@ -51,11 +51,16 @@ __host__ __device__ constexpr int al4(int x) { return (x + 3) & ~3; }
 __host__ __device__ constexpr int vpos(int ks, int g) { return 16 * (ks >> 2) + 4 * g + (ks & 3); }
 __host__ __device__ constexpr int vks(int pos) { return 4 * (pos >> 4) + (pos & 3); }
 __host__ __device__ constexpr int vfeat(int pos) { return 4 * vks(pos) + ((pos >> 2) & 3); }
+// Position of the constant-one row that carries the bias gradient: the first position past the layer's k-steps.
+// KS == 16 (widths 51..63) has no position to spare, so the row of feature 63 -- which such a layer does not have --
+// is used; a 64-wide layer therefore stays on the generic kernels.
 __host__ __device__ constexpr int vones(int KS) {
+  if (KS == 16) return 63;
   for (int p = 0; p < 64; ++p)
     if (vks(p) >= KS) return p;
   return -1;
 }
+static_assert(vfeat(63) == 63, "position 63 is feature 63");
 __host__ __device__ constexpr int mtiles(int KS) { return (KS + 3) / 4; }
 
 template <int L, int KS>
@@ -82,7 +87,7 @@ struct Lay {
   static constexpr int ST_OFF = T_OFF + T_SZ;
   static constexpr int ST_LAYER = NW * 2 * 64 * 4;
   static constexpr int ST_FIT = (160 * 256 - ST_OFF) / ST_LAYER;
-  static constexpr int NST = (KS != 13 || L < 2) ? 0 : (ST_FIT < L - 1 ? ST_FIT : L - 1);
+  static constexpr int NST = ((KS != 13 && KS != 16) || L < 3) ? 0 : (ST_FIT < L - 1 ? ST_FIT : L - 1);
   static constexpr int TOTAL = ST_OFF + NST * ST_LAYER;
 };
 
@@ -328,8 +333,8 @@ __device__ __forceinline__ void thin_flush_out(const f32x4& acc, float* Gl, int 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int pos = lane + i;
-    if (vks(pos) < KS) Gl[vfeat(pos)] += acc[i];
-    else if (pos == vones(KS)) Gl[4 * KS] += acc[i];
+    if (pos == vones(KS)) Gl[4 * KS] += acc[i];
+    else if (vks(pos) < KS) Gl[vfeat(pos)] += acc[i];
   }
 }
 
@@ -594,8 +599,8 @@ __device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl,
     for (int i = 0; i < 4; ++i) {
       const int ks = 4 * m + i;
       int row = -1;
-      if (ks < KSA) row = 4 * ks + lc.g;
-      else if (m == W::ones_m && i == W::ones_i && lc.g == W::ones_g) row = 4 * KSA;
+      if (m == W::ones_m && i == W::ones_i && lc.g == W::ones_g) row = 4 * KSA;
+      else if (ks < KSA) row = 4 * ks + lc.g;
       if (row >= 0 && colok) Gl[row * GS + col] += acc[t][i];
     }
   }
@@ -1028,6 +1033,16 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
           h13_wgrad_layer<TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, wacch[l - 2] STAMP_ARGS);
         }
       }
+      else if constexpr (NHACC == 2) {
+        if (l - 2 < LY::NST) {               // accumulators of this layer live in the LDS stash between tiles
+          f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
+          wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, acc2 STAMP_ARGS);
+          stash[(l - 2) * ST_L] = acc2[0];
+          stash[(l - 2) * ST_L + 64] = acc2[1];
+        } else {
+          wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
+        }
+      }
       else wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
       STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
@@ -1144,8 +1159,16 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       }
       if (sh == r) {
 #pragma unroll
-        for (int l = 2; l <= L; ++l)
+        for (int l = 2; l <= L; ++l) {
+          if constexpr (NHACC == 2) {
+            if (l - 2 < LY::NST) {
+              const f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
+              wgrad_flush<KS, KS, LY::HP>(acc2, Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
+              continue;
+            }
+          }
           wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
+        }
       }
       if (wave == r) thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
       __syncthreads();
@@ -1211,6 +1234,7 @@ int pick_ks(int hmax) {
   if (hmax <= 20) return 5;
   if (hmax <= 32) return 8;
   if (hmax <= 50) return 13;      // NVE == 2: the edge k-step carries features 48, 49 only
+  if (hmax <= 63) return 16;      // the bias gradient rides in the row of (absent) feature 63
   return 0;
 }
 
@@ -1219,7 +1243,8 @@ int pick_ks(int hmax) {
 #define VN_FUSED16_CASES(X) \
   X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(6, 5)   \
   X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8)   \
-  X(2, 13) X(3, 13) X(4, 13) X(5, 13)
+  X(2, 13) X(3, 13) X(4, 13) X(5, 13)       \
+  X(2, 16) X(3, 16) X(4, 16) X(5, 16)
 
 size_t vn_fused16_lds_bytes(const VnNet& net) {
   const int ks = pick_ks(net.hmax);
