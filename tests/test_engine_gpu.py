@@ -91,6 +91,11 @@ CASES = [
     (3, 2, [50, 50, 50],         36,      17,  12,  5,   False, True,  True),
     (3, 2, [50, 50, 50],         216,     7,   40,  22,  True,  True,  False),   # 3-point Gauss, 2D+t: two-pass fused
     (3, 2, [20, 20, 20, 20],     216,     5,   9,   4,   False, True,  True),
+    (3, 2, [60, 60, 60, 60],     64,      30,  50,  20,  False, False, False),   # widths 51..63: KS = 16 fused tiles
+    (3, 2, [51, 63, 57],         36,      17,  12,  5,   True,  True,  True),
+    (2, 1, [63, 63],             16,      90,  33,  11,  True,  False, False),
+    (3, 2, [60, 60, 60, 60, 60], 64,      9,   77,  40,  False, False, False),
+    (3, 2, [64, 64],             64,      6,   20,  8,   False, False, False),   # 64 wide: generic kernels
 ]
 
 
@@ -99,7 +104,7 @@ def _skip_unsupported(kernel, widths, integNum):
                         (max(widths) > 20 and len(widths) < 2) or (max(widths) > 32 and len(widths) < 3) or
                         len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused32 not instantiated for this shape')
-    if kernel == 3 and (max(widths) > 50 or len(widths) < 2 or          # integNum > 128: two-pass fused route
+    if kernel == 3 and (max(widths) > 63 or len(widths) < 2 or          # integNum > 128: two-pass fused route
                         len(widths) > (5 if max(widths) > 32 else 6)):
         pytest.skip('fused16 not instantiated for this shape')
 
