@@ -130,6 +130,31 @@ def main():
     mo['m2_argInd'] = mor2.argIndex(da2)
     mo['m2_names1'] = np.array(mor2.ArgNames[1])
     np.savez_compressed(os.path.join(OUT, 'mor.npz'), **mo)
+
+    # (9) ContourPlot: plotting grid and the field arrays conPlot / snap1Dt draw (ContourPlot.py:55-296);
+    #     matplotlib runs on the Agg backend, only the returned arrays are kept
+    import ContourPlot as RC
+    import matplotlib.pyplot as plt
+    cp = {}
+    verts = np.array([[0.0, -0.5], [0.0, -0.2], [0.0, 0.2], [0.0, 0.5], [2.0, 0.5], [2.0, -0.5]])
+    obs = [np.array([[0.5, -0.2], [0.8, -0.2], [0.8, 0.1], [0.5, 0.1]])]
+    f2 = lambda x, t=0.0: (np.sin(3 * x[:, 0:1]) * np.cos(2 * x[:, 1:2]) + t)
+    f1 = lambda x, t: np.sin(np.pi * x) * np.exp(-t)
+    for key, dom, tI in (('2dt', RD.PolygonDomain2D(verts), [0, 1.5]), ('2d', RD.PolygonDomain2D(verts), None),
+                         ('2dobs', RD.PolygonDomain2D(verts, obs), [0, 1.5]), ('1dt', RD.Domain1D(), [0, 2.0])):
+        c = RC.ContourPlot(dom, tI)
+        cp[key + '_X'], cp[key + '_Y'], cp[key + '_out'], cp[key + '_he'] = c.X_coord, c.Y_coord, c.isOutside, c.he
+        cp[key + '_xx'], cp[key + '_yy'] = c.xx, c.yy
+        if key == '1dt':
+            cp[key + '_field'] = c.conPlot(f1)
+            c.snap1Dt(f1, 0.7)
+            cp[key + '_snap'] = f1(c.x_coord, 0.7)
+        elif key == '2d':
+            cp[key + '_field'] = c.conPlot(f2)
+        else:
+            cp[key + '_field'] = c.conPlot(f2, 0.4, fill_val=-7.0)
+        plt.close('all')
+    np.savez_compressed(os.path.join(OUT, 'contour.npz'), **cp)
     print('golden fixtures written to', OUT)
 
 

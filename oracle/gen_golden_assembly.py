@@ -172,6 +172,39 @@ def main():
     vn_s = RV.VarNet(pde1(td=False), layerWidth=[5], discNum=7, bDiscNum=None, tDiscNum=[], integPnum=2)
     record(st, '1d_steady', vn_s, RVU, None, None, 1)
 
+    # MOR batches (Operator_1DtMOR.py:166-204 in small): kappa as third network input, 3 values; the reference walks
+    # the batches through trainData(batch, MORdiscArg, tData) -- first pass computes, with saveMORdata=True the
+    # second pass reloads the stored fields (VarNetUtility.py:660-752).  Recorded per batch: what the towers are fed.
+    import MOR as RM
+
+    def diffFun(x, t=0, D=0.01):
+        return D * np.ones([np.shape(x)[0], 1])
+
+    def disc(discNum=3):
+        return np.array([0.003 * (11 ** (n / (discNum - 1))) for n in range(discNum)])[np.newaxis].T
+
+    for save in (False, True):
+        PU[0] = 1
+        mor = RM.MOR(diffFun, ['D'], [[0.003, 0.033]])
+        pde_m = RA.ADPDE(RD.Domain1D(), diff=diffFun, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                         IC=lambda x: -np.sin(np.pi * x), MORvar=mor)
+        vn_m = RV.VarNet(pde_m, layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, MORdiscScheme=disc, integPnum=2)
+        vn_m.tfData = TowerRecord()
+        fdm = vn_m.fixData
+        fdm.setFEdata()
+        Input, _, biInput, biDof = vn_m.trainingPoints('uniform')
+        tD = RVU.ManageTrainData(Input, biInput, batchNum=2, saveMORdata=save, MORbatchNum=fdm.MORbatchNum)
+        for rnd in range(2):                               # second round: the stored-data path when save=True
+            for b in range(fdm.MORbatchNum):
+                tD = vn_m.trainData(b, fdm.MORdiscArg, tD)
+                InpuTot, biInpuTot, biLabel, gcoef, sourceVal = tD.getTrainData()
+                g = '1dt_mor_save%d_r%d_b%d_' % (int(save), rnd, b)
+                st[g + 'Input'], st[g + 'biInput'], st[g + 'biLabel'], st[g + 'gcoef'] = InpuTot, biInpuTot, biLabel, gcoef
+                fd0 = tD.optimFeedicts[1][vn_m.tfData.compTowers[0].Input]
+                st[g + 'mb1_Input'] = fd0
+        st['1dt_mor_scalars'] = np.array([fdm.MORbatchNum, fdm.nt, fdm.integNum, tD.batchNum, tD.batchLen], dtype=float)
+        st['1dt_mor_disc'] = fdm.MORdiscArg[0]
+
     # (8) trainWeight arithmetic: the three branches on fixed loss triples, time-dependent and steady
     triples = np.array([[0.37, 1.9, 42.0], [1e-3, 5.0, 0.2], [12.5, 0.04, 3.3e3]])
     weights = [[10., 10., 1.], [5., 1., 1.], [1., 2., 3.]]

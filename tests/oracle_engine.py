@@ -47,13 +47,17 @@ class OracleEngine:
         self.theta = np.asarray(flat).astype(self.dtype)
 
     def export_state(self):
-        return np.concatenate([[self.adam.t], self.theta, self.adam.m, self.adam.v]).astype(np.float64).view(np.uint8)
+        # the C ABI's layout (include/varnet_hip.h, vn_state_export): int64 step, then theta, m, v as float32
+        step = np.array([self.adam.t], dtype=np.int64).view(np.uint8)
+        body = np.concatenate([self.theta, self.adam.m, self.adam.v]).astype(np.float32).view(np.uint8)
+        return np.concatenate([step, body])
 
     def import_state(self, buf):
-        a = np.asarray(buf, dtype=np.uint8).view(np.float64)
+        buf = np.asarray(buf, dtype=np.uint8)
         P = self.P
-        self.adam.t = int(a[0])
-        self.theta, self.adam.m, self.adam.v = a[1:1 + P].copy(), a[1 + P:1 + 2 * P].copy(), a[1 + 2 * P:].copy()
+        self.adam.t = int(buf[:8].view(np.int64)[0])
+        a = buf[8:].view(np.float32).astype(self.dtype)
+        self.theta, self.adam.m, self.adam.v = a[:P].copy(), a[P:2 * P].copy(), a[2 * P:3 * P].copy()
 
     @property
     def step(self):

@@ -167,3 +167,38 @@ def test_train_weight_matches_reference(name):
                     continue
                 np.testing.assert_allclose(trainW, ref, rtol=1e-14)
     assert n_nan == (9 if name == 'td' else 0)
+
+
+def test_mor_batches_match_reference():
+    """MOR (kappa as a network input, 3 values) with mini-batches: every kappa-batch the reference walks through
+    `trainData(batch, ...)` -- computed (first pass) or reloaded from the saveMORdata store (second pass) -- equals
+    the device-resident batch the build registers up front (rows f2 / a7 of the scope table)."""
+    from varnet_amd.mor import MOR
+
+    def diffFun(x, t=0, D=0.01):
+        return D * np.ones([np.shape(x)[0], 1])
+
+    def disc(discNum=3):
+        return np.array([0.003 * (11 ** (n / (discNum - 1))) for n in range(discNum)])[np.newaxis].T
+
+    mor = MOR(diffFun, ['D'], [[0.003, 0.033]])
+    pde = ADPDE(Domain1D(), diff=diffFun, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                IC=lambda x: -np.sin(np.pi * x), MORvar=mor)
+    vn = VarNet(pde, layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, MORdiscScheme=disc, integPnum=2)
+    fd = vn.fixData
+    td = vn._build_tdata(batchNum=2)
+    sc = G['1dt_mor_scalars']
+    assert (fd.MORbatchNum, fd.nt, fd.integNum, td.batchNum, td.batchLen) == tuple(int(v) for v in sc)
+    np.testing.assert_allclose(fd.MORdiscArg[0], G['1dt_mor_disc'], rtol=1e-15)
+    q = fd.integNum
+    for save in (0, 1):
+        for rnd in (0, 1):
+            for b in range(3):
+                g = '1dt_mor_save%d_r%d_b%d_' % (save, rnd, b)
+                d = td.mor[b]
+                np.testing.assert_allclose(d['Input_host'], G[g + 'Input'], **TOL)
+                np.testing.assert_allclose(npy(d['biInput']), G[g + 'biInput'], **TOL)
+                np.testing.assert_allclose(npy(d['biLabel']).reshape(-1, 1), G[g + 'biLabel'], **TOL)
+                np.testing.assert_allclose(npy(d['gcoef']), G[g + 'gcoef'], **TOL)
+                Inp = vn.engine.batches[td.engine_batch(b, 1)][0]             # second mini-batch of kappa-batch b
+                np.testing.assert_allclose(Inp.reshape(-1, 3), G[g + 'mb1_Input'], **TOL)

@@ -147,3 +147,32 @@ def test_mor_matches_reference():
     assert list(g['m2_names1']) == mor2.ArgNames[1]
     with pytest.raises(ValueError):
         MOR(diffFun, ['nope'], [[0, 1]])
+
+
+def test_contour_grid_and_fields_match_reference():
+    """varnet_amd.ContourPlot reproduces the reference's plotting grid and the arrays conPlot / snap1Dt draw
+    (ContourPlot.py:55-296; fixture from the reference's own module, Agg backend)."""
+    from varnet_amd.contour import ContourPlot
+    GD = globals()['G']
+    G = np.load(os.path.join(GD, 'contour.npz'))
+    verts = np.array([[0.0, -0.5], [0.0, -0.2], [0.0, 0.2], [0.0, 0.5], [2.0, 0.5], [2.0, -0.5]])
+    obs = [np.array([[0.5, -0.2], [0.8, -0.2], [0.8, 0.1], [0.5, 0.1]])]
+    f2 = lambda x, t=0.0: (np.sin(3 * x[:, 0:1]) * np.cos(2 * x[:, 1:2]) + t)
+    f1 = lambda x, t: np.sin(np.pi * x) * np.exp(-t)
+    for key, dom, tI in (('2dt', PolygonDomain2D(verts), [0, 1.5]), ('2d', PolygonDomain2D(verts), None),
+                         ('2dobs', PolygonDomain2D(verts, obs), [0, 1.5]), ('1dt', Domain1D(), [0, 2.0])):
+        c = ContourPlot(dom, tI)
+        np.testing.assert_allclose(c.X_coord, G[key + '_X'], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(c.Y_coord, G[key + '_Y'], rtol=0, atol=1e-15)
+        np.testing.assert_array_equal(c.isOutside, G[key + '_out'])
+        np.testing.assert_allclose(c.he, G[key + '_he'], rtol=1e-15)
+        np.testing.assert_allclose(c.xx, G[key + '_xx'], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(c.yy, G[key + '_yy'], rtol=0, atol=1e-15)
+        if key == '1dt':
+            np.testing.assert_allclose(c.field(f1), G[key + '_field'], rtol=1e-14, atol=1e-15)
+            np.testing.assert_allclose(c.snap(f1, 0.7)[1], G[key + '_snap'], rtol=1e-14, atol=1e-15)
+        elif key == '2d':
+            np.testing.assert_allclose(c.field(f2), G[key + '_field'], rtol=1e-14, atol=1e-15)
+        else:
+            np.testing.assert_allclose(c.field(f2, 0.4, fill_val=-7.0), G[key + '_field'], rtol=1e-14, atol=1e-15)
+    assert G['2dobs_out'].sum() > G['2dt_out'].sum()          # the obstacle really masks grid points

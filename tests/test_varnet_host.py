@@ -330,3 +330,71 @@ def test_optimal_sampling_training(tmp_path, addTrainPts, suppFactor):
     assert np.isfinite(res.lossAll).all()
     # weights were re-derived with 5x on BC/IC (adjustWeight) and renormalised to 1e6
     np.testing.assert_allclose(res.lossAll[5], 1e6, rtol=1e-6)
+
+
+def test_simres_returns_the_fields_the_reference_plots(tmp_path):
+    """simRes (VarNet.py:1970-2175) without a display: arrays on the ContourPlot grid, consistent with
+    evaluate / residual / cEx, plus the reference's figure file names when plot=True."""
+    vn = op1dt(layerWidth=[6, 6], discNum=6, tDiscNum=8, cEx=cExact)
+    vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=4, saveFreq=2, verbose=False)
+    out = vn.simRes()
+    assert out['t'] == [0.0, 0.5, 1.0, 1.5, 2.0] and len(out['cApp']) == 5
+    x = out['grid'].x_coord
+    assert x.shape == (51, 1) and out['cApp'][2].shape == (51, 1)
+    np.testing.assert_allclose(out['cApp'][2], vn.evaluate(x, 1.0), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out['cEx'][3], cExact(x, 1.5 * np.ones([51, 1])), rtol=1e-12)
+    np.testing.assert_allclose(out['cErr'][1], out['cEx'][1] - out['cApp'][1], rtol=0, atol=1e-12)
+    _, rv, _, _ = vn.residual(np.hstack([x, 0.5 * np.ones([51, 1])]))
+    np.testing.assert_allclose(out['res'][1], rv, rtol=0, atol=1e-10)
+    assert len(out['l2Err']) == 5 and 'lossField' in out and out['lossField'][0].shape == (51, 1)
+    vn.simRes(plot=True)
+    files = set(os.listdir(os.path.join(str(tmp_path), 'plots')))
+    assert {'cApp-t=0.50s.png', 'cErr.png', 'residual.png', 'lossField.png'} <= files
+    with pytest.raises(ValueError):
+        vn.simRes(pltFrmt='bmp')
+
+
+def test_simres_2d_fields(tmp_path):
+    vn = op2dt(discNum=[6, 4], bDiscNum=4, tDiscNum=3, layerWidth=[5])
+    out = vn.simRes(tcoord=[0.3, 1.2])
+    assert out['cApp'][0].shape == (51, 51) and out['res'][1].shape == (51, 51) and 'cEx' not in out
+    cp = out['grid']
+    X = np.concatenate([cp.X_coord, cp.Y_coord], axis=1)
+    ref = vn.evaluate(X, 1.2).reshape(51, 51)
+    ref[cp.isOutside.reshape(51, 51)] = 0.0
+    np.testing.assert_allclose(out['cApp'][1], ref, rtol=0, atol=1e-12)
+
+
+def test_checkpoint_uses_tf_variable_names_and_round_trips(tmp_path):
+    """best_model-<n>.npz holds what tf.train.Saver stores for this graph, under the TF names
+    (TFModel.py:208-242, 307): kernels [in,out], biases, Adam slots, beta powers, step."""
+    vn = op1dt(layerWidth=[6, 5], discNum=5, tDiscNum=6)
+    vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=6, saveFreq=2, verbose=False)
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('best_model-'))
+    assert len(files) <= 2 and all(f.endswith('.npz') for f in files)           # max_to_keep = 2
+    z = np.load(os.path.join(str(tmp_path), files[-1]))
+    names = set(z.files)
+    for v in ('dense_0', 'dense_1', 'output'):
+        assert {v + '/kernel', v + '/bias', v + '/kernel/Adam', v + '/kernel/Adam_1', v + '/bias/Adam_1'} <= names
+    assert z['dense_0/kernel'].shape == (2, 6) and z['dense_1/kernel'].shape == (6, 5) and z['output/kernel'].shape == (5, 1)
+    assert {'global_step', 'beta1_power', 'beta2_power'} <= names
+    txt = open(os.path.join(str(tmp_path), 'checkpoint')).read()
+    assert txt.startswith('model_checkpoint_path: ') and 'all_model_checkpoint_paths: ' in txt and 'best_model-' in txt
+    before = vn.engine.export_state().copy()
+    n = int(files[-1][len('best_model-'):-4])
+    step_saved = int(z['global_step'])
+    vn.engine.init_params(seed=9)
+    assert vn.loadModel() == n and vn.engine.step == step_saved
+    arr = vn.checkpoint_arrays()
+    np.testing.assert_array_equal(arr['dense_1/kernel'], z['dense_1/kernel'])
+    np.testing.assert_array_equal(arr['output/bias/Adam'], z['output/bias/Adam'])
+    # a folder that only holds TF saver files is reported as such, not as "nothing found"
+    d2 = tmp_path / 'tfonly'
+    d2.mkdir()
+    (d2 / 'best_model-100.index').write_bytes(b'')
+    with pytest.raises(ValueError, match='TensorFlow saver files'):
+        vn.loadModel(folderpath=str(d2))
+    with pytest.raises(ValueError, match='no restorable'):
+        d3 = tmp_path / 'empty'
+        d3.mkdir()
+        vn.loadModel(folderpath=str(d3))

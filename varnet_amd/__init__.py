@@ -18,6 +18,7 @@ from .domain import Domain, Domain1D, PolygonDomain2D, Mesh
 from .adpde import ADPDE
 from .mor import MOR
 from .varnet import VarNet, FIXData, ManageTrainData, TrainResult
+from .contour import ContourPlot
 
 __all__ = ['UF', 'FE', 'Domain', 'Domain1D', 'PolygonDomain2D', 'Mesh', 'ADPDE', 'MOR', 'VarNet',
-           'FIXData', 'ManageTrainData', 'TrainResult']
+           'FIXData', 'ManageTrainData', 'TrainResult', 'ContourPlot']

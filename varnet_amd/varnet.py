@@ -1141,14 +1141,69 @@ class VarNet:
         return trainRes
 
     # -- checkpoints ----------------------------------------------------------------------------------
+    # Checkpoint layout.  tf.train.Saver writes every global variable of the graph under its TF name
+    # (TFModel.py:307; VarNet.py:1362): the Keras kernels / biases `dense_<i>/kernel` [in,out], `dense_<i>/bias`,
+    # `output/kernel`, `output/bias` (TFModel.py:208-242), the Adam slots `<var>/Adam` (m) and `<var>/Adam_1` (v),
+    # `beta1_power`, `beta2_power` and the step counter.  `best_model-<epoch>.npz` holds exactly those arrays under
+    # those names (RMSProp: `<var>/RMSProp` = mean square, `<var>/RMSProp_1` = momentum), so a TF-side converter is a
+    # loop over names.  TF's own files (`best_model-<n>.index/.meta/.data-*`) cannot be restored here -- reading them
+    # needs TensorFlow -- and loadModel says so instead of reporting "nothing found" (Checkpoints).
+    def _var_names(self):
+        names = ['dense_%d' % i for i in range(len(self.layerWidth))] + ['output']
+        return names
+
+    def checkpoint_arrays(self):
+        """{TF variable name: array} for the current engine state (see the layout note above)."""
+        buf = np.asarray(self.engine.export_state(), dtype=np.uint8)
+        step = int(buf[:8].view(np.int64)[0])
+        P = self.engine.P
+        flat = buf[8:].view(np.float32)
+        theta, m, v = flat[:P], flat[P:2 * P], flat[2 * P:3 * P]
+        slot = ('RMSProp_1', 'RMSProp') if str(self.optimizer).lower() == 'rmsprop' else ('Adam', 'Adam_1')
+        out, off, fan = {}, 0, self.inpDim
+        for name, h in zip(self._var_names(), self.layerWidth + [1]):
+            for part, n, shp in (('kernel', fan * h, (fan, h)), ('bias', h, (h,))):
+                key = '%s/%s' % (name, part)
+                out[key] = theta[off:off + n].reshape(shp).copy()
+                out[key + '/' + slot[0]] = m[off:off + n].reshape(shp).copy()
+                out[key + '/' + slot[1]] = v[off:off + n].reshape(shp).copy()
+                off += n
+            fan = h
+        out['global_step'] = np.int64(step)
+        if slot[0] == 'Adam':
+            out['beta1_power'] = np.float32(0.9 ** (step + 1))       # TF keeps beta^(t+1) for the next update
+            out['beta2_power'] = np.float32(0.999 ** (step + 1))
+        return out
+
+    def restore_arrays(self, arrays):
+        """Inverse of `checkpoint_arrays`: load {TF variable name: array} into the engine."""
+        slot = ('RMSProp_1', 'RMSProp') if str(self.optimizer).lower() == 'rmsprop' else ('Adam', 'Adam_1')
+        th, m, v, fan = [], [], [], self.inpDim
+        for name, h in zip(self._var_names(), self.layerWidth + [1]):
+            for part, shp in (('kernel', (fan, h)), ('bias', (h,))):
+                key = '%s/%s' % (name, part)
+                if key not in arrays:
+                    raise ValueError('checkpoint does not match the network architecture (no variable %s)!' % key)
+                a = np.asarray(arrays[key], dtype=np.float32)
+                if a.shape != shp:
+                    raise ValueError('checkpoint does not match the network architecture (%s is %s, expected %s)!'
+                                     % (key, a.shape, shp))
+                th.append(a.reshape(-1))
+                m.append(np.asarray(arrays.get(key + '/' + slot[0], np.zeros(shp)), dtype=np.float32).reshape(-1))
+                dflt = np.ones(shp) if slot[1] == 'RMSProp' else np.zeros(shp)
+                v.append(np.asarray(arrays.get(key + '/' + slot[1], dflt), dtype=np.float32).reshape(-1))
+            fan = h
+        step = np.array([int(arrays['global_step']) if 'global_step' in arrays else 0], dtype=np.int64)
+        blob = np.concatenate([step.view(np.uint8), np.concatenate(th + m + v).astype(np.float32).view(np.uint8)])
+        self.engine.import_state(blob)
+
     def saveModel(self, epoch):
-        """`saver.save(sess, 'best_model', global_step=epoch)` with max_to_keep=2
-        (TFModel.py:307, VarNet.py:1359-1362) -> best_model-<epoch>.npz."""
+        """`saver.save(sess, 'best_model', global_step=epoch)` with max_to_keep=2 (TFModel.py:307,
+        VarNet.py:1359-1362) -> `best_model-<epoch>.npz` + the `checkpoint` text file TF keeps beside it."""
         if self.rank != 0:
             return
         path = os.path.join(self.folderpath, 'best_model-%d.npz' % epoch)
-        np.savez(path, state=self.engine.export_state(), layerWidth=np.array(self.layerWidth),
-                 inpDim=self.inpDim, epoch=epoch)
+        np.savez(path, **self.checkpoint_arrays())
         kept = getattr(self, '_ckpts', [])
         kept.append(path)
         while len(kept) > 2:
@@ -1156,9 +1211,20 @@ class VarNet:
             if os.path.exists(old):
                 os.remove(old)
         self._ckpts = kept
+        self._write_checkpoint_file(self.folderpath, epoch, [int(os.path.basename(k)[len('best_model-'):-4]) for k in kept])
+
+    @staticmethod
+    def _write_checkpoint_file(folderpath, current, kept):
+        with open(os.path.join(folderpath, 'checkpoint'), 'w') as f:
+            f.write('model_checkpoint_path: ' + repr(os.path.join(folderpath, 'best_model-%d' % current)))
+            for n in kept:
+                f.write('\nall_model_checkpoint_paths: ' + repr(os.path.join(folderpath, 'best_model-%d' % n)))
+            f.write('\n')
 
     def loadModel(self, iterNum=None, folderpath=None):
-        """Restore the newest (or requested) best_model checkpoint (VarNet.py:1426-1506)."""
+        """Restore the newest (or requested) `best_model-<n>` checkpoint (VarNet.py:1426-1506): without `iterNum`
+        the stored iterations are tried newest first; the `checkpoint` file is rewritten to point at the restored
+        one, as the reference does."""
         if folderpath is None:
             if not hasattr(self, 'folderpath'):
                 raise ValueError('\'folderpath\' must be provided!')
@@ -1168,22 +1234,36 @@ class VarNet:
             self.trainRes = TrainResult(folderpath)
             if os.path.exists(os.path.join(folderpath, 'trainData.vn')):
                 self.trainRes.loadData()
+        tf_only = []
         if iterNum is None:
             nums = []
             for f in os.listdir(folderpath):
                 if f.startswith('best_model-') and f.endswith('.npz'):
                     nums.append(int(f[len('best_model-'):-4]))
+                elif f.startswith('best_model-') and f.endswith('.index'):
+                    tf_only.append(f)
             nums.sort(reverse=True)
         else:
             nums = [iterNum]
+            if os.path.isfile(os.path.join(folderpath, 'best_model-%d.index' % iterNum)):
+                tf_only.append('best_model-%d.index' % iterNum)
         for n in nums:
             path = os.path.join(folderpath, 'best_model-%d.npz' % n)
             if os.path.isfile(path):
                 z = np.load(path)
-                if list(z['layerWidth']) != self.layerWidth or int(z['inpDim']) != self.inpDim:
-                    raise ValueError('checkpoint does not match the network architecture!')
-                self.engine.import_state(z['state'])
+                if 'state' in z.files:                               # files written by round-1 builds
+                    if list(z['layerWidth']) != self.layerWidth or int(z['inpDim']) != self.inpDim:
+                        raise ValueError('checkpoint does not match the network architecture!')
+                    self.engine.import_state(z['state'])
+                else:
+                    self.restore_arrays({k: z[k] for k in z.files})
+                if self.rank == 0:
+                    self._write_checkpoint_file(folderpath, n, [n])
                 return n
+        if tf_only:
+            raise ValueError('only TensorFlow saver files (%s ...) were found: they cannot be read without TensorFlow; '
+                             'convert them to best_model-<n>.npz with the variable names of '
+                             'VarNet.checkpoint_arrays() (INTEGRATION.md, "Checkpoints")' % tf_only[0])
         raise ValueError('no restorable checkpoint data found!')
 
     def saveNNparam(self, dpOut=False, matOut=False, verbose=False, timeFirst=False, path=None):
@@ -1227,6 +1307,115 @@ class VarNet:
         if path is not None:
             np.savez(path, **npz)
         return layers
+
+    # -- reporting --------------------------------------------------------------------------------------
+    def simRes(self, batch=None, tcoord=None, plotpath=None, pltFrmt='png', plot=False):
+        """
+        Simulation results on the plotting grid (/root/reference/VarNet.py:1970-2175): for every time in `tcoord`
+        (default 5 snapshots over the time interval) the fields the reference draws -- approximate solution `cApp`,
+        exact solution `cEx` and error `cErr` (when the PDE has `cEx`), strong residual `res`, interpolated loss field
+        `lossField` (when the last training run kept `lossVec`) -- as arrays: [51, 51] contour fields in 2D, curves on
+        the 51-point x grid in 1D.  Returned as {'t': [...], 'grid': ContourPlot, 'cApp': [...], ..., 'l2Err': [...]}.
+        With `plot=True` (and matplotlib present) the same figures are also written under `plotpath` with the
+        reference's file names (cApp-t=0.00s.png, cEx-..., cErr-..., res-..., lossField-... / cApp.png, cErr.png,
+        residual.png, lossField.png in 1D).
+        """
+        from .contour import ContourPlot
+        if not hasattr(self, 'trainRes') and uf.isnone(plotpath) and plot:
+            raise ValueError('\'plotpath\' must be provided!')
+        elif uf.isnone(plotpath) and hasattr(self, 'trainRes'):
+            plotpath = self.trainRes.plotpath
+        if pltFrmt not in ('png', 'jpg', 'pdf', 'eps'):
+            raise ValueError('invalid plot format!')
+        suffix = ('.' if uf.isnone(batch) else '-b=' + str(int(batch)) + '.') + pltFrmt
+        dim, PDE = self.dim, self.PDE
+        td, tInterval, cExact = PDE.timeDependent, PDE.tInterval, PDE.cEx
+        if td and uf.isnone(tcoord):
+            tcoord = np.linspace(tInterval[0], tInterval[1], num=5)
+        elif not td:
+            tcoord = [0.]
+        if dim > 2:
+            raise ValueError('simRes is available for 1D and 2D domains!')
+        cp = ContourPlot(PDE.domain, tInterval if td else None)
+        cAppFun = lambda x, t=None: self.evaluate(x, t, batch)
+
+        def resFun(x, t=None):
+            Input = np.concatenate([x, t * np.ones([len(x), 1])], axis=1) if td else x
+            return self.residual(Input, None, batch)[1]
+
+        cExFun = cErrFun = None
+        if not uf.isnone(cExact):
+            cExFun = (lambda x, t: cExact(x, t * np.ones([len(x), 1]))) if td else (lambda x, t=None: cExact(x))
+            cErrFun = lambda x, t=None: cExFun(x, t) - cAppFun(x, t)
+        lossFun = None
+        lv = getattr(getattr(self, 'trainRes', None), 'lossVec', None)
+        if not uf.isnone(lv) and len(lv) > 0:
+            from scipy import interpolate
+            lossVec = lv[0] if uf.isnone(batch) else lv[batch]
+            ui = self.fixData.uniform_input
+            if ui.shape[1] == 1:
+                lossField = lambda X: np.interp(X[:, 0], ui[:, 0], np.reshape(lossVec, -1), left=0.0, right=0.0).reshape(-1, 1)
+            else:
+                lossField = interpolate.LinearNDInterpolator(ui, lossVec, fill_value=0.0)
+            lossFun = lambda x, t=None: lossField(uf.hstack([x, t * np.ones([len(x), 1])]) if td else x)
+        funs = {'cApp': cAppFun, 'cEx': cExFun, 'cErr': cErrFun, 'res': resFun, 'lossField': lossFun}
+        out = {'t': [float(t) for t in tcoord], 'grid': cp, 'l2Err': []}
+        for name, f in funs.items():
+            if f is None:
+                continue
+            if dim == 1:
+                out[name] = [np.asarray(cp.snap(f, float(t))[1], dtype=float).reshape(-1, 1) for t in tcoord]
+            else:
+                out[name] = [cp.field(f, float(t) if td else None) for t in tcoord]
+        if cExFun is not None:
+            out['l2Err'] = [uf.l2Err(e, a) for e, a in zip(out['cEx'], out['cApp'])]
+        if plot:
+            self._simres_figures(out, cp, plotpath, suffix)
+        return out
+
+    def _simres_figures(self, out, cp, plotpath, suffix):
+        """Draw and save what simRes computed, with the reference's file names (VarNet.py:2066-2172)."""
+        try:
+            import matplotlib
+            matplotlib.use('Agg')
+            import matplotlib.pyplot as plt
+        except ImportError:
+            warnings.warn('matplotlib is not available: simRes figures are not written')
+            return
+        os.makedirs(plotpath, exist_ok=True)
+        ts = out['t']
+        if self.dim == 1:
+            names = {'cErr': 'cErr', 'res': 'residual', 'lossField': 'lossField'}
+            if 'cEx' in out:
+                for i, t in enumerate(ts):
+                    plt.figure()
+                    plt.plot(cp.x_coord, out['cEx'][i], 'b')
+                    plt.plot(cp.x_coord, out['cApp'][i], 'r')
+                    plt.legend(['exact solution', 'approximate solution'])
+                    plt.savefig(os.path.join(plotpath, 'cApp-' + 't={0:.2f}s'.format(t) + suffix), dpi=300)
+                    plt.close()
+            else:
+                names['cApp'] = 'cApp'
+            for key, fname in names.items():
+                if key not in out:
+                    continue
+                plt.figure()
+                for i, t in enumerate(ts):
+                    plt.plot(cp.x_coord, out[key][i])
+                plt.legend(['t={0:.2f}s'.format(t) for t in ts])
+                plt.savefig(os.path.join(plotpath, fname + suffix), dpi=300)
+                plt.close()
+        else:
+            for key in ('cApp', 'cEx', 'cErr', 'res', 'lossField'):
+                if key not in out:
+                    continue
+                for i, t in enumerate(ts):
+                    plt.figure()
+                    c = plt.contourf(cp.xx, cp.yy, out[key][i])
+                    plt.colorbar(c)
+                    plt.axis('scaled')
+                    plt.savefig(os.path.join(plotpath, key + '-' + 't={0:.2f}s'.format(t) + suffix), dpi=300)
+                    plt.close()
 
     # -- evaluation -------------------------------------------------------------------------------------
     def _mor_columns(self, batch, n):
