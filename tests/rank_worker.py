@@ -79,3 +79,32 @@ def launch(ctx, world, outdir, backend, engine, problem, train_kw, tag, timeout=
         if p.is_alive():
             p.terminate()
     assert not bad, 'rank exit codes %s' % [p.exitcode for p in procs]
+
+
+def run_controller(outdir, backend, ngpu_entries, q):
+    """The reference's single-process multi-GPU call: VarNet(..., processors=[...]) in a process that has not
+    touched the GPU; the object forks its towers (varnet_amd/towers.py)."""
+    try:
+        os.environ['VN_DIST_BACKEND'] = backend
+        import torch
+        from tests.test_varnet_host import cExact, pi
+        from varnet_amd import ADPDE, Domain1D, VarNet
+        pde = ADPDE(Domain1D(), diff=0.1 / pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                    IC=lambda x: -np.sin(pi * x), cEx=cExact)               # lambdas: only a fork can carry them
+        procs = ['GPU:%d' % (i if backend == 'nccl' else 0) for i in range(ngpu_entries)]
+        vn = VarNet(pde, layerWidth=[20, 20, 20], discNum=20, bDiscNum=None, tDiscNum=30, processors=procs,
+                    controller='GPU:0')
+        assert not torch.cuda.is_initialized()                             # the controller never touches the GPU
+        res = vn.train(os.path.join(outdir, 'ctl'), weight=[10., 10., 1.], epochNum=30, saveFreq=10, verbose=False)
+        u = vn.evaluate()
+        r, rv, err, ca = vn.residual()
+        sim = vn.simRes(tcoord=[0.5])
+        n = vn.loadModel()
+        np.savez(os.path.join(outdir, 'ctl.npz'), loss=np.array(res.lossAll), u=u, err=err, r=r,
+                 cApp=sim['cApp'][0], n=n, w=np.asarray(res.trainWeight))
+        assert not torch.cuda.is_initialized()
+        vn._towers.close()
+        q.put((0, 'ok'))
+    except Exception:
+        import traceback
+        q.put((1, traceback.format_exc()))

@@ -163,3 +163,26 @@ def _bench_child(q):
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
                        capture_output=True, text=True, env=env, timeout=800)
     q.put((r.returncode, r.stdout + '\n' + r.stderr))
+
+
+def test_processors_list_in_one_user_process(tmp_path):
+    """VarNet(..., processors=['GPU:0','GPU:1'], controller=...) -- the reference's way to go multi-GPU
+    (TFModel.py:120-165) -- from one user process: the object forks one tower per entry and forwards train /
+    evaluate / residual / simRes / loadModel.  Here both towers share GPU 0 over gloo unless the box has 2 GPUs."""
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    out = str(tmp_path)
+    backend = 'nccl' if _ndev() >= 2 else 'gloo'
+    q = conftest.FORKSERVER.Queue()
+    p = conftest.FORKSERVER.Process(target=rw.run_controller, args=(out, backend, 2, q))
+    p.start()
+    rc, text = q.get(timeout=600)
+    p.join(60)
+    assert rc == 0, text
+    kw = dict(weight=[10., 10., 1.], epochNum=30, saveFreq=10, verbose=False)
+    rw.launch(conftest.FORKSERVER, 1, out, 'gloo', 'hip', _problem(), kw, 'c1')
+    a = np.load(os.path.join(out, 'c1_w1_r0.npz'))
+    c = np.load(os.path.join(out, 'ctl.npz'))
+    np.testing.assert_allclose(c['w'], a['w'], rtol=1e-4)
+    np.testing.assert_allclose(c['loss'], a['loss'], rtol=2e-4)
+    assert c['u'].shape == (600, 1) and np.isfinite(c['err']) and c['cApp'].shape == (51, 1) and int(c['n']) in (10, 20, 30)

@@ -1,0 +1,135 @@
+"""
+`processors=['GPU:0', 'GPU:1', ...]` in ONE user process.
+
+The reference builds all its towers inside one TF-1 process (/root/reference/TFModel.py:120-165, 253-289;
+`VarNet(..., processors=[...], controller=...)`, VarNet.py:201-203).  This engine runs one process per GPU, so
+a `VarNet` constructed with several processors and no launcher becomes a *controller*: it forks one child per
+listed GPU (before anything in the parent has touched the GPU -- a forked child cannot inherit an initialised
+HIP runtime), every child builds the real `VarNet` on its GPU and joins the process group, and the public
+methods (`train`, `evaluate`, `residual`, `loadModel`, `simRes`, `saveNNparam`) are forwarded to all children;
+rank 0's result is returned.  `fork` is used on purpose: the PDE holds user callables (lambdas) that cannot be
+pickled but are inherited by a fork.  `controller` is accepted and unused: the gradient is summed by an
+all-reduce and the optimizer step is repeated on every rank, there is no controller device.
+"""
+import multiprocessing
+import os
+import socket
+import traceback
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tower_main(rank, world, port, conn, cls, args, kwargs, device, backend):
+    try:
+        os.environ.update({'RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_RANK': str(device),
+                           'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        vn = cls(*args, **kwargs)                       # inside a rank: takes its own entry of `processors`
+        conn.send(('ready', None))
+    except Exception:
+        conn.send(('err', traceback.format_exc()))
+        return
+    while True:
+        msg = conn.recv()
+        if msg is None:
+            break
+        name, a, k = msg
+        try:
+            r = getattr(vn, name)(*a, **k)
+            if name == 'simRes' and isinstance(r, dict):
+                r = {key: v for key, v in r.items() if key != 'grid'}
+            conn.send(('ok', r if rank == 0 else None))
+        except Exception:
+            conn.send(('err', traceback.format_exc()))
+    try:
+        if getattr(vn, 'comm', 'none') == 'rccl':
+            vn.engine.comm_destroy()
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+class TowerGroup:
+    def __init__(self, cls, args, kwargs, processors):
+        import torch
+        if torch.cuda.is_initialized():
+            raise RuntimeError('processors=%s: the towers are forked from this process, which has already initialised '
+                               'the GPU; construct the multi-GPU VarNet before any other GPU work, or start one rank '
+                               'per GPU with `python -m varnet_amd.launch --gpus N script.py`' % (processors,))
+        devices = []
+        for p in processors:
+            kind, _, idx = str(p).partition(':')
+            if kind.upper() != 'GPU':
+                raise ValueError('requested processor %s is unavailable!' % p)        # TFModel.py:121-123
+            devices.append(int(idx or 0))
+        backend = os.environ.get('VN_DIST_BACKEND', 'nccl')
+        if backend == 'nccl' and len(set(devices)) != len(devices):
+            raise ValueError('processors %s name a GPU twice' % (processors,))
+        ndev = torch.cuda.device_count()
+        if any(d >= ndev for d in devices):
+            raise ValueError('requested processor GPU:%d is unavailable!' % max(devices))
+        ctx = multiprocessing.get_context('fork')
+        port = _free_port()
+        self.world = len(devices)
+        self.conns, self.procs = [], []
+        for r, dev in enumerate(devices):
+            here, there = ctx.Pipe()
+            p = ctx.Process(target=_tower_main, args=(r, self.world, port, there, cls, args, kwargs, dev, backend),
+                            daemon=True)
+            p.start()
+            there.close()
+            self.conns.append(here)
+            self.procs.append(p)
+        self._gather()
+
+    def _gather(self):
+        out, err = None, None
+        for r, c in enumerate(self.conns):
+            try:
+                tag, val = c.recv()
+            except EOFError:
+                tag, val = 'err', 'tower %d exited' % r
+            if tag == 'err' and err is None:
+                err = 'tower %d failed:\n%s' % (r, val)
+            if r == 0:
+                out = val
+        if err is not None:
+            self.close()
+            raise RuntimeError(err)
+        return out
+
+    def call(self, name, *a, **k):
+        for c in self.conns:
+            c.send((name, a, k))
+        return self._gather()
+
+    def close(self):
+        for c in self.conns:
+            try:
+                c.send(None)
+            except Exception:
+                pass
+        for p in self.procs:
+            p.join(20)
+            if p.is_alive():
+                p.terminate()
+        self.conns, self.procs = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -589,12 +589,24 @@ class VarNet:
 
         # distributed context: one process per GPU; world_size plays the reference's puNum
         self.rank, self.world, self.dist = 0, 1, None
+        self._towers = None
         try:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
         except ImportError:
             pass
+        if isinstance(processors, (list, tuple)) and len(processors) > 1 and self.world == 1:
+            # the reference's single-process multi-GPU call (TFModel.py:120-165): this process becomes the
+            # controller of one forked child per GPU (varnet_amd/towers.py); it never touches the GPU itself
+            from .towers import TowerGroup
+            kw = dict(layerWidth=layerWidth, modelId=modelId, activationFun=activationFun, discNum=discNum,
+                      bDiscNum=bDiscNum, tDiscNum=tDiscNum, MORdiscScheme=MORdiscScheme, processors=list(processors),
+                      controller=controller, integPnum=integPnum, optimizer=optimizer, learning_rate=learning_rate)
+            self._towers = TowerGroup(type(self), (PDE,), kw, list(processors))
+            self.world = self._towers.world
+            self.engine = self.tfData = None
+            return
         self._rng = np.random.default_rng(12345)
         self.engine = self._make_engine(processors)
         self.engine.init_params(seed=0)
@@ -625,11 +637,8 @@ class VarNet:
                 if self.world > 1 and len(processors) == self.world:
                     processors = processors[self.rank]
                 else:
-                    raise ValueError('processors=%s asks for %d towers in one process; this engine runs one '
-                                     'process per GPU: start %d ranks (python -m torch.distributed.run '
-                                     '--nproc-per-node %d --master-addr 127.0.0.1 script.py, or varnet_amd.launch) '
-                                     'and pass the same list on every rank' % (processors, len(processors),
-                                                                              len(processors), len(processors)))
+                    raise ValueError('processors=%s lists %d GPUs but %d ranks are running: pass one entry per rank'
+                                     % (processors, len(processors), self.world))
             else:
                 processors = processors[0]
         if isinstance(processors, str):
@@ -1032,6 +1041,11 @@ class VarNet:
               dedup=False):
         """Training loop of /root/reference/VarNet.py:1197-1421 (uniform, random and residual-driven
         "optimal" sampling with re-initialisation and re-weighting)."""
+        if self._towers is not None:                  # controller of forked towers: every tower runs the loop
+            kw = {k: v for k, v in locals().items() if k not in ('self', 'folderpath')}
+            self.folderpath = folderpath
+            self.trainRes = self._towers.call('train', folderpath, **kw)
+            return self.trainRes
         if uf.isnone(folderpath) or uf.isempty(folderpath):
             raise ValueError('a folder path must be provided to backup the trained model!')
         self.folderpath = folderpath
@@ -1225,6 +1239,10 @@ class VarNet:
         """Restore the newest (or requested) `best_model-<n>` checkpoint (VarNet.py:1426-1506): without `iterNum`
         the stored iterations are tried newest first; the `checkpoint` file is rewritten to point at the restored
         one, as the reference does."""
+        if self._towers is not None:
+            if folderpath is None and hasattr(self, 'folderpath'):
+                folderpath = self.folderpath
+            return self._towers.call('loadModel', iterNum, folderpath)
         if folderpath is None:
             if not hasattr(self, 'folderpath'):
                 raise ValueError('\'folderpath\' must be provided!')
@@ -1273,6 +1291,8 @@ class VarNet:
         spatial ones in the first layer.  `matOut` writes `NN_parameters/W<n>.mat, B<n>.mat` (MATLAB),
         `dpOut` the Diffpack-readable `W<n>.m, B<n>.m`; `path` additionally writes one `.npz`.
         """
+        if self._towers is not None:
+            return self._towers.call('saveNNparam', dpOut, matOut, verbose, timeFirst, path)
         flat = self.engine.get_params()
         td = self.PDE.timeDependent
         if not td:
@@ -1321,6 +1341,10 @@ class VarNet:
         residual.png, lossField.png in 1D).
         """
         from .contour import ContourPlot
+        if self._towers is not None:
+            out = self._towers.call('simRes', batch, tcoord, plotpath, pltFrmt, plot)
+            out['grid'] = ContourPlot(self.PDE.domain, self.PDE.tInterval if self.PDE.timeDependent else None)
+            return out
         if not hasattr(self, 'trainRes') and uf.isnone(plotpath) and plot:
             raise ValueError('\'plotpath\' must be provided!')
         elif uf.isnone(plotpath) and hasattr(self, 'trainRes'):
@@ -1427,6 +1451,8 @@ class VarNet:
 
     def evaluate(self, x=None, t=None, batch=None, MORarg=None):
         """NN approximation of the PDE solution at (x,t[,mu]) (VarNet.py:1510-1595) -> [n,1]."""
+        if self._towers is not None:
+            return self._towers.call('evaluate', x, t, batch, MORarg)
         dim, PDE, fd = self.dim, self.PDE, self.fixData
         td = PDE.timeDependent
         MORvar = PDE.MORvar
@@ -1471,6 +1497,8 @@ class VarNet:
             res = sqrt(sum(resVec^2) * prod(hVec)), err = l2Err(cEx, cApp), averaged over MOR batches.
         Returns (res, resVec, err, cApp).
         """
+        if self._towers is not None:
+            return self._towers.call('residual', Input, tDiscIND, batch, fp64)
         dim, PDE, fd = self.dim, self.PDE, self.fixData
         td = PDE.timeDependent
         elemSize = np.prod(fd.hVec)
