@@ -96,6 +96,10 @@ CASES = [
     (2, 1, [63, 63],             16,      90,  33,  11,  True,  False, False),
     (3, 2, [60, 60, 60, 60, 60], 64,      9,   77,  40,  False, False, False),
     (3, 2, [64, 64],             64,      6,   20,  8,   False, False, False),   # 64 wide: generic kernels
+    (2, 1, [20],                 16,      300, 40,  25,  False, False, False),   # one hidden layer (Operator_1Dt.py:156)
+    (3, 2, [50],                 64,      40,  30,  10,  True,  False, True),
+    (3, 2, [60],                 36,      21,  30,  10,  False, True,  False),
+    (3, 2, [50] * 6,             64,      12,  30,  10,  False, False, False),   # six hidden layers, 50 wide
 ]
 
 
@@ -104,8 +108,7 @@ def _skip_unsupported(kernel, widths, integNum):
                         (max(widths) > 20 and len(widths) < 2) or (max(widths) > 32 and len(widths) < 3) or
                         len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused32 not instantiated for this shape')
-    if kernel == 3 and (max(widths) > 63 or len(widths) < 2 or          # integNum > 128: two-pass fused route
-                        len(widths) > (5 if max(widths) > 32 else 6)):
+    if kernel == 3 and (max(widths) > 63 or len(widths) > (5 if max(widths) > 50 else 6)):   # integNum > 128: two-pass
         pytest.skip('fused16 not instantiated for this shape')
 
 
@@ -341,7 +344,9 @@ def test_engine_argument_errors():
         eng.set_interior(0, np.zeros((17, 2), np.float32), np.zeros((17, 1), np.float32), n_k=1)
     eng.close()
     with pytest.raises(ValueError):
-        VNEngine(1, 2, [5], True, 16, activationFun='tanh')
+        VNEngine(1, 2, [5], True, 16, activationFun='relu')          # options: 'sigmoid' or 'tanh' (VarNet.py:97)
+    with pytest.raises(ValueError):
+        VNEngine(1, 2, [5, 5], True, 16, activationFun=['tanh', 'sigmoid'])
     with pytest.raises(ValueError):
         VNEngine(1, 2, [500], True, 16)
 

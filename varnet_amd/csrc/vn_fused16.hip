@@ -119,7 +119,8 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 struct LaneC {
   int g, c;
   int offF;        // forward A-fragment lane offset: g*WS + c            (+ 16*m + 4*ks*WS)
-  int offB[4];     // backward A-fragment lane offset per row tile: fin*WS + 4g   (+ vpos(ks,0))
+  int offB0;       // backward A-fragment lane offset of row tile 0: fin*WS + 4g   (+ 16m*WS + vpos(ks,0)): the
+                   // in-features of row tile m are fin(c) + 16m, and 16*MTM <= HP in every instantiation
   int twr;         // transposition write offset: 4g*TSW + wave*16 + c     (+ vpos(ks,0)*TSW)
 };
 
@@ -718,12 +719,9 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   lc.g = lane >> 4;
   lc.c = lane & 15;
   lc.offF = lc.g * WS + lc.c;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    int fin = vfeat(16 * m + lc.c);
-    if (fin >= LY::HP) fin = 0;
-    lc.offB[m] = fin * WS + 4 * lc.g;
-  }
+  static_assert(16 * MTM <= LY::HP, "backward fragment rows stay inside the weight image");
+  static_assert(vfeat(16 + 5) == 16 + vfeat(5), "row tile m holds features fin(c) + 16m");
+  lc.offB0 = vfeat(lc.c) * WS + 4 * lc.g;
   // Diagnostic ablations (-DVN_ABL_FWD_W / -DVN_ABL_BWD_W; results are WRONG, only counters and time matter):
   // the weight-fragment reads of the forward / backward GEMMs become bank-conflict-free (32 lanes of a half on
   // 32 distinct banks), to attribute SQ_LDS_BANK_CONFLICT (profiles/r2_lds_conflict_ablation.md).
@@ -731,8 +729,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   lc.offF = (lane & 31);
 #endif
 #ifdef VN_ABL_BWD_W
-#pragma unroll
-  for (int m = 0; m < 4; ++m) lc.offB[m] = (lane & 31) + 64 * m;
+  lc.offB0 = (lane & 31);
 #endif
   lc.twr = 4 * lc.g * TSW + wave * CW + lc.c;
 
@@ -1051,7 +1048,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       for (int m = 0; m < MT; ++m) { accv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acct[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       float wf[MTM], we[NVE], ev[NVE], et[NVE];
 #pragma unroll
-      for (int m = 0; m < MTM; ++m) wf[m] = Wl[lc.offB[m] + vpos(0, 0)];
+      for (int m = 0; m < MTM; ++m) wf[m] = Wl[lc.offB0 + 16 * m * WS + vpos(0, 0)];
 #pragma unroll
       for (int v = 0; v < NVE; ++v) {
         we[v] = EDGE ? Wl[(4 * (KS - 1) + v) * WS + 4 * lc.g + vpos(0, 0)] : 0.f;
@@ -1062,7 +1059,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       for (int ks = 0; ks < KS; ++ks) {
         float wn[MTM], wen[NVE];
 #pragma unroll
-        for (int m = 0; m < MTM; ++m) wn[m] = (ks + 1 < KS) ? Wl[lc.offB[m] + vpos(ks + 1, 0)] : 0.f;
+        for (int m = 0; m < MTM; ++m) wn[m] = (ks + 1 < KS) ? Wl[lc.offB0 + 16 * m * WS + vpos(ks + 1, 0)] : 0.f;
 #pragma unroll
         for (int v = 0; v < NVE; ++v)
           wen[v] = (EDGE && ks + 1 < KS) ? Wl[(4 * (KS - 1) + v) * WS + 4 * lc.g + vpos(ks + 1, 0)] : 0.f;
@@ -1241,10 +1238,10 @@ int pick_ks(int hmax) {
 }  // namespace
 
 #define VN_FUSED16_CASES(X) \
-  X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(6, 5)   \
-  X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8)   \
-  X(2, 13) X(3, 13) X(4, 13) X(5, 13)       \
-  X(2, 16) X(3, 16) X(4, 16) X(5, 16)
+  X(1, 5) X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(6, 5)        \
+  X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8)        \
+  X(1, 13) X(2, 13) X(3, 13) X(4, 13) X(5, 13) X(6, 13)  \
+  X(1, 16) X(2, 16) X(3, 16) X(4, 16) X(5, 16)
 
 size_t vn_fused16_lds_bytes(const VnNet& net) {
   const int ks = pick_ks(net.hmax);
