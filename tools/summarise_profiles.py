@@ -5,6 +5,33 @@ tag, pre = sys.argv[1], sys.argv[2]
 src = 'gpurun_out/prof_%s' % tag
 os.makedirs('profiles', exist_ok=True)
 shutil.copy(src + '/bench.json', 'profiles/%s_bench_default.json' % pre)
+for extra, dst in (('bench_cfg2.json', '%s_bench_cfg2.json'), ('shard_perf.txt', '%s_shard_perf.txt'), ('mor_perf.txt', '%s_mor_perf.txt'),
+                   ('q216.txt', '%s_q216_perf.txt'), ('generic_w64.txt', '%s_generic_w64_perf.txt'), ('width60.txt', '%s_width60_perf.txt')):
+    if os.path.exists(src + '/' + extra):
+        shutil.copy(src + '/' + extra, 'profiles/' + dst % pre)
+for sub, dst in (('stats_q216', '%s_twopass_q216_kernel_stats.csv'), ('stats_generic', '%s_generic_w64_kernel_stats.csv')):
+    g = glob.glob(src + '/' + sub + '/**/s_kernel_stats.csv', recursive=True)
+    if g:
+        shutil.copy(g[0], 'profiles/' + dst % pre)
+gen = {}
+for f in glob.glob(src + '/gpmc_*/**/p_counter_collection.csv', recursive=True):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'vn_generic_bwd_kernel' in r['Kernel_Name']:
+            d[r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, v in d.items():
+        v = sorted(v); gen[k] = v[len(v) // 2]
+if gen:
+    cyc = gen.get('GRBM_GUI_ACTIVE', 0) / 8.0
+    gen['derived'] = {'shader_cycles_per_launch': cyc,
+                      'mfma_pipe_utilisation': gen.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024.0 / cyc if cyc else None,
+                      'lds_utilisation': gen.get('SQ_LDS_IDX_ACTIVE', 0) / 256.0 / cyc if cyc else None,
+                      'lds_conflict_share': gen.get('SQ_LDS_BANK_CONFLICT', 0) / max(gen.get('SQ_LDS_IDX_ACTIVE', 1), 1),
+                      'wait_any_share': gen.get('SQ_WAIT_ANY', 0) / max(gen.get('SQ_WAVE_CYCLES', 1), 1),
+                      'wait_inst_share': gen.get('SQ_WAIT_INST_ANY', 0) / max(gen.get('SQ_WAVE_CYCLES', 1), 1),
+                      'hbm_bytes_per_launch': (2 * gen.get('FETCH_SIZE', 0) + gen.get('WRITE_SIZE', 0)) * 1024.0}
+    gen['kernel'] = 'vn_generic_bwd_kernel, 3x64 net, config-3 sized inputs (tools/width_perf.py 64 3)'
+    json.dump(gen, open('profiles/%s_pmc_generic_bwd.json' % pre, 'w'), indent=1)
 st = glob.glob(src + '/stats/**/s_kernel_stats.csv', recursive=True)[0]
 shutil.copy(st, 'profiles/%s_fused16_kernel_stats.csv' % pre)
 tot = {}
@@ -29,7 +56,8 @@ out = {
              'SQ_LDS_IDX_ACTIVE': tot['SQ_LDS_IDX_ACTIVE'], 'SQ_LDS_BANK_CONFLICT': tot['SQ_LDS_BANK_CONFLICT'],
              'lds_utilisation': tot['SQ_LDS_IDX_ACTIVE'] / 256.0 / cyc},
     'waves': {k: tot[k] for k in ('SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU') if k in tot},
-    'command': 'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dedup',
+    'round': pre, 'command': 'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dedup',
 }
 json.dump(out, open('profiles/%s_pmc_traffic.json' % pre, 'w'), indent=1)
+json.dump(out, open('profiles/pmc_traffic.json', 'w'), indent=1)      # the file bench.py quotes `traffic` from
 print(json.dumps(out, indent=1))
