@@ -112,6 +112,46 @@ __device__ __forceinline__ float act_d1(float a) { return TANH ? __builtin_fmaf(
 template <bool TANH>
 __device__ __forceinline__ float act_d2r(float a) { return TANH ? -2.f * a : 1.f - 2.f * a; }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Per-lane value arrays indexed by k-step, kept as even-aligned REGISTER PAIRS: k-steps 2j and 2j+1 share a pair, so
+// the elementwise chains of the reverse pass run as v_pk_mul_f32 / v_pk_fma_f32 on two k-steps per instruction
+// (packed fp32 issues at the scalar rate on gfx950, and every vector instruction costs matrix time here).  A pair of
+// accumulator rows (ks, ks+1), ks even, of an MFMA tile is a register pair already.
+template <int N>
+struct PA {
+  static constexpr int NP = (N + 1) / 2;
+  f32x2 p[NP];
+  __device__ __forceinline__ float operator[](int i) const { return p[i >> 1][i & 1]; }
+  __device__ __forceinline__ void set(int i, float v) { p[i >> 1][i & 1] = v; }
+};
+__device__ __forceinline__ f32x2 opaque2(f32x2 x) {
+  asm("" : "+v"(x));
+  return x;
+}
+template <bool TANH>
+__device__ __forceinline__ f32x2 act_exp2(f32x2 z) {      // two exponentials: one packed scale, two v_exp
+  const float c = TANH ? -2.8853900817779268f : -1.4426950408889634f;
+  const f32x2 t = z * f32x2{c, c};
+  return f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+}
+template <bool TANH>
+__device__ __forceinline__ f32x2 act_fin2(f32x2 e) {
+  const f32x2 d = e + f32x2{1.f, 1.f};
+  const f32x2 s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return TANH ? (s * f32x2{2.f, 2.f} - f32x2{1.f, 1.f}) : s;
+}
+template <bool TANH>
+__device__ __forceinline__ f32x2 act_d1_2(f32x2 a) {
+  const f32x2 one = {1.f, 1.f};
+  return TANH ? (one - a * a) : (a - a * a);
+}
+template <bool TANH>
+__device__ __forceinline__ f32x2 act_d2r_2(f32x2 a) {
+  const f32x2 one = {1.f, 1.f}, two = {2.f, 2.f};
+  return TANH ? (-two * a) : (one - two * a);
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -197,9 +237,8 @@ __device__ __forceinline__ void t_write(float* T, const LaneC& lc, int ks, float
 // Cooperative weight gradient (see vn_fused.hip): all waves publish their 16 point-columns of
 // the transposed operands, then each wave contracts its output tile(s) over its share of the
 // 128 points into persistent accumulators.
-template <int KSA, int KSB, bool RAWA, bool TANH, int NACC>
-__device__ __forceinline__ void wgrad_layer(const float (&av)[KSA], const float (&azd)[KSA],
-                                            const float (&bv)[KSB], const float (&bt)[KSB], float* TA,
+template <int KSA, int KSB, bool RAWA, bool TANH, int NACC, class AV, class BV>
+__device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const BV& bv, const BV& bt, float* TA,
                                             float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC] STAMP_PARAMS) {
   using W = WG<KSA, KSB>;
   static_assert(NACC == W::TPW, "accumulator count");
@@ -305,8 +344,8 @@ __device__ __forceinline__ void thin_contract(const float* TA, const float* TB, 
 
 // output layer: rows = the KS*4 positions of a (and the bias row), one column ubar (lanes g == 0 publish it
 // into row 0, the other lane groups publish zeros into rows 4, 8, 12)
-template <int KS, bool TANH>
-__device__ __forceinline__ void thin_wgrad_out(const float (&av)[KS], const float (&azd)[KS], float ubar, float udbar,
+template <int KS, bool TANH, class AV>
+__device__ __forceinline__ void thin_wgrad_out(const AV& av, const AV& azd, float ubar, float udbar,
                                                float* TA, float* TB, const LaneC& lc, int wave, int lane, f32x4& acc) {
   using W = WG<KS, 1>;
 #pragma unroll
@@ -340,9 +379,9 @@ __device__ __forceinline__ void thin_flush_out(const f32x4& acc, float* Gl, int 
 }
 
 // input layer, d_in <= 3: rows x0, x1, x2 (positions 0, 4, 8) and the bias row against all columns
-template <int KS>
-__device__ __forceinline__ void thin_wgrad_in(const float (&xv)[KS0], const float (&gv)[KS0], const float (&bv)[KS],
-                                              const float (&bt)[KS], float* TA, float* TB, const LaneC& lc, int wave,
+template <int KS, class BV>
+__device__ __forceinline__ void thin_wgrad_in(const float (&xv)[KS0], const float (&gv)[KS0], const BV& bv,
+                                              const BV& bt, float* TA, float* TB, const LaneC& lc, int wave,
                                               int lane, f32x4& acc) {
   using W = WG<KS0, KS>;
   const int sel = lane & 3;
@@ -514,23 +553,25 @@ __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, c
 
 template <int KS_, int I, bool TANH>
 struct H13Pub {      // unrolled stores with compile-time offsets (inline-asm immediates)
-  static __device__ __forceinline__ void run(int half, const float (&av)[13], const float (&azd)[13], const float (&bv)[13],
-                                             const float (&bt)[13]) {
-    float v = av[I];
-    if (half == 1) {
-      const float x = opaque(av[I]);
-      v = act_d1<TANH>(x) * azd[I];
-    }
-    addtid_store<I * H13::RS * 4>(v);
+  static __device__ __forceinline__ void run(int half, const PA<13>& av, const PA<13>& azd, const PA<13>& bv,
+                                             const PA<13>& bt) {
+    // I even: this step publishes k-steps I and I+1 (one packed sigma'(a)*zdot for both)
+    f32x2 v2 = av.p[I >> 1];
+    if (half == 1) v2 = act_d1_2<TANH>(opaque2(av.p[I >> 1])) * azd.p[I >> 1];
+    addtid_store<I * H13::RS * 4>(v2[0]);
     addtid_store<(H13::TA_ROWS + I) * H13::RS * 4>(half == 0 ? bv[I] : bt[I]);
-    if constexpr (I + 1 < KS_) H13Pub<KS_, I + 1, TANH>::run(half, av, azd, bv, bt);
+    if constexpr (I + 1 < KS_) {
+      addtid_store<(I + 1) * H13::RS * 4>(v2[1]);
+      addtid_store<(H13::TA_ROWS + I + 1) * H13::RS * 4>(half == 0 ? bv[I + 1] : bt[I + 1]);
+    }
+    if constexpr (I + 2 < KS_) H13Pub<KS_, I + 2, TANH>::run(half, av, azd, bv, bt);
   }
 };
 
 // both rounds of a 50-wide hidden layer; t_base_bytes = byte address of this wave's 64 columns of TA
 template <bool TANH>
-__device__ __forceinline__ void h13_wgrad_layer(const float (&av)[13], const float (&azd)[13], const float (&bv)[13],
-                                                const float (&bt)[13], float* TA, const LaneC& lc, int wave, int lane,
+__device__ __forceinline__ void h13_wgrad_layer(const PA<13>& av, const PA<13>& azd, const PA<13>& bv,
+                                                const PA<13>& bt, float* TA, const LaneC& lc, int wave, int lane,
                                                 unsigned t_base_bytes, f32x4 (&acc)[2] STAMP_PARAMS) {
   const float* TB = TA + H13::TA_ROWS * H13::RS;
 #pragma unroll
@@ -800,7 +841,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     }
 
     STAMP(0);
-    float a[L][KS], zd[L][KS];
+    PA<KS> a[L], zd[L];
 
     // ---------------------------------------------------------------- layer 1 (also recomputed late)
     auto layer1_raw = [&](const float (&xi)[KS0], const float (&gi)[KS0], f32x4 (&ov)[MT], f32x4 (&ot)[MT]) {
@@ -849,8 +890,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       }
       float cs = stB(stA(0));
       float cq = act_d1<TANH>(cs) * zdin(0);
-      a[l - 2][0] = cs;
-      zd[l - 2][0] = zdin(0);
+      a[l - 2].set(0, cs);
+      zd[l - 2].set(0, zdin(0));
       float s1 = (KS > 1) ? stB(stA(1)) : 0.f;
       float e2 = (KS > 2) ? stA(2) : 0.f;
 #pragma unroll
@@ -877,8 +918,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         if (ks + 1 < KS) {
           const float zz = zdin(ks + 1);
           q1 = act_d1<TANH>(s1) * zz;
-          a[l - 2][ks + 1] = s1;
-          zd[l - 2][ks + 1] = zz;
+          a[l - 2].set(ks + 1, s1);
+          zd[l - 2].set(ks + 1, zz);
         }
         __builtin_amdgcn_sched_barrier(0);
         cs = s1; cq = q1; s1 = s2; e2 = e3;
@@ -903,20 +944,29 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
       for (int m = 0; m < MT; ++m) { pv[m] = nv[m]; ptn[m] = nt[m]; }
     }
+    // rows (2j, 2j+1) of an accumulator tile are a register pair: pairs of k-steps per packed instruction (the
+    // second half of a last, odd pair is a padding row: computed, never used)
+    auto pairOf = [](const f32x4 (&t)[MT], int j) { return f32x2{t[(2 * j) >> 2][(2 * j) & 3], t[(2 * j) >> 2][((2 * j) & 3) + 1]}; };
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      a[L - 1][ks] = act_fin<TANH>(act_exp<TANH>(pv[ks >> 2][ks & 3]));
-      zd[L - 1][ks] = ptn[ks >> 2][ks & 3];
+    for (int j = 0; j < PA<KS>::NP; ++j) {
+      a[L - 1].p[j] = act_fin2<TANH>(act_exp2<TANH>(pairOf(pv, j)));
+      zd[L - 1].p[j] = pairOf(ptn, j);
     }
     STAMP(1);
     // output layer (VALU)
     float u = 0.f, ud = 0.f;
+    {
+      f32x2 u2 = {0.f, 0.f}, ud2 = {0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float wv = WO[4 * ks + lc.g];
-      const float av = a[L - 1][ks];
-      u += wv * av;
-      ud += wv * (act_d1<TANH>(av) * zd[L - 1][ks]);
+      for (int j = 0; j < PA<KS>::NP; ++j) {
+        const bool full = 2 * j + 1 < KS;
+        const f32x2 wv = {WO[4 * (2 * j) + lc.g], full ? WO[4 * (2 * j + 1) + lc.g] : 0.f};
+        const f32x2 av = a[L - 1].p[j];
+        u2 += wv * av;
+        ud2 += wv * (act_d1_2<TANH>(av) * zd[L - 1].p[j]);
+      }
+      u = u2[0] + u2[1];
+      ud = ud2[0] + ud2[1];
     }
     u += __shfl_xor(u, 16, 64);  ud += __shfl_xor(ud, 16, 64);
     u += __shfl_xor(u, 32, 64);  ud += __shfl_xor(ud, 32, 64);
@@ -992,15 +1042,17 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 
     STAMP(2);
     // ---------------------------------------------------------------- backward
-    float zb[KS], zdb[KS];
+    PA<KS> zb, zdb;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float wv = WO[4 * ks + lc.g];
-      const float av = opaque(a[L - 1][ks]);
-      const float sp = act_d1<TANH>(av);
-      const float ab = ubar * wv, adb = udbar * wv;
-      zdb[ks] = adb * sp;
-      zb[ks] = ab * sp + adb * sp * act_d2r<TANH>(av) * zd[L - 1][ks];
+    for (int j = 0; j < PA<KS>::NP; ++j) {
+      const bool full = 2 * j + 1 < KS;
+      const f32x2 wv = {WO[4 * (2 * j) + lc.g], full ? WO[4 * (2 * j + 1) + lc.g] : 0.f};
+      const f32x2 av = opaque2(a[L - 1].p[j]);
+      const f32x2 sp = act_d1_2<TANH>(av);
+      const f32x2 ab = wv * f32x2{ubar, ubar}, adb = wv * f32x2{udbar, udbar};
+      const f32x2 zq = adb * sp;
+      zdb.p[j] = zq;
+      zb.p[j] = ab * sp + zq * act_d2r_2<TANH>(av) * zd[L - 1].p[j];
     }
     STAMP(3);
     thin_wgrad_out<KS, TANH>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0]);
@@ -1015,9 +1067,9 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         f32x4 rv[MT], rt[MT];
         layer1_raw(xr, gr, rv, rt);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          a[0][ks] = act_fin<TANH>(act_exp<TANH>(rv[ks >> 2][ks & 3]));
-          zd[0][ks] = rt[ks >> 2][ks & 3];
+        for (int j = 0; j < PA<KS>::NP; ++j) {
+          a[0].p[j] = act_fin2<TANH>(act_exp2<TANH>(pairOf(rv, j)));
+          zd[0].p[j] = pairOf(rt, j);
         }
       }
       if constexpr (HID13) {
@@ -1091,13 +1143,25 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         accv[MT - 1][0] = vsel;
         acct[MT - 1][0] = tsel;
       }
+      // zbar of layer l-1, two k-steps per packed instruction (accumulator rows ks, ks+1 are a register pair)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float av = opaque(a[l - 2][ks]);
-        const float sp = act_d1<TANH>(av);
-        const float ab = accv[ks >> 2][ks & 3], adb = acct[ks >> 2][ks & 3];
-        zdb[ks] = adb * sp;
-        zb[ks] = ab * sp + adb * sp * act_d2r<TANH>(av) * zd[l - 2][ks];
+      for (int j = 0; j < PA<KS>::NP; ++j) {
+        const int ks = 2 * j;
+        if (ks + 1 < KS) {
+          const f32x2 av = opaque2(a[l - 2].p[j]);
+          const f32x2 sp = act_d1_2<TANH>(av);
+          const f32x2 ab = {accv[ks >> 2][ks & 3], accv[ks >> 2][(ks & 3) + 1]};
+          const f32x2 adb = {acct[ks >> 2][ks & 3], acct[ks >> 2][(ks & 3) + 1]};
+          const f32x2 zq = adb * sp;
+          zdb.p[j] = zq;
+          zb.p[j] = ab * sp + zq * act_d2r_2<TANH>(av) * zd[l - 2].p[j];
+        } else {
+          const float av = opaque(a[l - 2][ks]);
+          const float sp = act_d1<TANH>(av);
+          const float ab = accv[ks >> 2][ks & 3], adb = acct[ks >> 2][ks & 3];
+          zdb.set(ks, adb * sp);
+          zb.set(ks, ab * sp + adb * sp * act_d2r<TANH>(av) * zd[l - 2][ks]);
+        }
       }
       STAMP(6);
     }
