@@ -875,10 +875,15 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         nv[m] = *reinterpret_cast<const f32x4a*>(&BI[(l - 1) * 64 + m * 16 + lc.g * 4]);
         nt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      auto zin = [&](int j) { return pv[j >> 2][j & 3]; };
-      auto zdin = [&](int j) { return ptn[j >> 2][j & 3]; };
-      auto stA = [&](int j) { return act_exp<TANH>(zin(j)); };
-      auto stB = [&](float e) { return act_fin<TANH>(e); };
+      // Activation of the previous layer, pipelined under this layer's MFMAs in PAIRS of k-steps (rows 2j, 2j+1 of an
+      // accumulator tile are a register pair): stage A = packed scale + 2 v_exp, stage B = packed 1+e + 2 v_rcp,
+      // stage C = packed sigma' * zdot.  Pair j is consumed by k-steps 2j and 2j+1; A(j+3) is issued after the first
+      // of them, B(j+2) and C(j+1) after the second, so no transcendental chain is longer than one stage.
+      // (The edge rows stay scalar FMAs: packing them -- across the edge features with splat activations, or along k
+      // with weight pairs -- was measured 2.4-3.8 % SLOWER: the extra register pairs push 25 -> 48 spilled VGPRs.)
+      constexpr int NP = PA<KS>::NP;
+      auto zin2 = [&](int j) { return f32x2{pv[(2 * j) >> 2][(2 * j) & 3], pv[(2 * j) >> 2][((2 * j) & 3) + 1]}; };
+      auto zdin2 = [&](int j) { return f32x2{ptn[(2 * j) >> 2][(2 * j) & 3], ptn[(2 * j) >> 2][((2 * j) & 3) + 1]}; };
       float wf[MTM], we[NVE], ev[NVE], et[NVE];
 #pragma unroll
       for (int m = 0; m < MTM; ++m) wf[m] = Wl[lc.offF + 16 * m];
@@ -888,20 +893,23 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         ev[v] = 0.f;
         et[v] = 0.f;
       }
-      float cs = stB(stA(0));
-      float cq = act_d1<TANH>(cs) * zdin(0);
-      a[l - 2].set(0, cs);
-      zd[l - 2].set(0, zdin(0));
-      float s1 = (KS > 1) ? stB(stA(1)) : 0.f;
-      float e2 = (KS > 2) ? stA(2) : 0.f;
+      f32x2 cs2 = act_fin2<TANH>(act_exp2<TANH>(zin2(0)));
+      f32x2 cq2 = act_d1_2<TANH>(cs2) * zdin2(0);
+      a[l - 2].p[0] = cs2;
+      zd[l - 2].p[0] = zdin2(0);
+      f32x2 s1 = (NP > 1) ? act_fin2<TANH>(act_exp2<TANH>(zin2(1))) : f32x2{0.f, 0.f};
+      f32x2 e2 = (NP > 2) ? act_exp2<TANH>(zin2(2)) : f32x2{0.f, 0.f};
+      f32x2 e3 = {0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
+        const int j = ks >> 1;
         float wn[MTM], wen[NVE];
 #pragma unroll
         for (int m = 0; m < MTM; ++m) wn[m] = (ks + 1 < KS) ? Wl[4 * (ks + 1) * WS + lc.offF + 16 * m] : 0.f;
 #pragma unroll
         for (int v = 0; v < NVE; ++v)
           wen[v] = (EDGE && ks + 1 < KS) ? Wl[4 * (ks + 1) * WS + lc.offF - lc.c + EPOS + 4 * v] : 0.f;
+        const float cs = cs2[ks & 1], cq = cq2[ks & 1];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MTM; ++m) {
@@ -912,17 +920,21 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
           for (int v = 0; v < NVE; ++v) { ev[v] += we[v] * cs; et[v] += we[v] * cq; }
         }
-        float e3 = 0.f, s2 = 0.f, q1 = 0.f;
-        if (ks + 3 < KS) e3 = stA(ks + 3);
-        if (ks + 2 < KS) s2 = stB(e2);
-        if (ks + 1 < KS) {
-          const float zz = zdin(ks + 1);
-          q1 = act_d1<TANH>(s1) * zz;
-          a[l - 2].set(ks + 1, s1);
-          zd[l - 2].set(ks + 1, zz);
+        if ((ks & 1) == 0) {
+          if (j + 3 < NP) e3 = act_exp2<TANH>(zin2(j + 3));                  // stage A of pair j+3
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          f32x2 s2 = s1, q1 = cq2;
+          if (j + 2 < NP) s2 = act_fin2<TANH>(e2);                            // stage B of pair j+2
+          if (j + 1 < NP) {                                                    // stage C of pair j+1
+            const f32x2 zz = zdin2(j + 1);
+            q1 = act_d1_2<TANH>(s1) * zz;
+            a[l - 2].p[j + 1] = s1;
+            zd[l - 2].p[j + 1] = zz;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          cs2 = s1; cq2 = q1; s1 = s2; e2 = e3;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        cs = s1; cq = q1; s1 = s2; e2 = e3;
 #pragma unroll
         for (int m = 0; m < MTM; ++m) wf[m] = wn[m];
 #pragma unroll
