@@ -255,16 +255,17 @@ __device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const B
   for (int t = 0; t < W::TPW; ++t) rdBt[t] = trow<KSB>(16 * (n0 + t) + lc.c) * TSW + sidx * W::PTS + goff;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    if constexpr (RAWA) {
 #pragma unroll
-    for (int ks = 0; ks < KSA; ++ks) {
-      float v;
-      if (half == 0) v = av[ks];
-      else if (RAWA) v = azd[ks];
-      else {
-        const float x = opaque(av[ks]);
-        v = act_d1<TANH>(x) * azd[ks];
+      for (int ks = 0; ks < KSA; ++ks) t_write<KSA>(TA, lc, ks, half == 0 ? av[ks] : azd[ks]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < PA<KSA>::NP; ++j) {            // sigma'(a) * zdot for two k-steps per packed instruction
+        f32x2 v2 = av.p[j];
+        if (half == 1) v2 = act_d1_2<TANH>(opaque2(av.p[j])) * azd.p[j];
+        t_write<KSA>(TA, lc, 2 * j, v2[0]);
+        if (2 * j + 1 < KSA) t_write<KSA>(TA, lc, 2 * j + 1, v2[1]);
       }
-      t_write<KSA>(TA, lc, ks, v);
     }
     if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
 #pragma unroll
@@ -351,13 +352,11 @@ __device__ __forceinline__ void thin_wgrad_out(const AV& av, const AV& azd, floa
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      float v = av[ks];
-      if (half == 1) {
-        const float x = opaque(av[ks]);
-        v = act_d1<TANH>(x) * azd[ks];
-      }
-      t_write<KS>(TA, lc, ks, v);
+    for (int j = 0; j < PA<KS>::NP; ++j) {
+      f32x2 v2 = av.p[j];
+      if (half == 1) v2 = act_d1_2<TANH>(opaque2(av.p[j])) * azd.p[j];
+      t_write<KS>(TA, lc, 2 * j, v2[0]);
+      if (2 * j + 1 < KS) t_write<KS>(TA, lc, 2 * j + 1, v2[1]);
     }
     if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
     TB[lc.twr] = (lc.g == 0) ? (half == 0 ? ubar : udbar) : 0.f;
