@@ -1,0 +1,41 @@
+"""Fixed cost of one fused launch: time of vn_grad on an EMPTY batch (n_k = 0, nB = 0: prologue + epilogue only)
+and on 1 / 2 tiles per workgroup, for the 5x50 and 4x50 nets.   python tools/fixed_cost.py"""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from varnet_amd.engine import VNEngine
+for widths, d_in, dim, q in (([50] * 5, 3, 2, 64), ([50] * 4, 2, 1, 16), ([10, 20, 30], 3, 1, 16)):
+    for tiles_per_wg in (0, 1, 2, 4):
+        n_k = tiles_per_wg * 256 * (128 // q)
+        n = n_k * q
+        e = VNEngine(dim, d_in, widths, True, q)
+        e.init_params(0)
+        rng = np.random.default_rng(0)
+        e.set_fe_table(rng.uniform(0, 1, q), rng.standard_normal(q))
+        X = torch.rand(max(n, 1), d_in, device='cuda'); G = torch.randn(max(n, 1), dim, device='cuda')
+        e.set_interior(0, X[:n], G[:n], None, n_k=n_k, detJ=1e-3)
+        e.set_bic(None, None, 0, 1.0)
+        e.set_weights([1, 1, 1])
+        for _ in range(5): e.train_step(0)
+        torch.cuda.synchronize()
+        e.profile_begin()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(200): e.train_step(0)
+        ev1.record(); torch.cuda.synchronize()
+        ms, nl, kn = e.profile_end()
+        print('net %s q=%d: %d tiles/WG: fused kernel %.1f us, whole step %.1f us' % (widths, q, tiles_per_wg, ms * 1e3, ev0.elapsed_time(ev1) / 200 * 1e3))
+        e.close()
+
+# with a -DVN_FIXSTAMPS build (VARNET_HIP_LIB=.../libvarnet_hip_fix.so): where the empty launch's cycles go
+import os
+if 'fix' in os.environ.get('VARNET_HIP_LIB', ''):
+    e = VNEngine(2, 3, [50] * 5, True, 64)
+    e.init_params(0); e.set_fe_table(np.ones(64), np.ones(64))
+    X = torch.rand(1, 3, device='cuda'); G = torch.randn(1, 2, device='cuda')
+    e.set_interior(0, X[:0], G[:0], None, n_k=0, detJ=1e-3); e.set_bic(None, None, 0, 1.0); e.set_weights([1, 1, 1])
+    for _ in range(3): e.train_step(0)
+    torch.cuda.synchronize()
+    st = e.debug_stamps()
+    d = [st[i + 1] - st[i] for i in range(4)]
+    print('empty 5x50 launch, workgroup 0 (s_memtime ticks at 100 MHz -> us): prologue %.2f  loop %.2f  flush %.2f  store %.2f'
+          % tuple(x / 100.0 for x in d))

@@ -183,6 +183,19 @@ struct WG {
   static_assert(NT < NW || NTB % TPW == 0, "a wave's tiles must share a row tile");
 };
 
+#ifdef VN_FIXSTAMPS
+// Diagnostic build only (-DVN_FIXSTAMPS): s_memtime at entry / after the prologue / after the tile loop / after the
+// accumulator flush / at the end, workgroup 0 wave 0 -> A.stamps[0..4] (tools/fixed_cost.py)
+#define FIXSTAMP(i)                                                                  \
+  do {                                                                               \
+    unsigned long long t_;                                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    if (A.stamps && blockIdx.x == 0 && threadIdx.x == 0) A.stamps[i] = t_;           \
+  } while (0)
+#else
+#define FIXSTAMP(i) do {} while (0)
+#endif
+
 #ifdef VN_STAMPS
 // Diagnostic build only (-DVN_STAMPS=1: phases of the tile loop; =2: inside the cooperative weight
 // gradient: 0 inputs+forward, 1 epilogue, 2 publish, 3 wait at the publish barrier, 4 contraction,
@@ -704,6 +717,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   const unsigned t_base_bytes = (unsigned)((LY::T_OFF + wave * 64) * 4);      // lane-major images: this wave's columns
   float* Gacc = lds + LY::T_OFF;
 
+  FIXSTAMP(0);
   // ------------------------------------------------------------------ prologue: LDS images
   {
     // every thread first issues ALL its parameter loads (L2 latency ~1 us each if taken one by one), then
@@ -755,6 +769,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   }
   __syncthreads();
 
+  FIXSTAMP(1);
   LaneC lc;
   lc.g = lane >> 4;
   lc.c = lane & 15;
@@ -1181,6 +1196,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     STAMP(7);
   }
 
+  FIXSTAMP(2);
   // ------------------------------------------------------------------ epilogue
 #ifdef VN_STAMPS
   if (A.stamps && blockIdx.x == 0 && tid == 64 * VN_STAMP_WAVE)
@@ -1246,6 +1262,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       __syncthreads();
     }
   }
+  FIXSTAMP(3);
   float* out = A.partial + (long)blockIdx.x * P;
 #pragma unroll
   for (int l = 1; l <= L + 1; ++l) {
@@ -1275,6 +1292,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     for (int w = 0; w < NW; ++w) s += sInt[w * 3 + tid];
     A.losspart[blockIdx.x * 3 + tid] = s;
   }
+  FIXSTAMP(4);
 }
 
 template <int L, int KS, bool TANH>
