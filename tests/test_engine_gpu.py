@@ -559,3 +559,39 @@ def test_reference_assembled_inputs_through_engine(key, widths):
     assert abs(gg[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
     assert np.max(np.abs(gg[:eng.P] - gref)) / np.max(np.abs(gref)) <= GRAD_RTOL
     eng.close()
+
+
+@pytest.mark.parametrize('kernel', [1, 0], ids=['generic', 'auto'])
+def test_empty_tower_feed(kernel):
+    """n_k == 0 (a tower block past the end of the set, VarNetUtility.py:830-838): only the BC/IC rows count;
+    with no BC/IC rows either, loss and gradient are exactly zero and nothing faults."""
+    from varnet_amd.engine import VNEngine
+    d = synth(3, 3, 2, [50] * 3, 64, 4, 50, 20)
+    eng = VNEngine(2, 3, [50] * 3, True, 64, kernel=kernel)
+    eng.init_params(seed=3)
+    flat = eng.get_params()
+    eng.set_fe_table(d['N1'], d['dNt1'], None)
+    empty = torch.zeros(0, 3, device='cuda')
+    eng.set_interior(0, empty, torch.zeros(0, 2, device='cuda'), None, n_k=0, detJ=0.137)
+    eng.set_bic(d['biInput'], d['biLabel'], 20, 2.0)
+    eng.set_weights(d['w'])
+    ref, gref = og.loss_and_grad(
+        flat.astype(np.float64), 3, [50] * 3, torch.float64, Input=np.zeros((0, 3)), gcoef=np.zeros((0, 2)), source=None,
+        N=np.zeros((0, 1)), dNt=np.zeros((0, 1)), integW=None, intShape=[0, 64], detJ=0.137, detJvec=False,
+        biInput=d['biInput'].astype(np.float64), biLabel=d['biLabel'].astype(np.float64), bDof=20, biDimVal=2.0,
+        w=d['w'], dim=2, time_dependent=True, is_source=False, integWflag=False)
+    out, lv = eng.eval_loss(0, lossVec=True)
+    assert lv.numel() == 0 and out[3] == 0.0
+    assert abs(out[0] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy()
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
+    assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
+    eng.set_bic(None, None, 0, 2.0)                     # nothing at all
+    out, _ = eng.eval_loss(0)
+    eng.grad(0)
+    torch.cuda.synchronize()
+    assert out == [0.0, 0.0, 0.0, 0.0] and not gb.cpu().numpy().any()
+    eng.close()
