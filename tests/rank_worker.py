@@ -108,3 +108,19 @@ def run_controller(outdir, backend, ngpu_entries, q):
     except Exception:
         import traceback
         q.put((1, traceback.format_exc()))
+
+
+def run_c_host(root, outdir, q):
+    """Build and run examples/c_host_step.c: a plain-C host on the C ABI, no Python / PyTorch in the process."""
+    import subprocess
+    exe = os.path.join(outdir, 'c_host_step')
+    cc = subprocess.run(['gcc', '-O2', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I' + os.path.join(root, 'include'),
+                         os.path.join(root, 'examples', 'c_host_step.c'), '-L/opt/rocm/lib', '-lamdhip64', '-ldl', '-lm',
+                         '-o', exe], capture_output=True, text=True)
+    if cc.returncode != 0:
+        q.put((cc.returncode, 'gcc failed:\n' + cc.stderr))
+        return
+    env = dict(os.environ, LD_LIBRARY_PATH='/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', ''))
+    r = subprocess.run([exe, os.path.join(root, 'varnet_amd', 'libvarnet_hip.so')], capture_output=True, text=True,
+                       env=env, timeout=300)
+    q.put((r.returncode, r.stdout + '\n' + r.stderr))

@@ -65,3 +65,19 @@ def test_product_package_never_imports_oracle():
         if f.endswith('.py'):
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+@pytest.mark.gpu
+def test_plain_c_host_trains_through_the_abi(tmp_path):
+    """examples/c_host_step.c: gcc-compiled C program (HIP runtime API for memory, dlopen of the library) runs 200
+    training steps through the C ABI -- no Python, no PyTorch in that process -- and the loss falls."""
+    from tests import conftest, rank_worker as rw
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    q = conftest.FORKSERVER.Queue()
+    p = conftest.FORKSERVER.Process(target=rw.run_c_host, args=(root, str(tmp_path), q))
+    p.start()
+    rc, text = q.get(timeout=600)
+    p.join(60)
+    assert rc == 0 and 'C_HOST_OK' in text, text
