@@ -182,13 +182,38 @@ int check_batch(vn_engine* h, int32_t batch) {
   return VN_OK;
 }
 
+// Model value (and directional derivative along G, if given) at n rows with the 8-wave fused kernel in its
+// forward-only mode: 2 F_pt per row at the fused kernel's efficiency instead of the generic forward kernel.
+int fused_forward(vn_engine* h, const float* X, const float* G, long n, float* out_u, float* out_ud) {
+  if (n <= 0) return VN_OK;
+  VnFusedArgs f{};
+  f.net = h->net; f.theta = h->theta; f.X = X; f.G = G; f.src = nullptr;
+  f.nT = n; f.n_k = 0; f.integ_num = h->cfg.integ_num;
+  f.feN = h->feN; f.fedNt = h->fedNt; f.feW = nullptr; f.detJv = nullptr; f.detJ = 0.f;
+  f.time_dependent = h->cfg.time_dependent; f.lossVec = nullptr;
+  f.Xb = nullptr; f.label = nullptr; f.nB = 0; f.bDof = 0; f.biDimVal = 0.f;
+  f.w0 = f.w1 = f.w2 = 0.f;
+  f.partial = h->partial; f.losspart = h->fused_losspart ? h->fused_losspart : h->tp_losspart; f.stamps = nullptr;
+  f.mode = 1; f.dir = G ? -1 : 0; f.ostride = 1; f.out_u = out_u; f.out_ud = G ? out_ud : nullptr;
+  const long tiles = (n + 127) / 128;
+  const int grid = (int)(tiles < h->ncu ? tiles : h->ncu);
+  HIPCHK(vn_fused16_launch(f, grid, h->stream));
+  return VN_OK;
+}
+
 // forward + weak-form epilogue; with_seeds = also produce backward seeds.
 int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* lossVec, float* lossdst) {
   const long nT = b.n_k * h->cfg.integ_num;
-  VnRows s0{}, s1{};
-  s0.X = b.Input; s0.G = b.gcoef; s0.u = h->u; s0.ud = h->ud; s0.n = nT;
-  s1.X = h->biInput; s1.G = nullptr; s1.u = h->ub; s1.ud = nullptr; s1.n = h->nB;
-  HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));
+  if (h->use_fused16 && h->has_fe && !with_seeds) {
+    // splitLoss / trainWeight / the monitors: the fused kernel's forward-only mode for both row sets
+    if (int rc = fused_forward(h, b.Input, b.gcoef, nT, h->u, h->ud)) return rc;
+    if (int rc = fused_forward(h, h->biInput, nullptr, h->nB, h->ub, nullptr)) return rc;
+  } else {
+    VnRows s0{}, s1{};
+    s0.X = b.Input; s0.G = b.gcoef; s0.u = h->u; s0.ud = h->ud; s0.n = nT;
+    s1.X = h->biInput; s1.G = nullptr; s1.u = h->ub; s1.ud = nullptr; s1.n = h->nB;
+    HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));
+  }
 
   const long nthreads = b.n_k > h->nB ? b.n_k : h->nB;
   const int grid = (int)(((nthreads > 0 ? nthreads : 1) + 255) / 256);      // an empty set still zeroes its partials
@@ -801,6 +826,7 @@ int vn_eval_loss(vn_engine* h, int32_t batch, double out[4], float* lossVec_dev)
 int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
   if (!h || (n > 0 && (!X || !u))) return fail(VN_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->use_fused16) return fused_forward(h, X, nullptr, n, u, nullptr);
   VnRows s0{}, s1{};
   s0.X = X; s0.G = nullptr; s0.u = u; s0.ud = nullptr; s0.n = n;
   HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));

@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     if (A.mode == 1) {                                       // forward only: model value and directional derivative
       if (valid && lc.g == 0) {
         if (A.out_u) A.out_u[row] = u;
-        A.out_ud[row * A.ostride] = ud;
+        if (A.out_ud) A.out_ud[row * A.ostride] = ud;
       }
       continue;
     }
