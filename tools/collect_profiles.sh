@@ -23,6 +23,10 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BA
   t=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --kernel-trace -d $out/gpmc_$t -o p --output-format csv -- python tools/width_perf.py 64 3 > $out/gpmc_$t.log 2>&1
 done
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
+  t=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace -d $out/tpmc_$t -o p --output-format csv -- python tools/q216_perf.py > $out/tpmc_$t.log 2>&1
+done
 python tools/shard_perf.py > $out/shard_perf.txt 2>&1
 python tools/mor_perf.py > $out/mor_perf.txt 2>&1
 python tools/width_perf.py 60 4 > $out/width60.txt 2>&1

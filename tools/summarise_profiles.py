@@ -13,6 +13,23 @@ for sub, dst in (('stats_q216', '%s_twopass_q216_kernel_stats.csv'), ('stats_gen
     g = glob.glob(src + '/' + sub + '/**/s_kernel_stats.csv', recursive=True)
     if g:
         shutil.copy(g[0], 'profiles/' + dst % pre)
+tp = {}
+for f in glob.glob(src + '/tpmc_*/**/p_counter_collection.csv', recursive=True):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        for kn in ('vn_fused16_kernel', 'vn_seed_kernel'):
+            if kn in r['Kernel_Name']:
+                d[kn][r['Counter_Name']].append(float(r['Counter_Value']))
+    for kn, dd in d.items():
+        for k, v in dd.items():
+            v = sorted(v)
+            # the fused kernel runs twice per step (forward-only, then reverse with seeds): report both halves
+            tp.setdefault(kn, {})[k] = {'min': v[0], 'median': v[len(v) // 2], 'max': v[-1], 'launches': len(v)}
+if tp:
+    tp['note'] = ('two-pass route at integNum 216 (tools/q216_perf.py: 30 000 test functions x 216 points, 5x50): per launch; '
+                  'vn_fused16_kernel is launched in forward-only mode (min column) and in reverse mode (max column) each step; '
+                  'MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / (GRBM_GUI_ACTIVE / 8)')
+    json.dump(tp, open('profiles/%s_pmc_twopass.json' % pre, 'w'), indent=1)
 gen = {}
 for f in glob.glob(src + '/gpmc_*/**/p_counter_collection.csv', recursive=True):
     d = collections.defaultdict(list)
