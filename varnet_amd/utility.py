@@ -5,6 +5,8 @@ polyArea/buildDict/reorderList/mergeDict).  Same names and argument meaning so t
 scripts written against the reference keep working.
 """
 import numbers
+import os
+
 import numpy as np
 
 
@@ -203,6 +205,38 @@ class UF:
                 out.extend('%s(%d,%d) = \t%s;\n' % (fieldname, i + 1, j + 1, str(mat[i, j])) for i in range(sh[0]))
         with open(filename, 'w') as f:
             f.write(''.join(out))
+
+    def clearFolder(self, folderpath, ask=True):
+        """Empty `folderpath` (files and sub-folders); like the reference (UtilityFunc.py:502-523) it asks on the console
+        first unless `ask=False`.  The operator scripts call it before `train` (Operator_1Dt.py:167)."""
+        import shutil
+        entries = os.listdir(folderpath)
+        if not entries:
+            return
+        while ask:
+            answer = input('clear the content of the folder? (y/n)\n').lower()
+            if answer in ('y', 'yes'):
+                break
+            if answer in ('n', 'no'):
+                return
+        for name in entries:
+            path = os.path.join(folderpath, name)
+            try:
+                if os.path.isdir(path) and not os.path.islink(path):
+                    shutil.rmtree(path)
+                else:
+                    os.remove(path)
+            except OSError as e:
+                print(e)
+
+    def copyFile(self, filename, folderpath):
+        """Back up a file (the operator script itself, Operator_1Dt.py:168) into `folderpath` (UtilityFunc.py:526-538)."""
+        import shutil
+        if not os.path.exists(filename):
+            filename = os.path.join(os.getcwd(), filename)
+            if not os.path.exists(filename):
+                raise ValueError('The file does not exist!')
+        shutil.copy2(filename, folderpath)
 
     def nodeNum(self, x, val):
         """Index of the entry of x closest to each value in val."""
