@@ -92,6 +92,34 @@ class ContourPlot:
             plt.axis('scaled')
         return field
 
+    def animPlot(self, func, t=[], figNum=None, title=None, fill_val=0., draw=True):
+        """Frames of a 2D time-dependent field (ContourPlot.py:199-258): returns the list of [discNum, discNum] fields for
+        the times `t` (default: 5 over the time interval); draws them one after the other when matplotlib is there."""
+        if not callable(func):
+            raise ValueError('field function must be callable!')
+        if self.status in ('1D-time', '2D'):
+            raise ValueError('animation contour plot is only available for 2D time-dependent problems!')
+        if np.size(t) == 0:
+            t = np.linspace(self.tInterval[0], self.tInterval[1], num=5)
+        frames = []
+        for ti in t:
+            f = self.field(func, float(ti), fill_val)
+            frames.append(f)
+            if draw:
+                try:
+                    import matplotlib.pyplot as plt
+                except ImportError:
+                    continue
+                plt.figure(0 if figNum is None else figNum)
+                cP = plt.contourf(self.xx, self.yy, f)
+                plt.colorbar(cP)
+                tt = 't = {0:.2f}s'.format(ti)
+                plt.title(tt if title is None else title + '-' + tt)
+                plt.xlabel('$x_1$')
+                plt.ylabel('$x_2$')
+                plt.axis('scaled')
+        return frames
+
     def snap1Dt(self, func, t, lineOpt=None, figNum=None, title=None, draw=True):
         x, f = self.snap(func, t)
         if draw:
