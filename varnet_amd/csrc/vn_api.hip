@@ -411,8 +411,11 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
                 e == hipSuccess ? "device count 0" : hipGetErrorString(e));
   if (cfg->device < 0 || cfg->device >= ndev) return fail(VN_EINVAL, "requested processor %d is unavailable!", cfg->device);
   HIPCHK(hipSetDevice(cfg->device));
-  if (vn_generic_bwd_lds_bytes(net) > 160 * 1024)
-    return fail(VN_EUNSUPPORTED, "network needs %zu B of LDS per tile (> 160 KiB): reduce depth/width",
+  // the generic backward kernel keeps every layer of a tile in LDS; nets it cannot hold are fine as long as the
+  // fused kernel (which the AUTO choice then uses, directly or through the two-pass route) is instantiated for them
+  const bool fused_ok = cfg->kernel != VN_KERNEL_GENERIC && cfg->kernel != VN_KERNEL_FUSED && vn_fused16_net_supported(net);
+  if (!fused_ok && vn_generic_bwd_lds_bytes(net) > 160 * 1024)
+    return fail(VN_EUNSUPPORTED, "network needs %zu B of LDS per tile on the generic kernels (> 160 KiB): reduce depth/width",
                 vn_generic_bwd_lds_bytes(net));
   vn_engine* h = new vn_engine();
   h->cfg = *cfg;              // taken literally (lr = 0 is a legal, if useless, TF learning rate: TFModel.py:130)
