@@ -47,9 +47,8 @@ enum {
 enum { VN_ACT_SIGMOID = 0, VN_ACT_TANH = 1 };   /* activationFun options of the constructor (VarNet.py:97) */
 enum { VN_OPT_ADAM = 0, VN_OPT_RMSPROP = 1 };   /* tf.train.AdamOptimizer / RMSPropOptimizer (TFModel.py:183-186) */
 /* Kernel families.  AUTO picks the 8-wave fused kernel where it is instantiated: uniform or ragged hidden widths
- * <= 20 / 32 (2..6 layers), <= 50 (2..5 layers), <= 63 (2..5 layers), d_in <= 8, sigmoid or tanh; integ_num <= 128
- * in one launch, larger through the two-pass route.  Everything else the ABI accepts (one hidden layer, width 64,
- * 6 layers wider than 32) runs on the generic kernels. */
+ * <= 50 with 1..6 layers, <= 64 with 1..5 layers, d_in <= 8, sigmoid or tanh; integ_num <= 128 in one launch, larger
+ * through the two-pass route.  What is left (6 layers wider than 50) runs on the generic kernels. */
 enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 /* 4 waves, 32x32x2 */,
        VN_KERNEL_FUSED16 = 3 /* 8 waves, 16x16x4 */ };
 

@@ -95,11 +95,14 @@ CASES = [
     (3, 2, [51, 63, 57],         36,      17,  12,  5,   True,  True,  True),
     (2, 1, [63, 63],             16,      90,  33,  11,  True,  False, False),
     (3, 2, [60, 60, 60, 60, 60], 64,      9,   77,  40,  False, False, False),
-    (3, 2, [64, 64],             64,      6,   20,  8,   False, False, False),   # 64 wide: generic kernels
+    (3, 2, [64, 64],             64,      6,   20,  8,   False, False, False),   # 64 wide: bias gradient by thin_bias
     (2, 1, [20],                 16,      300, 40,  25,  False, False, False),   # one hidden layer (Operator_1Dt.py:156)
     (3, 2, [50],                 64,      40,  30,  10,  True,  False, True),
     (3, 2, [60],                 36,      21,  30,  10,  False, True,  False),
     (3, 2, [50] * 6,             64,      12,  30,  10,  False, False, False),   # six hidden layers, 50 wide
+    (3, 2, [64, 64, 64, 64],     64,      40,  70,  30,  True,  False, True),    # 64 wide, several tiles
+    (2, 1, [64, 40, 64],         16,      77,  33,  11,  False, False, False),   # 64 wide next to narrower layers
+    (3, 2, [64],                 36,      21,  30,  10,  False, True,  False),   # one 64-wide layer: output bias per lane
 ]
 
 
@@ -108,7 +111,7 @@ def _skip_unsupported(kernel, widths, integNum):
                         (max(widths) > 20 and len(widths) < 2) or (max(widths) > 32 and len(widths) < 3) or
                         len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused32 not instantiated for this shape')
-    if kernel == 3 and (max(widths) > 63 or len(widths) > (5 if max(widths) > 50 else 6)):   # integNum > 128: two-pass
+    if kernel == 3 and len(widths) > (5 if max(widths) > 50 else 6):   # integNum > 128: two-pass
         pytest.skip('fused16 not instantiated for this shape')
 
 

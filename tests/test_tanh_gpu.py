@@ -18,7 +18,7 @@ def engine(d_in, dim, widths, q, source, integW, kernel):
                     activationFun='tanh')
 
 
-TCASES = [CASES[i] for i in (0, 1, 2, 4, 5, 7, 9, 11, 12, 14, 15, 19, 20, 22)]
+TCASES = [CASES[i] for i in (0, 1, 2, 4, 5, 7, 9, 11, 12, 14, 15, 18, 19, 20, 22, 23, 24, 25)]
 
 
 @pytest.mark.parametrize('kernel', [1, 0], ids=['generic', 'auto'])
@@ -27,7 +27,7 @@ def test_tanh_loss_and_grad_parity(case, kernel):
     d_in, dim, widths, q, n_k, nB, bDof, source, integW, detJvec = case
     d = synth(2, d_in, dim, widths, q, n_k, nB, bDof, source, integW, detJvec)
     eng = engine(d_in, dim, widths, q, source, integW, kernel)
-    if kernel == 0 and max(widths) <= 63 and len(widths) <= (5 if max(widths) > 50 else 6):
+    if kernel == 0 and len(widths) <= (5 if max(widths) > 50 else 6):
         assert eng.kernel_path()[0] == 3                       # the 8-wave fused kernel carries tanh
     eng.init_params(seed=3)
     flat = eng.get_params() + 0.05 * np.random.default_rng(5).standard_normal(eng.P).astype(np.float32)

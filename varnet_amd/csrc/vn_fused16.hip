@@ -52,8 +52,8 @@ __host__ __device__ constexpr int vpos(int ks, int g) { return 16 * (ks >> 2) + 
 __host__ __device__ constexpr int vks(int pos) { return 4 * (pos >> 4) + (pos & 3); }
 __host__ __device__ constexpr int vfeat(int pos) { return 4 * vks(pos) + ((pos >> 2) & 3); }
 // Position of the constant-one row that carries the bias gradient: the first position past the layer's k-steps.
-// KS == 16 (widths 51..63) has no position to spare, so the row of feature 63 -- which such a layer does not have --
-// is used; a 64-wide layer therefore stays on the generic kernels.
+// KS == 16 (widths 51..64) has no position to spare, so the row of feature 63 is used where the layer does not have
+// that feature; behind a 64-wide layer the bias gradient is summed by thin_bias instead (ones_row = false).
 __host__ __device__ constexpr int vones(int KS) {
   if (KS == 16) return 63;
   for (int p = 0; p < 64; ++p)
@@ -250,9 +250,11 @@ __device__ __forceinline__ void t_write(float* T, const LaneC& lc, int ks, float
 // Cooperative weight gradient (see vn_fused.hip): all waves publish their 16 point-columns of
 // the transposed operands, then each wave contracts its output tile(s) over its share of the
 // 128 points into persistent accumulators.
+// ones_row: the layer's input side has a position to spare for the constant-one row that carries the bias gradient
+// (always, except for a 64-wide input side at KS == 16: then the bias gradient comes from thin_bias below).
 template <int KSA, int KSB, bool RAWA, bool TANH, int NACC, class AV, class BV>
 __device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const BV& bv, const BV& bt, float* TA,
-                                            float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC] STAMP_PARAMS) {
+                                            float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC], bool ones_row STAMP_PARAMS) {
   using W = WG<KSA, KSB>;
   static_assert(NACC == W::TPW, "accumulator count");
   const int t0 = (W::NT >= NW) ? wave * W::TPW : wave % W::NT;
@@ -280,7 +282,7 @@ __device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const B
         if (2 * j + 1 < KSA) t_write<KSA>(TA, lc, 2 * j + 1, v2[1]);
       }
     }
-    if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
+    if (ones_row && lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks) t_write<KSB>(TB, lc, ks, (half == 0) ? bv[ks] : bt[ks]);
     WSTAMP(2);
@@ -360,7 +362,8 @@ __device__ __forceinline__ void thin_contract(const float* TA, const float* TB, 
 // into row 0, the other lane groups publish zeros into rows 4, 8, 12)
 template <int KS, bool TANH, class AV>
 __device__ __forceinline__ void thin_wgrad_out(const AV& av, const AV& azd, float ubar, float udbar,
-                                               float* TA, float* TB, const LaneC& lc, int wave, int lane, f32x4& acc) {
+                                               float* TA, float* TB, const LaneC& lc, int wave, int lane, f32x4& acc,
+                                               bool ones_row) {
   using W = WG<KS, 1>;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -371,7 +374,7 @@ __device__ __forceinline__ void thin_wgrad_out(const AV& av, const AV& azd, floa
       t_write<KS>(TA, lc, 2 * j, v2[0]);
       if (2 * j + 1 < KS) t_write<KS>(TA, lc, 2 * j + 1, v2[1]);
     }
-    if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
+    if (ones_row && lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
     TB[lc.twr] = (lc.g == 0) ? (half == 0 ? ubar : udbar) : 0.f;
     wave_lds_sync();
     thin_contract<KS, true>(TA, TB, (lane & 3) == 0 ? 0 : 4, wave, lane, acc);
@@ -380,14 +383,34 @@ __device__ __forceinline__ void thin_wgrad_out(const AV& av, const AV& azd, floa
 }
 
 template <int KS>
-__device__ __forceinline__ void thin_flush_out(const f32x4& acc, float* Gl, int lane) {
+__device__ __forceinline__ void thin_flush_out(const f32x4& acc, float* Gl, int lane, bool ones_row) {
   if ((lane & 3) != 0) return;                         // column j = 0 holds the products with ubar
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int pos = lane + i;
-    if (pos == vones(KS)) Gl[4 * KS] += acc[i];
+    if (ones_row && pos == vones(KS)) Gl[4 * KS] += acc[i];
     else if (vks(pos) < KS) Gl[vfeat(pos)] += acc[i];
   }
+}
+
+// Bias gradient of a layer whose 64-wide input side leaves no position for the constant-one row (KS == 16 only):
+// sum_p zbar[j][p] as a thin contraction of a ones row against the wave's own 16 columns of zbar -- one 4x4x1 MFMA
+// per point, no workgroup barrier (the images are free between two cooperative rounds; every wave touches only its
+// own columns).  bsum: this lane's position j = lane.
+template <int KS, class BV>
+__device__ __forceinline__ void thin_bias(const BV& bv, float* TA, float* TB, const LaneC& lc, int wave, int lane, float& bsum) {
+  using W = WG<KS0, KS>;
+  const int sel = lane & 3;
+  const int rowsel = sel == 3 ? W::ONES : 4 * sel;
+  TA[lc.twr] = 0.f;                                                               // rows 0, 4, 8, 12: unused
+  if (lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = 1.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) t_write<KS>(TB, lc, ks, bv[ks]);
+  wave_lds_sync();
+  f32x4 t = {0.f, 0.f, 0.f, bsum};
+  thin_contract<KS, false>(TA, TB, rowsel, wave, lane, t);
+  bsum = t[3];
+  wave_lds_sync();
 }
 
 // input layer, d_in <= 3: rows x0, x1, x2 (positions 0, 4, 8) and the bias row against all columns
@@ -640,7 +663,7 @@ __device__ __forceinline__ void h13_flush(const f32x4 (&acc)[2], float* Gl, cons
 }
 
 template <int KSA, int KSB, int GS, int NACC>
-__device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl, const LaneC& lc, int wave) {
+__device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl, const LaneC& lc, int wave, bool ones_row = true) {
   using W = WG<KSA, KSB>;
   const int t0 = (W::NT >= NW) ? wave * W::TPW : wave % W::NT;
   const int m = t0 / W::NTB, n0 = t0 % W::NTB;
@@ -653,7 +676,7 @@ __device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl,
     for (int i = 0; i < 4; ++i) {
       const int ks = 4 * m + i;
       int row = -1;
-      if (m == W::ones_m && i == W::ones_i && lc.g == W::ones_g) row = 4 * KSA;
+      if (ones_row && m == W::ones_m && i == W::ones_i && lc.g == W::ones_g) row = 4 * KSA;
       else if (ks < KSA) row = 4 * ks + lc.g;
       if (row >= 0 && colok) Gl[row * GS + col] += acc[t][i];
     }
@@ -811,6 +834,16 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 
   const float bo = A.theta[net.boff[L + 1]];
   const bool thin_in = net.d_in <= 3;                // input-layer weight gradient without workgroup barriers
+  // KS == 16 with a 64-wide layer: its output side has no position left for the constant-one row of the NEXT layer's
+  // weight gradient, whose bias gradient is then summed by thin_bias (hidden) / a per-lane scalar (output layer)
+  bool ones_h[L > 1 ? L - 1 : 1];                    // layer l = 2..L: input side H[l-1] < 64
+#pragma unroll
+  for (int l = 2; l <= L; ++l) ones_h[l - 2] = (KS != 16) || net.H[l - 1] < 64;
+  const bool ones_o = (KS != 16) || net.H[L] < 64;
+  float bsum_h[L > 1 ? L - 1 : 1];
+#pragma unroll
+  for (int l = 0; l < (L > 1 ? L - 1 : 1); ++l) bsum_h[l] = 0.f;
+  float bsum_o = 0.f;
   const int q = A.integ_num;
   const int TT = TILE / q;                                   // whole test functions per tile
   const int TPTS = TT * q;                                   // points used in an interior tile (<= TILE)
@@ -1081,7 +1114,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       zb.p[j] = ab * sp + zq * act_d2r_2<TANH>(av) * zd[L - 1].p[j];
     }
     STAMP(3);
-    thin_wgrad_out<KS, TANH>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0]);
+    thin_wgrad_out<KS, TANH>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0], ones_o);
+    if (KS == 16 && !ones_o && lc.g == 0) bsum_o += ubar;          // d loss / d b_o = sum_p ubar_p
     if constexpr (HID13) __syncthreads();    // the lane-major images of the hidden layers overlap other waves' columns
     STAMP(4);
 #pragma unroll
@@ -1111,14 +1145,17 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       else if constexpr (NHACC == 2) {
         if (l - 2 < LY::NST) {               // accumulators of this layer live in the LDS stash between tiles
           f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
-          wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, acc2 STAMP_ARGS);
+          wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, acc2, ones_h[l - 2] STAMP_ARGS);
           stash[(l - 2) * ST_L] = acc2[0];
           stash[(l - 2) * ST_L + 64] = acc2[1];
         } else {
-          wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
+          wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
         }
       }
-      else wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2] STAMP_ARGS);
+      else wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], true STAMP_ARGS);
+      if constexpr (KS == 16) {
+        if (!ones_h[l - 2]) thin_bias<KS>(zb, TA, TB, lc, wave, lane, bsum_h[l - 2]);
+      }
       STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
       f32x4 accv[MT], acct[MT];
@@ -1192,7 +1229,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       STAMP(6);
     }
     if (thin_in) thin_wgrad_in<KS>(xin, gin, zb, zdb, TA, TB, lc, wave, lane, wacc1[0]);
-    else wgrad_layer<KS0, KS, true, TANH>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1 STAMP_ARGS);
+    else wgrad_layer<KS0, KS, true, TANH>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1, true STAMP_ARGS);
     STAMP(7);
   }
 
@@ -1229,7 +1266,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       if (wave == w) {
         if (thin_in) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
         else wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
-        thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
+        thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane, true);
       }
       __syncthreads();
     }
@@ -1251,14 +1288,30 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
           if constexpr (NHACC == 2) {
             if (l - 2 < LY::NST) {
               const f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
-              wgrad_flush<KS, KS, LY::HP>(acc2, Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
+              wgrad_flush<KS, KS, LY::HP>(acc2, Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, ones_h[l - 2]);
               continue;
             }
           }
-          wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave);
+          wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, ones_h[l - 2]);
         }
       }
-      if (wave == r) thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane);
+      if (wave == r) {
+        thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane, ones_o);
+        if constexpr (KS == 16) {
+          // bias gradients that did not ride in a constant-one row (64-wide input side): per-wave partial sums, added
+          // in wave order.  Hidden: lane = position of the output feature; output layer: sum over the wave's 16 points.
+#pragma unroll
+          for (int l = 2; l <= L; ++l)
+            if (!ones_h[l - 2] && vfeat(lane) < LY::HP)
+              Gacc[LY::G1_SZ + (l - 2) * LY::GH_SZ + LY::HP * LY::HP + vfeat(lane)] += bsum_h[l - 2];
+          if (!ones_o) {
+            float b = bsum_o;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+            if (lane == 0) Gacc[LY::GO_OFF + 4 * KS] += b;
+          }
+        }
+      }
       __syncthreads();
     }
   }
@@ -1324,7 +1377,8 @@ int pick_ks(int hmax) {
   if (hmax <= 20) return 5;
   if (hmax <= 32) return 8;
   if (hmax <= 50) return 13;      // NVE == 2: the edge k-step carries features 48, 49 only
-  if (hmax <= 63) return 16;      // the bias gradient rides in the row of (absent) feature 63
+  if (hmax <= 64) return 16;      // <= 63: the bias gradient rides in the row of (absent) feature 63; a 64-wide layer's
+                                  // successor gets it from thin_bias
   return 0;
 }
 
