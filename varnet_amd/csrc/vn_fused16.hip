@@ -611,16 +611,26 @@ __device__ __forceinline__ void h13_wgrad_layer(const PA<13>& av, const PA<13>& 
   const float* TB = TA + H13::TA_ROWS * H13::RS;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    // (-DVN_ABL_NOPUB / -DVN_ABL_NOBAR / -DVN_ABL_NOCONTRACT: diagnostic ablations, results wrong: what the publish
+    // stores, the two workgroup barriers and the contraction of a round cost; profiles/r2_round_ablation.txt)
+#ifndef VN_ABL_NOPUB
     addtid_base(t_base_bytes);
     H13Pub<13, 0, TANH>::run(half, av, azd, bv, bt);
     addtid_store<13 * H13::RS * 4>((half == 0 && lc.g == 0) ? 1.f : 0.f);      // bias row | zeros
     addtid_drain();
+#endif
     WSTAMP(2);
+#ifndef VN_ABL_NOBAR
     __syncthreads();
+#endif
     WSTAMP(3);
+#ifndef VN_ABL_NOCONTRACT
     h13_contract(TA, TB, lc, wave, lane, acc);
+#endif
     WSTAMP(4);
+#ifndef VN_ABL_NOBAR
     __syncthreads();
+#endif
     WSTAMP(5);
   }
 }
@@ -881,9 +891,15 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
       for (int s = 0; s < KS0; ++s) {
         const int f = 4 * s + lc.g;
+#ifdef VN_ABL_NOINPUT   // diagnostic: no global input loads (results wrong) -> upper bound of what hiding their latency can buy
+        xin[s] = (valid && f < net.d_in) ? 0.001f * (float)(row & 1023) : 0.f;
+        gin[s] = (valid && interior && f < net.dim) ? 0.01f * (float)(f + 1) : 0.f;
+        (void)Xp;
+#else
         xin[s] = (valid && f < net.d_in) ? Xp[row * net.d_in + f] : 0.f;
         if (A.dir >= 0) gin[s] = (valid && interior && f == A.dir) ? 1.f : 0.f;
         else gin[s] = (valid && interior && f < net.dim) ? A.G[row * net.dim + f] : 0.f;
+#endif
       }
     }
 
