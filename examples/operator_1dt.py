@@ -3,7 +3,7 @@ The reference's 1D+t demo (/root/reference/Operator_1Dt.py:69-186) on the MI355X
 ([20]), same discretisation (discNum=20, tDiscNum=300 -> 96 000 training points), same call sequence -- the only
 edit a user of the reference makes is the import line (varnet_amd instead of the flat VarNet modules).
 
-    python examples/operator_1dt.py [out_folder] [epochs] [smpScheme]
+    python examples/operator_1dt.py [out_folder] [epochs] [smpScheme] [lossLag]
 
 The reference runs `train(..., smpScheme='optimal', adjustWeight=True)` until `loss < tol` or 500 000 epochs; pass an
 epoch count to bound the run.  Prints the script's own acceptance metric, "Normalized approximation error".
@@ -49,13 +49,14 @@ def main():
     folder = sys.argv[1] if len(sys.argv) > 1 else 'out_operator_1dt'
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
     scheme = sys.argv[3] if len(sys.argv) > 3 else 'optimal'
+    lag = int(sys.argv[4]) if len(sys.argv) > 4 else 0                 # lossLag extension (uniform sampling only)
     domain = Domain1D()
     pde = ADPDE(domain, diff=D, vel=u, timeDependent=True, tInterval=[0, T], IC=IC, cEx=cExact)
     vn = VarNet(pde, layerWidth=[20], discNum=20, bDiscNum=None, tDiscNum=300, processors='GPU:0')
     os.makedirs(folder, exist_ok=True)
     t0 = time.perf_counter()
     vn.train(folder, weight=[1.e1, 1.e1, 1.], smpScheme=scheme, adjustWeight=True, epochNum=epochs, saveFreq=1000,
-             verbose=False)
+             verbose=False, lossLag=lag)
     dt = time.perf_counter() - t0
     vn.loadModel()
     sim = vn.simRes()

@@ -398,3 +398,24 @@ def test_checkpoint_uses_tf_variable_names_and_round_trips(tmp_path):
         d3 = tmp_path / 'empty'
         d3.mkdir()
         vn.loadModel(folderpath=str(d3))
+
+
+def test_loss_lag_is_only_a_readback_schedule(tmp_path):
+    """train(..., lossLag=k): k epochs per host read-back.  Same steps, same losses, same checkpoints and monitor epochs
+    as lossLag=0; only the stopping test sees its losses up to k-1 steps late."""
+    runs = []
+    for lag in (0, 7):
+        vn = op1dt(layerWidth=[6, 5], discNum=5, tDiscNum=6, cEx=cExact)
+        res = vn.train(str(tmp_path / ('lag%d' % lag)), weight=[10., 10., 1.], epochNum=23, saveFreq=5, verbose=False,
+                       batchNum=2, shuffleData=True, shuffleFreq=4, lossLag=lag)
+        runs.append((np.array(res.lossAll), list(res.iterSmp), vn.engine.get_params().copy(), vn.engine.step,
+                     sorted(f for f in os.listdir(str(tmp_path / ('lag%d' % lag))) if f.startswith('best_model'))))
+    (l0, s0, p0, n0, f0), (l1, s1, p1, n1, f1) = runs
+    assert n0 == n1 == 23 * 2 and s0 == s1 == [5, 10, 15, 20] and f0 == f1
+    np.testing.assert_array_equal(l1, l0)
+    np.testing.assert_array_equal(p1, p0)
+    # the stopping test fires on the delayed value: at most lag-1 extra epochs
+    vn = op1dt(layerWidth=[6, 5], discNum=5, tDiscNum=6)
+    res = vn.train(str(tmp_path / 'stop'), weight=[10., 10., 1.], epochNum=60, tol=0.95e6, saveFreq=100, verbose=False, lossLag=6)
+    assert res.lossAll[-1] < 0.95e6 and all(v >= 0.95e6 for v in res.lossAll[:-1])
+    assert len(res.lossAll) <= vn.engine.step <= len(res.lossAll) + 5

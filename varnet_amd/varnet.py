@@ -1038,7 +1038,7 @@ class VarNet:
               addTrainPts=True, suppFactor=1.0, multiTrainUpd=False, trainUpdelay=2e4, tolUpd=0.01,
               reinitrain=True, updateWeights=False, normalizeW=False, adjustWeight=False,
               useOriginalW=False, batchNum=None, batchLen=None, shuffleData=False, shuffleFreq=1,
-              dedup=False):
+              dedup=False, lossLag=0):
         """Training loop of /root/reference/VarNet.py:1197-1421 (uniform, random and residual-driven
         "optimal" sampling with re-initialisation and re-weighting)."""
         if self._towers is not None:                  # controller of forked towers: every tower runs the loop
@@ -1097,61 +1097,82 @@ class VarNet:
         epoch_time = 0.0
         tp_epoch, tp_updates = 1, 0
         resVal = err = lossComp = lossVec = None
-        loss_acc = torch.zeros((), dtype=torch.float32, device=eng.device)
-        for epoch in range(1, epochNum + 1):
+        # `lossLag` (extension, default 0 = the reference's behaviour: the loss is read back after every epoch,
+        # VarNetUtility.py:1044): with lossLag = k > 0 up to k epochs are enqueued before ONE read-back of their k losses,
+        # so small problems (an epoch of 30 us of GPU work behind a 20 us host round trip) keep the GPU busy.  Blocks end
+        # at every epoch that acts on the state (saveFreq monitors / checkpoints, shuffles), so those see exactly the
+        # state the reference would; the stopping test `loss < tol` is evaluated on the delayed values, i.e. up to k-1
+        # further steps may already have been taken when it fires.  Non-uniform sampling keeps k = 0.
+        lag = 0 if smpScheme != 'uniform' else max(0, int(lossLag))
+        loss_buf = torch.zeros(max(lag, 1), dtype=torch.float32, device=eng.device)
+        epoch = 1
+        done = False
+        while epoch <= epochNum and not done:
+            nblk = 1
+            if lag > 1:
+                nblk = min(lag, epochNum - epoch + 1, saveFreq - (epoch - 1) % saveFreq)
+                if shuffleData:
+                    nblk = min(nblk, shuffleFreq - (epoch - 1) % shuffleFreq)
             t0 = time.perf_counter()
-            loss_acc.zero_()
-            for mb in range(fd.MORbatchNum):
-                tData.select_mor(mb)
-                self.optimIter(tData, mb, loss_acc)
-            current_loss = float(loss_acc.item())                   # one host sync per epoch
-            epoch_time += time.perf_counter() - t0
+            loss_buf.zero_()
+            for i in range(nblk):
+                for mb in range(fd.MORbatchNum):
+                    tData.select_mor(mb)
+                    self.optimIter(tData, mb, loss_buf[i])
+            losses = loss_buf[:nblk].tolist()                        # one host sync per block (per epoch when lossLag = 0)
+            blk_time = time.perf_counter() - t0
+            first = epoch
+            for i in range(nblk):
+                epoch = first + i
+                current_loss = float(losses[i])
+                epoch_time += blk_time / nblk
+                if shuffleData and epoch % shuffleFreq == 0:
+                    tData.shuffleTrainData()
 
-            if shuffleData and epoch % shuffleFreq == 0:
-                tData.shuffleTrainData()
+                if epoch % saveFreq == 0:
+                    if min_loss > current_loss:
+                        min_loss = current_loss
+                        self.saveModel(epoch)
+                    resVal, _, err, _ = self.residual()
+                    eng.set_weights([1.0, 1.0, 1.0])
+                    if tData0 is not tData:
+                        tData0.activate()
+                    lossComp, _, lossVec = self.splitLoss(tData0)       # VarNet.py:1365
+                    if tData0 is not tData:
+                        tData.activate()
+                    eng.set_weights(w_eff)
+                trainRes.iterOutput(epoch, current_loss, min_loss, epoch_time, resVal, err, lossComp, lossVec)
 
-            if epoch % saveFreq == 0:
-                if min_loss > current_loss:
-                    min_loss = current_loss
-                    self.saveModel(epoch)
-                resVal, _, err, _ = self.residual()
-                eng.set_weights([1.0, 1.0, 1.0])
-                if tData0 is not tData:
-                    tData0.activate()
-                lossComp, _, lossVec = self.splitLoss(tData0)       # VarNet.py:1365
-                if tData0 is not tData:
-                    tData.activate()
-                eng.set_weights(w_eff)
-            trainRes.iterOutput(epoch, current_loss, min_loss, epoch_time, resVal, err, lossComp, lossVec)
-
-            if current_loss < tol:
-                trainRes.writeCase('Training completed!')
-                if verbose and self.rank == 0:
-                    print('Training completed!')
-                break
-
-            # regenerate the training set (VarNet.py:1385-1421)
-            if smpScheme != 'uniform' and (multiTrainUpd or tp_updates == 0) and (epoch - tp_epoch) >= (trainUpdelay - 1):
-                t_loss = np.array(trainRes.loss[-5:])                # sampled every saveFreq epochs, as the reference
-                tp_conv = t_loss[:-1] - t_loss[1:]
-                tp_conv = np.sum(tp_conv[tp_conv > 0])
-                if len(t_loss) > 0 and tp_conv / t_loss[-1] < tolUpd:
-                    min_loss = float('inf')
-                    tp_epoch = epoch
-                    tp_updates += 1
-                    trainRes.inpIter.append(epoch)
-                    tData = self._build_tdata(batchNum, batchLen, smpScheme, frac, addTrainPts, suppFactor)
-                    self.tData = tData
-                    msg = '\n\n==========================================================\nTraining points updated.\n\n'
-                    if reinitrain:
-                        eng.init_params(seed=tp_updates)            # global_variables_initializer, VarNet.py:1412
-                        msg += 'trainable variables reinitialized.\n\n'
+                if current_loss < tol:
+                    trainRes.writeCase('Training completed!')
                     if verbose and self.rank == 0:
-                        print(msg)
-                    trainRes.writeCase(msg)
-                    if adjustWeight:
-                        weight = [5 * wv for wv in weight[:-1]] + [weight[-1]]
-                    trainW, w_eff, _ = set_train_weights(tData, weight)
+                        print('Training completed!')
+                    done = True
+                    break
+
+                # regenerate the training set (VarNet.py:1385-1421)
+                if smpScheme != 'uniform' and (multiTrainUpd or tp_updates == 0) and (epoch - tp_epoch) >= (trainUpdelay - 1):
+                    t_loss = np.array(trainRes.loss[-5:])                # sampled every saveFreq epochs, as the reference
+                    tp_conv = t_loss[:-1] - t_loss[1:]
+                    tp_conv = np.sum(tp_conv[tp_conv > 0])
+                    if len(t_loss) > 0 and tp_conv / t_loss[-1] < tolUpd:
+                        min_loss = float('inf')
+                        tp_epoch = epoch
+                        tp_updates += 1
+                        trainRes.inpIter.append(epoch)
+                        tData = self._build_tdata(batchNum, batchLen, smpScheme, frac, addTrainPts, suppFactor)
+                        self.tData = tData
+                        msg = '\n\n==========================================================\nTraining points updated.\n\n'
+                        if reinitrain:
+                            eng.init_params(seed=tp_updates)            # global_variables_initializer, VarNet.py:1412
+                            msg += 'trainable variables reinitialized.\n\n'
+                        if verbose and self.rank == 0:
+                            print(msg)
+                        trainRes.writeCase(msg)
+                        if adjustWeight:
+                            weight = [5 * wv for wv in weight[:-1]] + [weight[-1]]
+                        trainW, w_eff, _ = set_train_weights(tData, weight)
+            epoch = first + nblk
         return trainRes
 
     # -- checkpoints ----------------------------------------------------------------------------------
