@@ -72,7 +72,7 @@ typedef struct vn_config {
 } vn_config;
 
 const char* vn_last_error(void);
-int  vn_abi_version(void);
+int  vn_abi_version(void);   /* 2 since round 2: towers (vn_comm_*), tanh, empty feeds, vn_kernel_path, vn_profile_comm */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
 int vn_create(const vn_config* cfg, vn_engine** out);

@@ -29,7 +29,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), 'missing export ' + n
     assert set(names) == set(engine.ABI_SYMBOLS), set(names) ^ set(engine.ABI_SYMBOLS)
-    assert lib.vn_abi_version() == 1
+    assert lib.vn_abi_version() == 2
 
 
 def test_no_silent_cpu_fallback():

@@ -397,7 +397,7 @@ int load_rccl() {
 extern "C" {
 
 const char* vn_last_error(void) { return g_err.c_str(); }
-int vn_abi_version(void) { return 1; }
+int vn_abi_version(void) { return 2; }   // 2: vn_comm_*, vn_profile_comm, vn_kernel_path, VN_ACT_TANH, VN_ECOMM, n_k == 0 feeds
 
 int vn_create(const vn_config* cfg, vn_engine** out) {
   if (!cfg || !out) return fail(VN_EINVAL, "null argument");
