@@ -619,8 +619,27 @@ class VarNet:
             mode = os.environ.get('VN_COMM', 'auto')      # auto: in-engine RCCL whenever the ranks own distinct GPUs
             if hasattr(self.engine, 'comm_init_from_torch') and \
                     (mode == 'rccl' or (mode == 'auto' and self.dist.get_backend() == 'nccl')):
-                self.engine.comm_init_from_torch(self.dist)
-                self.comm = 'rccl'
+                # every rank must end up on the SAME route: try the in-engine communicator, then agree (MIN over ranks)
+                # whether it came up everywhere; if not, all ranks drop it and keep the collective in torch.distributed
+                ok, why = 1, ''
+                try:
+                    self.engine.comm_init_from_torch(self.dist)
+                except Exception as e:                      # RCCL missing / refused on this rank
+                    ok, why = 0, str(e)
+                t = self.engine.torch
+                flag = t.tensor([ok], dtype=t.int32,
+                                device=self.engine.device if self.dist.get_backend() == 'nccl' else 'cpu')
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    self.comm = 'rccl'
+                else:
+                    if ok:
+                        self.engine.comm_destroy()
+                    if mode == 'rccl':
+                        raise RuntimeError('VN_COMM=rccl but the in-engine RCCL communicator did not come up on every rank'
+                                           + (': ' + why if why else ''))
+                    warnings.warn('in-engine RCCL communicator unavailable (%s): gradient SUM stays in torch.distributed'
+                                  % (why or 'another rank failed'))
         fd = self.fixData
         self.engine.set_fe_table(fd.N, fd.dNt, None if fd.integW is None else fd.integW)
         self.tfData = self.engine       # name kept for scripts that poke at `VarNet.tfData`
