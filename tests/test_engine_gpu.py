@@ -598,3 +598,27 @@ def test_empty_tower_feed(kernel):
     torch.cuda.synchronize()
     assert out == [0.0, 0.0, 0.0, 0.0] and not gb.cpu().numpy().any()
     eng.close()
+
+
+def test_six_wide_layers_run_on_the_generic_kernels():
+    """6 layers wider than 50 have no fused instantiation (LDS); at widths > 61 the generic backward kernel switches to the
+    65-float row stride to fit 160 KiB.  Checked against the fp64 oracle."""
+    from varnet_amd.engine import VNEngine
+    for widths in ([64] * 6, [55, 60, 52, 64, 51, 58]):
+        d = synth(9, 3, 2, widths, 16, 30, 40, 15)
+        eng = VNEngine(2, 3, widths, True, 16)
+        assert eng.kernel_path()[0] == 1
+        eng.init_params(seed=2)
+        flat = eng.get_params()
+        eng.set_fe_table(d['N1'], d['dNt1'], None)
+        eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=30, detJ=d['detJ'])
+        eng.set_bic(d['biInput'], d['biLabel'], 15, 2.0)
+        eng.set_weights(d['w'])
+        ref, gref = oracle_eval(flat, d, 3, 2, widths, 16, 30, 15, False, False, False)
+        gb = eng.bind_grad_buffer()
+        eng.grad(0)
+        torch.cuda.synchronize()
+        g = gb.cpu().numpy()
+        assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
+        assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
+        eng.close()

@@ -14,7 +14,7 @@ namespace {
 
 constexpr int TP = 32;        // points per tile
 constexpr int NC = 64;        // columns per tile: value | tangent
-constexpr int LDW = 81;       // LDS row stride (floats): 81 = 17 mod 32 keeps both the row-wise
+constexpr int LDW = 81;       // default LDS row stride (floats): 81 = 17 mod 32 keeps both the row-wise
                               // and the transposed (weight-gradient) accesses conflict-free
 constexpr int NTHREADS = 256;
 
@@ -65,6 +65,7 @@ __device__ __forceinline__ void gemm_cols64(int M, int K, int wave, int lane, AF
   }
 }
 
+template <int LDS_STRIDE = LDW>
 __device__ __forceinline__ void load_tile_inputs(const VnNet& net, const VnRows& sg, long r0,
                                                  float* S0, int tid) {
   const int d_in = net.d_in, dim = net.dim;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void load_tile_inputs(const VnNet& net, const VnRows&
       if (c < TP) v = sg.X[row * d_in + k];
       else if (sg.G != nullptr && k < dim) v = sg.G[row * dim + k];
     }
-    S0[k * LDW + c] = v;
+    S0[k * LDS_STRIDE + c] = v;
   }
 }
 
@@ -138,6 +139,9 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_fwd_kernel(VnNet net, con
 // --------------------------------------------------------------------------------------
 // backward: rows + seeds (ubar, udbar) -> per-workgroup partial parameter gradient
 // --------------------------------------------------------------------------------------
+// LDW: row stride of the LDS matrices.  81 is the bank-friendly default; 65 (the minimum for 64 columns) is used
+// when 81 would not fit 160 KiB (6 layers wider than 61): slower still, but the shape runs.
+template <int LDW>
 __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, const float* __restrict__ theta,
                                                                   VnRows sg0, VnRows sg1, long ntiles0,
                                                                   long ntiles, float* __restrict__ partial) {
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
     const bool first = tile < ntiles0;
     const VnRows& sg = first ? sg0 : sg1;
     const long r0 = (first ? tile : tile - ntiles0) * TP;
-    load_tile_inputs(net, sg, r0, S, tid);
+    load_tile_inputs<LDW>(net, sg, r0, S, tid);
     if (tid < TP) {
       const long row = r0 + tid;
       sub[tid] = (row < sg.n) ? sg.ubar[row] : 0.f;
@@ -489,10 +493,12 @@ size_t vn_generic_fwd_lds_bytes(const VnNet& net) {
   return (size_t)2 * rows * LDW * sizeof(float);
 }
 
-size_t vn_generic_bwd_lds_bytes(const VnNet& net) {
+static size_t bwd_lds_bytes(const VnNet& net, int ldw) {
   const int rows = net.hmax > net.d_in ? net.hmax : net.d_in;
-  return ((size_t)(net.L + 2) * rows * LDW + 2 * TP) * sizeof(float);
+  return ((size_t)(net.L + 2) * rows * ldw + 2 * TP) * sizeof(float);
 }
+static int bwd_ldw(const VnNet& net) { return bwd_lds_bytes(net, LDW) <= 160 * 1024 ? LDW : 65; }
+size_t vn_generic_bwd_lds_bytes(const VnNet& net) { return bwd_lds_bytes(net, bwd_ldw(net)); }
 
 static inline long tiles_of(long n) { return (n + TP - 1) / TP; }
 
@@ -513,12 +519,15 @@ hipError_t vn_generic_backward(const VnNet& net, const float* theta, VnRows seg0
                                int grid, hipStream_t s) {
   const long nt0 = tiles_of(seg0.n), nt = nt0 + tiles_of(seg1.n);
   const size_t lds = vn_generic_bwd_lds_bytes(net);
-  hipError_t e = hipFuncSetAttribute((const void*)vn_generic_bwd_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool narrow = bwd_ldw(net) != LDW;
+  const void* fn = narrow ? (const void*)vn_generic_bwd_kernel<65> : (const void*)vn_generic_bwd_kernel<LDW>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   // every workgroup of the grid writes its partial (zeros if it owns no tile)
-  hipLaunchKernelGGL(vn_generic_bwd_kernel, dim3(grid), dim3(NTHREADS), lds, s, net, theta, seg0, seg1, nt0, nt,
-                     partial);
+  if (narrow)
+    hipLaunchKernelGGL(vn_generic_bwd_kernel<65>, dim3(grid), dim3(NTHREADS), lds, s, net, theta, seg0, seg1, nt0, nt, partial);
+  else
+    hipLaunchKernelGGL(vn_generic_bwd_kernel<LDW>, dim3(grid), dim3(NTHREADS), lds, s, net, theta, seg0, seg1, nt0, nt, partial);
   return hipGetLastError();
 }
 
