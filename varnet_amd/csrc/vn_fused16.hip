@@ -694,6 +694,33 @@ __device__ __forceinline__ void wgrad_flush(const f32x4 (&acc)[NACC], float* Gl,
 }
 
 
+
+// Edge rows: every lane group holds a partial sum (its share of the k index) of each of the NV edge features; group g
+// must end up with the TOTAL of feature g.  A reduce-scatter instead of NV all-reduces: at each of the two exchange
+// steps a lane sends only the partials its partner keeps, so NV = 2 takes 2 cross-lane moves instead of 4, NV = 4 takes
+// 3 instead of 8 (ds_bpermute costs ~14 issue cycles on the shared vector path).  Groups >= NV get 0.
+template <int NV>
+__device__ __forceinline__ float edge_reduce_scatter(const float (&e)[NV], int g) {
+  if constexpr (NV == 2) {
+    // step 1 (partner g^1): keep feature g&1, hand the other one over
+    const float keep = (g & 1) ? e[1] : e[0], give = (g & 1) ? e[0] : e[1];
+    float t = keep + __shfl_xor(give, 16, 64);
+    t += __shfl_xor(t, 32, 64);                       // step 2 (partner g^2): both hold the same feature
+    return g < 2 ? t : 0.f;
+  } else {
+    static_assert(NV == 4, "edge features: 2 or 4");
+    // step 1 (partner g^1): keep the two features with the parity of g
+    const bool odd = (g & 1) != 0;
+    const float k0 = odd ? e[1] : e[0], k1 = odd ? e[3] : e[2];
+    const float g0 = odd ? e[0] : e[1], g1 = odd ? e[2] : e[3];
+    const float a = k0 + __shfl_xor(g0, 16, 64);      // feature (g&1)
+    const float b = k1 + __shfl_xor(g1, 16, 64);      // feature (g&1) + 2
+    // step 2 (partner g^2): keep feature g
+    const bool hi = (g & 2) != 0;
+    return (hi ? b : a) + __shfl_xor(hi ? a : b, 32, 64);
+  }
+}
+
 struct VnFusedArgsD {
   VnNet net;
   const float* theta;
@@ -1005,16 +1032,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       }
       if (EDGE) {
         // sum the four lane groups' shares; group g keeps edge feature g
-        float zsel = 0.f, tsel = 0.f;
-#pragma unroll
-        for (int v = 0; v < NVE; ++v) {
-          float x = ev[v], y = et[v];
-          x += __shfl_xor(x, 16, 64);  y += __shfl_xor(y, 16, 64);
-          x += __shfl_xor(x, 32, 64);  y += __shfl_xor(y, 32, 64);
-          if (lc.g == v) { zsel = x; tsel = y; }
-        }
-        nv[MT - 1][0] += zsel;                       // bias was loaded above
-        nt[MT - 1][0] = tsel;
+        nv[MT - 1][0] += edge_reduce_scatter<NVE>(ev, lc.g);         // bias was loaded above
+        nt[MT - 1][0] = edge_reduce_scatter<NVE>(et, lc.g);
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) { pv[m] = nv[m]; ptn[m] = nt[m]; }
@@ -1211,16 +1230,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         for (int v = 0; v < NVE; ++v) we[v] = wen[v];
       }
       if (EDGE) {
-        float vsel = 0.f, tsel = 0.f;
-#pragma unroll
-        for (int v = 0; v < NVE; ++v) {
-          float x = ev[v], y = et[v];
-          x += __shfl_xor(x, 16, 64);  y += __shfl_xor(y, 16, 64);
-          x += __shfl_xor(x, 32, 64);  y += __shfl_xor(y, 32, 64);
-          if (lc.g == v) { vsel = x; tsel = y; }
-        }
-        accv[MT - 1][0] = vsel;
-        acct[MT - 1][0] = tsel;
+        accv[MT - 1][0] = edge_reduce_scatter<NVE>(ev, lc.g);
+        acct[MT - 1][0] = edge_reduce_scatter<NVE>(et, lc.g);
       }
       // zbar of layer l-1, two k-steps per packed instruction (accumulator rows ks, ks+1 are a register pair)
 #pragma unroll
