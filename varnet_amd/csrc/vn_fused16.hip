@@ -1096,7 +1096,9 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         sInt[pt] = t;                                                 // q does not divide the tile: serial sum
       }
       ESTAMP(1);
+#ifndef VN_ABL_NOEPIBAR
       __syncthreads();
+#endif
       ESTAMP(2);
       // every lane sums the partials of its own test function (same order in all lanes, so all
       // agree bit for bit): no second barrier and no serial section
@@ -1149,7 +1151,9 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       zb.p[j] = ab * sp + zq * act_d2r_2<TANH>(av) * zd[L - 1].p[j];
     }
     STAMP(3);
+#ifndef VN_ABL_NOTHIN
     thin_wgrad_out<KS, TANH>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0], ones_o);
+#endif
     if (KS == 16 && !ones_o && lc.g == 0) bsum_o += ubar;          // d loss / d b_o = sum_p ubar_p
     if constexpr (HID13) __syncthreads();    // the lane-major images of the hidden layers overlap other waves' columns
     STAMP(4);
@@ -1255,7 +1259,11 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       }
       STAMP(6);
     }
+#ifndef VN_ABL_NOTHIN
     if (thin_in) thin_wgrad_in<KS>(xin, gin, zb, zdb, TA, TB, lc, wave, lane, wacc1[0]);
+#else
+    if (0) {}
+#endif
     else wgrad_layer<KS0, KS, true, TANH>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1, true STAMP_ARGS);
     STAMP(7);
   }
