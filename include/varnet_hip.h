@@ -125,6 +125,10 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu_dev, int64_t U, co
  * biInput [nB, d_in], biLabel [nB]; rows [0,bDof) are boundary, [bDof,nB) initial condition. */
 int vn_set_bic(vn_engine* h, const float* biInput_dev, const float* biLabel_dev, int64_t nB,
                int64_t bDof, double biDimVal);
+/* Optional per-batch copy of the BC/IC rows: the reference's shuffleTrainData feeds every (mini-batch, tower) its own
+ * permutation of biInput / biLabel (VarNetUtility.py:988-996).  Same nB, bDof, biDimVal as vn_set_bic; NULL, NULL (or a
+ * new vn_set_interior for the batch) returns to the shared set. */
+int vn_set_batch_bic(vn_engine* h, int32_t batch, const float* biInput_dev, const float* biLabel_dev);
 /* updateDictFields('trainW') (VarNetUtility.py:921-922); the caller applies the
  * w[0:2] /= batchNum*puNum rule (VarNetUtility.py:900-901). */
 int vn_set_weights(vn_engine* h, const double w[3]);

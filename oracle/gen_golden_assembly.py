@@ -172,6 +172,22 @@ def main():
     vn_s = RV.VarNet(pde1(td=False), layerWidth=[5], discNum=7, bDiscNum=None, tDiscNum=[], integPnum=2)
     record(st, '1d_steady', vn_s, RVU, None, None, 1)
 
+    # shuffleTrainData (VarNetUtility.py:957-1017) from a fixed NumPy seed: the feeds of every (mini-batch, tower) after
+    # one and after two shuffles -- test-function order AND the per-feed permutation of the boundary/initial rows
+    for pu in (1, 2):
+        PU[0] = pu
+        vn_s2 = RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2)
+        tD = record(st, '1dt_shuf_pu%d' % pu, vn_s2, RVU, 3, None, pu)
+        np.random.seed(4711)
+        for rnd in range(2):
+            tD.shuffleTrainData(vn_s2.fixData)
+            st['1dt_shuf_pu%d_r%d_batchInd' % (pu, rnd)] = tD.batchInd.copy()
+            for bi, fdict in enumerate(tD.optimFeedicts):
+                for ti, tw in enumerate(vn_s2.tfData.compTowers):
+                    h = '1dt_shuf_pu%d_r%d_b%d_t%d_' % (pu, rnd, bi, ti)
+                    st[h + 'Input'], st[h + 'gcoef'] = fdict[tw.Input], fdict[tw.gcoef]
+                    st[h + 'biInput'], st[h + 'biLabel'] = fdict[tw.biInput], fdict[tw.biLabel]
+
     # MOR batches (Operator_1DtMOR.py:166-204 in small): kappa as third network input, 3 values; the reference walks
     # the batches through trainData(batch, MORdiscArg, tData) -- first pass computes, with saveMORdata=True the
     # second pass reloads the stored fields (VarNetUtility.py:660-752).  Recorded per batch: what the towers are fed.

@@ -71,9 +71,18 @@ class OracleEngine:
         npy = lambda t: None if t is None else (t.numpy().copy() if isinstance(t, torch.Tensor) else np.array(t, dtype=float))
         dj = npy(detJ) if isinstance(detJ, torch.Tensor) or np.size(detJ) > 1 else float(np.reshape(detJ, -1)[0])
         self.batches[batch] = (npy(Input), npy(gcoef), npy(source), int(n_k), dj, npy(N_rows), npy(dNt_rows))
+        getattr(self, 'bbic', {}).pop(batch, None)
 
     def set_bic(self, biInput, biLabel, bDof, biDimVal):
         self.bic = (biInput.numpy().copy(), biLabel.numpy().copy(), int(bDof), float(biDimVal))
+
+    def set_batch_bic(self, batch, biInput=None, biLabel=None):
+        if not hasattr(self, 'bbic'):
+            self.bbic = {}
+        if biInput is None:
+            self.bbic.pop(batch, None)
+        else:
+            self.bbic[batch] = (biInput.numpy().copy(), biLabel.numpy().copy())
 
     def set_weights(self, w):
         self.w = np.array(w, dtype=float)
@@ -86,6 +95,8 @@ class OracleEngine:
     def _eval(self, batch):
         Input, gcoef, src, n_k, detJ, Nr, dNtr = self.batches[batch]
         biInput, biLabel, bDof, biDimVal = self.bic
+        if batch in getattr(self, 'bbic', {}):
+            biInput, biLabel = self.bbic[batch]
         N, dNt, W = self.fe
         q = self.integNum
         Nrow = np.tile(N, n_k) if Nr is None else Nr.reshape(-1)

@@ -202,3 +202,39 @@ def test_mor_batches_match_reference():
                 np.testing.assert_allclose(npy(d['gcoef']), G[g + 'gcoef'], **TOL)
                 Inp = vn.engine.batches[td.engine_batch(b, 1)][0]             # second mini-batch of kappa-batch b
                 np.testing.assert_allclose(Inp.reshape(-1, 3), G[g + 'mb1_Input'], **TOL)
+
+
+@pytest.mark.parametrize('pu', [1, 2])
+def test_shuffle_feeds_match_reference(pu):
+    """shuffleTrainData from the same NumPy seed: the reference's permutation of the test functions and its per-feed
+    permutation of the boundary/initial rows (VarNetUtility.py:957-1017) -- every (mini-batch, tower) feed after one and
+    after two shuffles equals the reference's."""
+    vn = build('1dt', 2)
+    tds = []
+    for r in range(pu):
+        vn.world, vn.rank = pu, r
+        td = vn._build_tdata(batchNum=3)
+        tds.append((td, vn.engine))
+        if r + 1 < pu:                                   # a second tower needs its own engine-side registry
+            vn.engine = vn._make_engine(None)
+            vn.engine.set_fe_table(vn.fixData.N, vn.fixData.dNt, None)
+    for rnd in range(2):
+        for r, (td, eng) in enumerate(tds):
+            vn.world, vn.rank, vn.engine = pu, r, eng
+            if rnd == 0 and r == 0:
+                np.random.seed(4711)
+                state0 = np.random.get_state()
+            np.random.set_state(state0 if rnd == 0 else state1)      # every tower sees the stream the reference saw
+            td.shuffleTrainData()
+            after = np.random.get_state()
+            np.testing.assert_array_equal(td.batchInd, G['1dt_shuf_pu%d_r%d_batchInd' % (pu, rnd)])
+            for bi in range(3):
+                h = '1dt_shuf_pu%d_r%d_b%d_t%d_' % (pu, rnd, bi, r)
+                Inp, gco, _, n_k, _, _, _ = eng.batches[td.engine_batch(0, bi)]
+                np.testing.assert_allclose(Inp.reshape(-1, 2), G[h + 'Input'], **TOL)
+                np.testing.assert_allclose(gco.reshape(-1, 1), G[h + 'gcoef'], **TOL)
+                bX, bY = eng.bbic[td.engine_batch(0, bi)]
+                np.testing.assert_allclose(bX, G[h + 'biInput'], **TOL)
+                np.testing.assert_allclose(bY.reshape(-1, 1), G[h + 'biLabel'], **TOL)
+        state1 = after
+    vn.world, vn.rank = 1, 0

@@ -240,3 +240,47 @@ def test_dedup_training_matches_rowwise(tmp_path):
         losses.append(np.array(res.lossAll))
         vn.engine.close()
     assert np.max(np.abs(losses[0] - losses[1]) / losses[0]) < 2e-3
+
+
+def test_shuffled_feeds_on_device(tmp_path):
+    """Non-MOR mini-batches with shuffleData: after a shuffle every mini-batch carries its own permutation of the BC/IC rows
+    (vn_set_batch_bic; the reference's quirk, VarNetUtility.py:988-996).  One shuffled mini-batch's loss / gradient against
+    the oracle fed the same permuted rows, then a short training run."""
+    vn = op1dt([20, 20], 10, 12)
+    fd, eng = vn.fixData, vn.engine
+    td = vn._build_tdata(batchNum=3)
+    td.select_mor(0)
+    np.random.seed(5)
+    td.shuffleTrainData()
+    assert set(td.biPerm) == {0, 1, 2}
+    w = np.array([4.0, 3.0, 2.0])
+    eng.set_weights(w)
+    bi = 1
+    gb = eng.bind_grad_buffer()
+    eng.grad(td.engine_batch(0, bi))
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy().astype(np.float64)
+    q, d = fd.integNum, td.mor[0]
+    n0, n1 = td.block(bi)
+    tf = td.batchInd[n0:n1]
+    rows = (tf[:, None] * q + np.arange(q)[None, :]).reshape(-1)
+    perm = td.biPerm[bi]
+    f64 = lambda t: t.cpu().numpy().astype(np.float64)
+    n = rows.size
+    ref, gref = og.loss_and_grad(
+        eng.get_params().astype(np.float64), 2, [20, 20], torch.float64, Input=f64(d['Input'])[rows], gcoef=f64(d['gcoef'])[rows],
+        source=None, N=np.tile(fd.N, n1 - n0).reshape(n, 1).astype(np.float32).astype(np.float64),
+        dNt=np.tile(fd.dNt, n1 - n0).reshape(n, 1).astype(np.float32).astype(np.float64), integW=None, intShape=[n1 - n0, q],
+        detJ=float(np.float32(fd.detJ)), detJvec=False, biInput=f64(d['biInput'])[perm], biLabel=f64(d['biLabel'])[perm].reshape(-1, 1),
+        bDof=fd.bDofsum, biDimVal=float(fd.biDimVal), w=w, dim=1, time_dependent=True, is_source=False, integWflag=False)
+    P = eng.P
+    assert abs(g[P] - ref['loss']) <= 1e-5 * abs(ref['loss'])
+    assert np.max(np.abs(g[:P] - gref)) <= 1e-4 * np.max(np.abs(gref))
+    # the permutation crosses the BC/IC split: the BC mean really differs from the unshuffled one
+    eng.set_batch_bic(td.engine_batch(0, bi))
+    eng.grad(td.engine_batch(0, bi))
+    torch.cuda.synchronize()
+    assert abs(gb.cpu().numpy()[P + 1] - g[P + 1]) > 1e-6 * abs(g[P + 1])
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=12, saveFreq=100, verbose=False, batchNum=3, shuffleData=True)
+    assert np.isfinite(res.lossAll).all() and vn.engine.step == 36
+    vn.engine.close()

@@ -405,6 +405,7 @@ def test_loss_lag_is_only_a_readback_schedule(tmp_path):
     as lossLag=0; only the stopping test sees its losses up to k-1 steps late."""
     runs = []
     for lag in (0, 7):
+        np.random.seed(31)                           # shuffles draw from the global NumPy stream, as in the reference
         vn = op1dt(layerWidth=[6, 5], discNum=5, tDiscNum=6, cEx=cExact)
         res = vn.train(str(tmp_path / ('lag%d' % lag)), weight=[10., 10., 1.], epochNum=23, saveFreq=5, verbose=False,
                        batchNum=2, shuffleData=True, shuffleFreq=4, lossLag=lag)

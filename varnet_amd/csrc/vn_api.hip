@@ -43,6 +43,9 @@ struct Batch {
   long n_k = 0;
   double detJ = 0.0;
   bool set = false;
+  // optional per-batch copy of the BC/IC rows (the reference's shuffle permutes them per feed: vn_set_batch_bic)
+  const float* biInput = nullptr;
+  const float* biLabel = nullptr;
   // de-duplicated formulation (vn_set_dedup)
   const float* Xu = nullptr;
   const int* uid = nullptr;
@@ -182,6 +185,9 @@ int check_batch(vn_engine* h, int32_t batch) {
   return VN_OK;
 }
 
+inline const float* bi_x(const vn_engine* h, const Batch& b) { return b.biInput ? b.biInput : h->biInput; }
+inline const float* bi_y(const vn_engine* h, const Batch& b) { return b.biLabel ? b.biLabel : h->biLabel; }
+
 // Model value (and directional derivative along G, if given) at n rows with the 8-wave fused kernel in its
 // forward-only mode: 2 F_pt per row at the fused kernel's efficiency instead of the generic forward kernel.
 int fused_forward(vn_engine* h, const float* X, const float* G, long n, float* out_u, float* out_ud) {
@@ -207,11 +213,11 @@ int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* l
   if (h->use_fused16 && h->has_fe && !with_seeds) {
     // splitLoss / trainWeight / the monitors: the fused kernel's forward-only mode for both row sets
     if (int rc = fused_forward(h, b.Input, b.gcoef, nT, h->u, h->ud)) return rc;
-    if (int rc = fused_forward(h, h->biInput, nullptr, h->nB, h->ub, nullptr)) return rc;
+    if (int rc = fused_forward(h, bi_x(h, b), nullptr, h->nB, h->ub, nullptr)) return rc;
   } else {
     VnRows s0{}, s1{};
     s0.X = b.Input; s0.G = b.gcoef; s0.u = h->u; s0.ud = h->ud; s0.n = nT;
-    s1.X = h->biInput; s1.G = nullptr; s1.u = h->ub; s1.ud = nullptr; s1.n = h->nB;
+    s1.X = bi_x(h, b); s1.G = nullptr; s1.u = h->ub; s1.ud = nullptr; s1.n = h->nB;
     HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));
   }
 
@@ -226,7 +232,7 @@ int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* l
   a.n_k = b.n_k; a.integ_num = h->cfg.integ_num; a.time_dependent = h->cfg.time_dependent;
   a.ubar = with_seeds ? h->ubar : nullptr; a.udbar = with_seeds ? h->udbar : nullptr;
   a.lossVec = lossVec;
-  a.ub = h->ub; a.label = h->biLabel; a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;
+  a.ub = h->ub; a.label = bi_y(h, b); a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;
   a.ubar_b = with_seeds ? h->ubar_b : nullptr;
   a.w0 = (float)h->w[0]; a.w1 = (float)h->w[1]; a.w2 = (float)h->w[2];
   a.part = h->losspart;
@@ -254,7 +260,7 @@ int run_twopass(vn_engine* h, const Batch& b, float* gradbuf) {
   f.nT = nT; f.n_k = 0; f.integ_num = q;
   f.feN = h->feN; f.fedNt = h->fedNt; f.feW = nullptr; f.detJv = nullptr; f.detJ = 0.f;
   f.time_dependent = h->cfg.time_dependent; f.lossVec = nullptr;
-  f.Xb = h->biInput; f.label = h->biLabel; f.nB = 0; f.bDof = h->bDof; f.biDimVal = (float)h->biDimVal;
+  f.Xb = bi_x(h, b); f.label = bi_y(h, b); f.nB = 0; f.bDof = h->bDof; f.biDimVal = (float)h->biDimVal;
   f.w0 = (float)h->w[0]; f.w1 = (float)h->w[1]; f.w2 = (float)h->w[2];
   f.partial = h->partial; f.losspart = lp; f.stamps = nullptr;
   f.dir = -1; f.ostride = 1;
@@ -298,7 +304,7 @@ int run_dedup(vn_engine* h, const Batch& b, bool with_grad, float* lossVec, floa
   f.nT = b.U; f.n_k = 0; f.integ_num = q;
   f.feN = h->feN; f.fedNt = h->fedNt; f.feW = nullptr; f.detJv = nullptr; f.detJ = 0.f;
   f.time_dependent = h->cfg.time_dependent; f.lossVec = nullptr;
-  f.Xb = h->biInput; f.label = h->biLabel; f.nB = 0; f.bDof = h->bDof; f.biDimVal = (float)h->biDimVal;
+  f.Xb = bi_x(h, b); f.label = bi_y(h, b); f.nB = 0; f.bDof = h->bDof; f.biDimVal = (float)h->biDimVal;
   f.w0 = (float)h->w[0]; f.w1 = (float)h->w[1]; f.w2 = (float)h->w[2];
   f.partial = h->dd_partial; f.losspart = lp; f.stamps = nullptr;
   f.ostride = dim;
@@ -626,6 +632,7 @@ int vn_set_interior(vn_engine* h, int32_t batch, const float* Input, const float
   b.Input = Input; b.gcoef = gcoef; b.source = source; b.detJv = detJ_dev; b.detJ = detJ;
   b.Nrow = N_rows; b.dNtrow = dNt_rows; b.n_k = n_k; b.set = true;
   b.Xu = nullptr; b.uid = nullptr; b.rowptr = nullptr; b.rowidx = nullptr; b.U = 0;   // re-register with vn_set_dedup
+  b.biInput = nullptr; b.biLabel = nullptr;                                            // ... and vn_set_batch_bic
   const long nT = n_k * h->cfg.integ_num;
   if (nT > h->work_rows) {
     long c0 = h->work_rows, c1 = h->work_rows, c2 = h->work_rows, c3 = h->work_rows;
@@ -691,6 +698,16 @@ int vn_set_bic(vn_engine* h, const float* biInput, const float* biLabel, int64_t
   return VN_OK;
 }
 
+int vn_set_batch_bic(vn_engine* h, int32_t batch, const float* biInput, const float* biLabel) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  if (batch < 0 || batch >= (int)h->batches.size() || !h->batches[batch].set)
+    return fail(VN_ESTATE, "batch %d has no interior data (call vn_set_interior first)", batch);
+  if ((biInput == nullptr) != (biLabel == nullptr)) return fail(VN_EINVAL, "biInput and biLabel must be given together");
+  h->batches[batch].biInput = biInput;
+  h->batches[batch].biLabel = biLabel;
+  return VN_OK;
+}
+
 int vn_set_weights(vn_engine* h, const double w[3]) {
   if (!h || !w) return fail(VN_EINVAL, "null argument");
   h->w[0] = w[0]; h->w[1] = w[1]; h->w[2] = w[2];
@@ -719,7 +736,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
     a.Nrow = b.Nrow; a.dNtrow = b.dNtrow;
     a.detJv = b.detJv; a.detJ = (float)b.detJ; a.time_dependent = h->cfg.time_dependent;
     a.lossVec = nullptr;
-    a.Xb = h->biInput; a.label = h->biLabel; a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;
+    a.Xb = bi_x(h, b); a.label = bi_y(h, b); a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;
     a.w0 = (float)h->w[0]; a.w1 = (float)h->w[1]; a.w2 = (float)h->w[2];
     a.partial = h->partial; a.losspart = h->fused_losspart; a.stamps = h->stamps;
     const int grid = h->ncu;
@@ -739,7 +756,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
   const long nT = b.n_k * h->cfg.integ_num;
   VnRows s0{}, s1{};
   s0.X = b.Input; s0.G = b.gcoef; s0.ubar = h->ubar; s0.udbar = h->udbar; s0.n = nT;
-  s1.X = h->biInput; s1.G = nullptr; s1.ubar = h->ubar_b; s1.udbar = nullptr; s1.n = h->nB;
+  s1.X = bi_x(h, b); s1.G = nullptr; s1.ubar = h->ubar_b; s1.udbar = nullptr; s1.n = h->nB;
   const bool rec = h->prof_on && h->prof_n < PROF_CAP;
   if (rec) {
     if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }

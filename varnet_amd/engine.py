@@ -52,6 +52,7 @@ _SIGS = {
                                   C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     'vn_set_dedup': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'vn_set_bic': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_double]),
+    'vn_set_batch_bic': (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'vn_set_weights': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     'vn_bind_grad_buffer': (C.c_int, [C.c_void_p, C.c_void_p]),
     'vn_grad': (C.c_int, [C.c_void_p, C.c_int32]),
@@ -286,6 +287,17 @@ class VNEngine:
         self._keep['bic'] = (biInput, biLabel)
         self._ck(self.lib.vn_set_bic(self.h, _ptr(biInput), _ptr(biLabel), biInput.shape[0], int(bDof),
                                      float(biDimVal)))
+
+    def set_batch_bic(self, batch, biInput=None, biLabel=None):
+        """Per-batch copy of the BC/IC rows (the reference's shuffle permutes them per feed); None returns to the shared set."""
+        if biInput is None:
+            self._keep.pop(('bbic', batch), None)
+            self._ck(self.lib.vn_set_batch_bic(self.h, batch, None, None))
+            return
+        biInput = self.dev(biInput)
+        biLabel = self.dev(np.reshape(biLabel, -1) if isinstance(biLabel, np.ndarray) else biLabel.reshape(-1))
+        self._keep[('bbic', batch)] = (biInput, biLabel)
+        self._ck(self.lib.vn_set_batch_bic(self.h, batch, _ptr(biInput), _ptr(biLabel)))
 
     def set_weights(self, w):
         arr = (C.c_double * 3)(*[float(x) for x in w])

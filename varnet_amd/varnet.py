@@ -483,11 +483,34 @@ class ManageTrainData:
                 eng.set_interior(self.engine_batch(mb, bi), pick(d['Input']), pick(d['gcoef']), pick(d['source']),
                                  n_k=n1 - n0, detJ=self.detJ if detJ is None else detJ,
                                  N_rows=pick(d.get('N_rows')), dNt_rows=pick(d.get('dNt_rows')))
+                perm = getattr(self, 'biPerm', {}).get(bi)
+                if perm is not None and hasattr(eng, 'set_batch_bic'):
+                    ix = torch.as_tensor(perm, device=eng.device, dtype=torch.long)
+                    eng.set_batch_bic(self.engine_batch(mb, bi), d['biInput'].index_select(0, ix),
+                                      d['biLabel'].index_select(0, ix))
 
     def shuffleTrainData(self):
-        """Permute the test-function order (VarNetUtility.py:957-1017); every rank draws the
-        same permutation (seeded generator shared at construction)."""
-        self.vn._rng.shuffle(self.batchInd)
+        """
+        Reshuffle the mini-batches exactly like the reference (VarNetUtility.py:957-1017), drawing from the global NumPy
+        stream in its call order, so that the same `np.random.seed` gives the same feeds: one permutation of the
+        test-function order, then -- per (mini-batch, tower), cumulatively -- a permutation of ALL boundary/initial rows
+        that the feed uses in place of the ordered set.  (That second permutation crosses the BC/IC split, so the rows
+        that enter the BC mean and the IC mean change; with MOR it is overwritten by the next `trainData` call of every
+        batch, VarNetUtility.py:921-926, and therefore has no effect there -- both reproduced.)  With towers, rank 0's
+        seed is broadcast first so that every rank draws the same permutations.
+        """
+        self.vn._sync_sampling()
+        np.random.shuffle(self.batchInd)
+        nB = int(self.mor[0]['biInput'].shape[0])
+        biInd = np.arange(nB)
+        self.biPerm = {}
+        for bi in range(self.batchNum):
+            for tower in range(self.puNum):
+                np.random.shuffle(biInd)
+                if tower == self.vn.rank:
+                    self.biPerm[bi] = biInd.copy()
+        if self.vn.PDE.MORvar is not None:
+            self.biPerm = {}                        # reset by updateDictFields before the batch is used
         self.shuffled = True
         self._register()
 
