@@ -188,6 +188,22 @@ def main():
                     st[h + 'Input'], st[h + 'gcoef'] = fdict[tw.Input], fdict[tw.gcoef]
                     st[h + 'biInput'], st[h + 'biLabel'] = fdict[tw.biInput], fdict[tw.biLabel]
 
+    # smpScheme='random' (VarNet.py:519-566: timeDisc / getMesh with rfrac, global NumPy stream) from a fixed seed
+    for key, mk in (('1dt', lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2)),
+                    ('2dt', lambda: RV.VarNet(pde2(), layerWidth=[5], discNum=[4, 3], bDiscNum=3, tDiscNum=4, integPnum=2))):
+        PU[0] = 1
+        vr = mk()
+        vr.fixData.setFEdata()
+        np.random.seed(99)
+        try:
+            Input, _, biInput, biDof = vr.trainingPoints('random', frac=0.5)
+        except ValueError as e:
+            # Domain1D.getMesh(rfrac > 0) hstacks a 1-D with a 2-D array (Domain.py:678): the reference's own 1-D random
+            # branch raises; recorded as absent
+            assert key == '1dt' and 'same number of dimensions' in str(e), e
+            continue
+        st['rand_%s_Input' % key], st['rand_%s_biInput' % key], st['rand_%s_biDof' % key] = Input, biInput, np.array(biDof)
+
     # MOR batches (Operator_1DtMOR.py:166-204 in small): kappa as third network input, 3 values; the reference walks
     # the batches through trainData(batch, MORdiscArg, tData) -- first pass computes, with saveMORdata=True the
     # second pass reloads the stored fields (VarNetUtility.py:660-752).  Recorded per batch: what the towers are fed.

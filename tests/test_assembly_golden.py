@@ -238,3 +238,17 @@ def test_shuffle_feeds_match_reference(pu):
                 np.testing.assert_allclose(bY.reshape(-1, 1), G[h + 'biLabel'], **TOL)
         state1 = after
     vn.world, vn.rank = 1, 0
+
+
+def test_random_sampling_matches_reference():
+    """smpScheme='random' consumes the global NumPy stream in the reference's order (VarNet.py:519-566, Domain.getMesh
+    with rfrac): same seed, same training points.  (2D+t only: the reference's own 1-D random branch raises,
+    Domain.py:678 hstacks a 1-D with a 2-D array.)"""
+    kind = '2dt'
+    assert 'rand_1dt_Input' not in G.files
+    vn = build(kind, 2)
+    np.random.seed(99)
+    Input, _, biInput, biDof = vn.trainingPoints('random', frac=0.5)
+    np.testing.assert_allclose(Input, G['rand_%s_Input' % kind], **TOL)
+    np.testing.assert_allclose(biInput, G['rand_%s_biInput' % kind], **TOL)
+    assert [int(b) for b in biDof] == [int(b) for b in G['rand_%s_biDof' % kind]]
