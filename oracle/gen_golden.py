@@ -131,6 +131,22 @@ def main():
     mo['m2_names1'] = np.array(mor2.ArgNames[1])
     np.savez_compressed(os.path.join(OUT, 'mor.npz'), **mo)
 
+    # (8b) rejection sampling (UtilityFunc.py:342-404) from a fixed NumPy seed: one segment, and two segments with dofT
+    rs = {}
+
+    def dens(x=None):
+        if x is None:
+            x = grid
+        return np.exp(-8.0 * (x[:, 0:1] - 0.3) ** 2) + 0.05
+
+    grid = np.linspace(-1, 1, 41).reshape(-1, 1)
+    np.random.seed(2024)
+    rs['one'] = uf.rejectionSampling(dens, lambda: np.random.uniform(-1, 1, [50, 1]), 37)
+    grid = np.vstack([np.linspace(-1, 1, 30).reshape(-1, 1), np.linspace(-1, 1, 20).reshape(-1, 1)])
+    np.random.seed(7)
+    rs['two'] = uf.rejectionSampling(dens, lambda: np.random.uniform(-1, 1, [50, 1]), [11, 9], [30, 20])
+    np.savez_compressed(os.path.join(OUT, 'rejection.npz'), **rs)
+
     # (9) ContourPlot: plotting grid and the field arrays conPlot / snap1Dt draw (ContourPlot.py:55-296);
     #     matplotlib runs on the Agg backend, only the returned arrays are kept
     import ContourPlot as RC

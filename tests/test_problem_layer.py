@@ -176,3 +176,22 @@ def test_contour_grid_and_fields_match_reference():
         else:
             np.testing.assert_allclose(c.field(f2, 0.4, fill_val=-7.0), G[key + '_field'], rtol=1e-14, atol=1e-15)
     assert G['2dobs_out'].sum() > G['2dt_out'].sum()          # the obstacle really masks grid points
+
+
+def test_rejection_sampling_matches_reference():
+    """uf.rejectionSampling consumes the NumPy stream like the reference's (UtilityFunc.py:342-404): same seed, same
+    accepted samples -- one segment, and two segments with dofT."""
+    Gr = np.load(os.path.join(G, 'rejection.npz'))
+    uf = UF()
+    grid = [np.linspace(-1, 1, 41).reshape(-1, 1)]
+
+    def dens(x=None):
+        if x is None:
+            x = grid[0]
+        return np.exp(-8.0 * (x[:, 0:1] - 0.3) ** 2) + 0.05
+
+    np.random.seed(2024)
+    np.testing.assert_array_equal(uf.rejectionSampling(dens, lambda: np.random.uniform(-1, 1, [50, 1]), 37), Gr['one'])
+    grid[0] = np.vstack([np.linspace(-1, 1, 30).reshape(-1, 1), np.linspace(-1, 1, 20).reshape(-1, 1)])
+    np.random.seed(7)
+    np.testing.assert_array_equal(uf.rejectionSampling(dens, lambda: np.random.uniform(-1, 1, [50, 1]), [11, 9], [30, 20]), Gr['two'])
