@@ -85,6 +85,16 @@ class Log:
         pass
 
 
+class ParamCount:
+    """`tfData.model.count_params()` is the one thing initializeCase asks of the Keras model (VarNetUtility.py:1288)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def count_params(self):
+        return self.n
+
+
 def record(store, key, vn, RVU, batchNum, batchLen, pu):
     """Run the reference assembly for one problem and store every array the device would be fed."""
     PU[0] = pu
@@ -236,6 +246,39 @@ def main():
                 st[g + 'mb1_Input'] = fd0
         st['1dt_mor_scalars'] = np.array([fdm.MORbatchNum, fdm.nt, fdm.integNum, tD.batchNum, tD.batchLen], dtype=float)
         st['1dt_mor_disc'] = fdm.MORdiscArg[0]
+
+    # caseData.txt as the reference's TrainResult.initializeCase writes it (VarNetUtility.py:1217-1464): the case header of a
+    # 1D+t run with mini-batches and of a 2D+t run with non-uniform sampling options -- kept as text lines (an OUTPUT
+    # file of the reference), used to check the build's section / field order
+    import tempfile
+    for key, mk, targ in (
+            ('1dt', lambda: RV.VarNet(pde1(), layerWidth=[6, 5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2),
+             dict(smpScheme='uniform', batchNum=3, shuffleData=True, shuffleFreq=2, weight=[10., 10., 1.])),
+            ('2dt', lambda: RV.VarNet(pde2(), layerWidth=[5], discNum=[4, 3], bDiscNum=3, tDiscNum=4, integPnum=2),
+             dict(smpScheme='optimal', batchNum=None, shuffleData=False, shuffleFreq=1, weight=[5., 1., 1.]))):
+        PU[0] = 1
+        v = mk()
+        v.fixData.setFEdata()
+        t = v.tfData = TowerRecord()
+        t.inpDim, t.layerWidth, t.activationFun = v.dim + 1, list(v.layerWidth if hasattr(v, 'layerWidth') else [5]), ['sigmoid']
+        widths = [6, 5] if key == '1dt' else [5]
+        t.layerWidth = widths
+        fan, P = v.dim + 1, 0
+        for h in widths + [1]:
+            P += fan * h + h
+            fan = h
+        t.model = ParamCount(P)
+        t.processors, t.controller, t.optimizer_name, t.learning_rate = ['/device:GPU:0'], '/device:GPU:0', 'Adam', 0.001
+        folder = tempfile.mkdtemp()
+        tr = RVU.TrainResult(folder, False, verbose=False, saveFreq=100, pltReplace=True)
+        arg = dict(epochNum=1000, tol=0.1, smpScheme=targ['smpScheme'], frac=0.5, addTrainPts=True, suppFactor=1.0,
+                   multiTrainUpd=False, trainUpdelay=20000, tolUpd=0.01, reinitrain=True, weight=targ['weight'],
+                   updateWeights=False, normalizeW=False, adjustWeight=True, useOriginalW=False, saveMORdata=False,
+                   batchNum=targ['batchNum'], batchLen=None, shuffleData=targ['shuffleData'], shuffleFreq=targ['shuffleFreq'])
+        tr.initializeCase(v, arg)
+        lines = open(os.path.join(folder, 'caseData.txt')).read().split('\n')
+        lines = ['Simulation date: <date>' if ln.startswith('Simulation date') else ln for ln in lines]   # keep the fixture stable
+        st['case_%s_lines' % key] = np.array(lines)
 
     # (8) trainWeight arithmetic: the three branches on fixed loss triples, time-dependent and steady
     triples = np.array([[0.37, 1.9, 42.0], [1e-3, 5.0, 0.2], [12.5, 0.04, 3.3e3]])

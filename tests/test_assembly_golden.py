@@ -252,3 +252,35 @@ def test_random_sampling_matches_reference():
     np.testing.assert_allclose(Input, G['rand_%s_Input' % kind], **TOL)
     np.testing.assert_allclose(biInput, G['rand_%s_biInput' % kind], **TOL)
     assert [int(b) for b in biDof] == [int(b) for b in G['rand_%s_biDof' % kind]]
+
+
+@pytest.mark.parametrize('kind', ['1dt', '2dt'])
+def test_case_file_matches_reference_layout(kind, tmp_path):
+    """caseData.txt header: the same sections, fields, order and values as the reference's TrainResult.initializeCase writes
+    for the same problem and train() arguments (VarNetUtility.py:1217-1464).  The banner, the date and the spelling of the
+    activation list are the only lines allowed to differ."""
+    from varnet_amd.varnet import TrainResult
+    ref = [str(x) for x in G['case_%s_lines' % kind]]
+    if kind == '1dt':
+        vn = VarNet(pde1(), layerWidth=[6, 5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2)
+        targ = dict(smpScheme='uniform', batchNum=3, shuffleData=True, shuffleFreq=2, weight=[10., 10., 1.])
+    else:
+        vn = VarNet(pde2(), layerWidth=[5], discNum=[4, 3], bDiscNum=3, tDiscNum=4, integPnum=2)
+        targ = dict(smpScheme='optimal', batchNum=None, shuffleData=False, shuffleFreq=1, weight=[5., 1., 1.])
+    arg = dict(epochNum=1000, tol=0.1, smpScheme=targ['smpScheme'], frac=0.5, addTrainPts=True, suppFactor=1.0,
+               multiTrainUpd=False, trainUpdelay=20000, tolUpd=0.01, reinitrain=True, weight=targ['weight'],
+               updateWeights=False, normalizeW=False, adjustWeight=True, useOriginalW=False, saveMORdata=False,
+               batchNum=targ['batchNum'], batchLen=None, shuffleData=targ['shuffleData'], shuffleFreq=targ['shuffleFreq'])
+    tr = TrainResult(str(tmp_path), False, verbose=False, saveFreq=100, pltReplace=True)
+    tr.initializeCase(vn, arg)
+    mine = open(os.path.join(str(tmp_path), 'caseData.txt')).read().split('\n')
+    i0 = next(i for i, ln in enumerate(ref) if 'Advection-Diffusion problem' in ln)
+    j0 = next(i for i, ln in enumerate(mine) if 'Advection-Diffusion problem' in ln)
+    a, b = ref[i0:], mine[j0:]
+    assert len(a) == len(b), (len(a), len(b), a, b)
+    for x, y in zip(a, b):
+        if x.strip().startswith('activation function for each layer'):
+            assert y.strip().startswith('activation function for each layer')
+            continue
+        assert x == y, (x, y)
+    assert ref[0] == mine[0] and ref[1] == mine[1] and mine[j0 - 2].startswith('Simulation date') and ref[i0 - 2].startswith('Simulation date')
