@@ -279,6 +279,22 @@ def main():
         lines = open(os.path.join(folder, 'caseData.txt')).read().split('\n')
         lines = ['Simulation date: <date>' if ln.startswith('Simulation date') else ln for ln in lines]   # keep the fixture stable
         st['case_%s_lines' % key] = np.array(lines)
+        if key == '1dt':
+            # per-epoch reporting: iterOutput over 25 epochs with saveFreq = 10 (VarNetUtility.py:1560-1631) -> the lines
+            # appended to caseData.txt, the sampled histories and the keys of the trainData.vn pickle
+            import contextlib, io, pickle
+            tr.saveFreq = 10
+            tr.trainWeight = np.array([1.0, 2.0, 3.0])
+            with contextlib.redirect_stdout(io.StringIO()):
+                for ep in range(1, 26):
+                    tr.iterOutput(ep, 1000.0 / ep, 900.0 / ep, 0.25 * ep, 0.5 / ep, 0.1 / ep, np.array([[1.0], [2.0], [3.0]]) / ep, None)
+            allines = open(os.path.join(folder, 'caseData.txt')).read().split('\n')
+            st['iter_lines'] = np.array(allines[len(lines) - 1:])
+            st['iter_iterSmp'], st['iter_loss'] = np.array(tr.iterSmp), np.array(tr.loss)
+            st['iter_lossComp'], st['iter_residual'] = np.array(tr.lossComp), np.array(tr.residual)
+            st['iter_avgtime'] = np.array([tr.avgtime0, tr.avgtime])
+            dump = pickle.load(open(os.path.join(folder, 'trainData.vn'), 'rb'))
+            st['iter_pickle_keys'] = np.array(sorted(dump.keys()))
 
     # (8) trainWeight arithmetic: the three branches on fixed loss triples, time-dependent and steady
     triples = np.array([[0.37, 1.9, 42.0], [1e-3, 5.0, 0.2], [12.5, 0.04, 3.3e3]])

@@ -284,3 +284,30 @@ def test_case_file_matches_reference_layout(kind, tmp_path):
             continue
         assert x == y, (x, y)
     assert ref[0] == mine[0] and ref[1] == mine[1] and mine[j0 - 2].startswith('Simulation date') and ref[i0 - 2].startswith('Simulation date')
+
+
+def test_iteration_report_and_pickle_match_reference(tmp_path):
+    """TrainResult.iterOutput over 25 epochs with saveFreq = 10 (VarNetUtility.py:1560-1631): the lines appended to
+    caseData.txt, the sampled histories and the key set of the trainData.vn pickle equal the reference's."""
+    import pickle
+    from varnet_amd.varnet import TrainResult
+    vn = VarNet(pde1(), layerWidth=[6, 5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2)
+    arg = dict(epochNum=1000, tol=0.1, smpScheme='uniform', frac=0.5, addTrainPts=True, suppFactor=1.0, multiTrainUpd=False,
+               trainUpdelay=20000, tolUpd=0.01, reinitrain=True, weight=[10., 10., 1.], updateWeights=False, normalizeW=False,
+               adjustWeight=True, useOriginalW=False, saveMORdata=False, batchNum=3, batchLen=None, shuffleData=True, shuffleFreq=2)
+    tr = TrainResult(str(tmp_path), False, verbose=False, saveFreq=10, pltReplace=True)
+    tr.initializeCase(vn, arg)
+    n_head = len(open(os.path.join(str(tmp_path), 'caseData.txt')).read().split('\n'))
+    tr.trainWeight = np.array([1.0, 2.0, 3.0])
+    for ep in range(1, 26):
+        tr.iterOutput(ep, 1000.0 / ep, 900.0 / ep, 0.25 * ep, 0.5 / ep, 0.1 / ep, np.array([[1.0], [2.0], [3.0]]) / ep, None)
+    lines = open(os.path.join(str(tmp_path), 'caseData.txt')).read().split('\n')[n_head - 1:]
+    assert lines == [str(x) for x in G['iter_lines']]
+    assert list(tr.iterSmp) == list(G['iter_iterSmp'])
+    np.testing.assert_allclose(tr.loss, G['iter_loss'], rtol=1e-15)
+    np.testing.assert_allclose(np.array(tr.lossComp), G['iter_lossComp'], rtol=1e-15)
+    np.testing.assert_allclose(tr.residual, G['iter_residual'], rtol=1e-15)
+    np.testing.assert_allclose([tr.avgtime0, tr.avgtime], G['iter_avgtime'], rtol=1e-15)
+    dump = pickle.load(open(os.path.join(str(tmp_path), 'trainData.vn'), 'rb'))
+    ref_keys = set(str(k) for k in G['iter_pickle_keys'])
+    assert ref_keys <= set(dump.keys()), ref_keys - set(dump.keys())      # the build adds `lossAll`, nothing is missing
