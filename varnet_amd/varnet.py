@@ -468,17 +468,21 @@ class ManageTrainData:
     def _register(self):
         eng, q = self.vn.engine, self.integNum
         torch = eng.torch
+        if self.shuffled:                         # one upload of the permutation per shuffle, not one per block
+            perm_dev = torch.as_tensor(self.batchInd, device=eng.device, dtype=torch.long)
+            rows_all = (perm_dev[:, None] * q + torch.arange(q, device=eng.device)[None, :]).reshape(-1)
         for mb, d in enumerate(self.mor):
+            if self.shuffled:                     # one gather per array and parameter batch; the blocks are views of it
+                d = dict(d)
+                for key in ('Input', 'gcoef', 'source', 'N_rows', 'dNt_rows'):
+                    if d.get(key) is not None:
+                        d[key] = d[key].index_select(0, rows_all)
+                if d.get('detJ') is not None:
+                    d['detJ'] = d['detJ'].index_select(0, perm_dev)
             for bi in range(self.batchNum):
                 n0, n1 = self.block(bi)
-                if self.shuffled:
-                    tf = torch.as_tensor(self.batchInd[n0:n1], device=eng.device, dtype=torch.long)
-                    rows = (tf[:, None] * q + torch.arange(q, device=eng.device)[None, :]).reshape(-1)
-                    pick = lambda t: None if t is None else t.index_select(0, rows)
-                    pick_k = lambda t: None if t is None else t.index_select(0, tf)
-                else:
-                    pick = lambda t: None if t is None else t[n0 * q:n1 * q]
-                    pick_k = lambda t: None if t is None else t[n0:n1]
+                pick = lambda t: None if t is None else t[n0 * q:n1 * q]
+                pick_k = lambda t: None if t is None else t[n0:n1]
                 detJ = pick_k(d.get('detJ'))
                 eng.set_interior(self.engine_batch(mb, bi), pick(d['Input']), pick(d['gcoef']), pick(d['source']),
                                  n_k=n1 - n0, detJ=self.detJ if detJ is None else detJ,
