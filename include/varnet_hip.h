@@ -30,9 +30,14 @@
 extern "C" {
 #endif
 
-#define VN_MAX_LAYERS 6   /* hidden layers                                   */
-#define VN_MAX_WIDTH  64  /* hidden width                                    */
-#define VN_MAX_DIN    8   /* network inputs: dim + time + MOR parameters     */
+/* What a vn_config may describe (the reference takes any layerWidth list, TFModel.py:208-221).  The hand-written
+ * kernels cover the VN_K* range; anything beyond it runs on the layer-by-layer route (VN_KERNEL_LAYERED). */
+#define VN_MAX_LAYERS 16    /* hidden layers                                   */
+#define VN_MAX_WIDTH  2048  /* hidden width                                    */
+#define VN_MAX_DIN    32    /* network inputs: dim + time + MOR parameters     */
+#define VN_KMAX_LAYERS 6    /* ... covered by the fused / generic kernels      */
+#define VN_KMAX_WIDTH  64
+#define VN_KMAX_DIN    8
 
 enum {
   VN_OK = 0,
@@ -48,9 +53,15 @@ enum { VN_ACT_SIGMOID = 0, VN_ACT_TANH = 1 };   /* activationFun options of the 
 enum { VN_OPT_ADAM = 0, VN_OPT_RMSPROP = 1 };   /* tf.train.AdamOptimizer / RMSPropOptimizer (TFModel.py:183-186) */
 /* Kernel families.  AUTO picks the 8-wave fused kernel where it is instantiated: uniform or ragged hidden widths
  * <= 50 with 1..6 layers, <= 64 with 1..5 layers, d_in <= 8, sigmoid or tanh; integ_num <= 128 in one launch, larger
- * through the two-pass route.  What is left (6 layers wider than 50) runs on the generic kernels. */
+ * through the two-pass route.  Six layers wider than 50 run on the generic kernels; networks beyond VN_KMAX_* on the
+ * layer-by-layer route. */
 enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 /* 4 waves, 32x32x2 */,
-       VN_KERNEL_FUSED16 = 3 /* 8 waves, 16x16x4 */ };
+       VN_KERNEL_FUSED16 = 3 /* 8 waves, 16x16x4 */,
+       /* Layer-by-layer route for networks outside the kernels' range (more than 6 hidden layers, widths above 64,
+        * more than 8 inputs): activations of a chunk of rows live in HBM, every layer is one GEMM over the stacked
+        * (value, tangent) rows -- rocBLAS, loaded with dlopen at first use -- plus hand-written elementwise kernels;
+        * forward twice + reverse once (8 F_pt per point).  Same results contract as the other routes. */
+       VN_KERNEL_LAYERED = 4 };
 
 typedef struct vn_engine vn_engine;
 
@@ -72,7 +83,8 @@ typedef struct vn_config {
 } vn_config;
 
 const char* vn_last_error(void);
-int  vn_abi_version(void);   /* 2 since round 2: towers (vn_comm_*), tanh, empty feeds, vn_kernel_path, vn_profile_comm */
+int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_kernel_path, vn_profile_comm;
+                                * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, VN_KERNEL_LAYERED */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
 int vn_create(const vn_config* cfg, vn_engine** out);

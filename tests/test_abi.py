@@ -29,7 +29,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), 'missing export ' + n
     assert set(names) == set(engine.ABI_SYMBOLS), set(names) ^ set(engine.ABI_SYMBOLS)
-    assert lib.vn_abi_version() == 2
+    assert lib.vn_abi_version() == 3
 
 
 def test_no_silent_cpu_fallback():
@@ -50,12 +50,22 @@ def test_no_silent_cpu_fallback():
 def test_argument_validation_without_gpu():
     engine, lib = _lib()
     cfg = engine.VnConfig()
-    cfg.dim, cfg.d_in, cfg.n_layers, cfg.integ_num = 1, 2, 9, 16     # too many layers
+    cfg.dim, cfg.d_in, cfg.n_layers, cfg.integ_num = 1, 2, 17, 16    # more layers than a vn_config can describe
     h = C.c_void_p()
     assert lib.vn_create(C.byref(cfg), C.byref(h)) == 1
     cfg.n_layers = 1
-    cfg.widths[0] = 500                                               # too wide
+    cfg.widths[0] = 5000                                              # wider than VN_MAX_WIDTH
     assert lib.vn_create(C.byref(cfg), C.byref(h)) == 1
+    cfg.widths[0], cfg.d_in = 20, 40                                  # more inputs than VN_MAX_DIN
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) == 1
+    # nets beyond the kernels' range (9 layers, 500 wide) are legal configs now: they pass validation and fail
+    # only for want of a GPU here (VN_EHIP = 2), not as bad arguments
+    cfg.d_in, cfg.n_layers = 2, 9
+    for i in range(9):
+        cfg.widths[i] = 500
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) in (0, 2)
+    if h.value:
+        lib.vn_destroy(h)
     assert lib.vn_create(None, C.byref(h)) == 1
 
 

@@ -351,7 +351,12 @@ def test_engine_argument_errors():
     with pytest.raises(ValueError):
         VNEngine(1, 2, [5, 5], True, 16, activationFun=['tanh', 'sigmoid'])
     with pytest.raises(ValueError):
-        VNEngine(1, 2, [500], True, 16)
+        VNEngine(1, 2, [5000], True, 16)                             # beyond what a vn_config can describe
+    with pytest.raises(VNError):
+        VNEngine(1, 2, [500], True, 16, kernel=1)                    # outside the generic kernels' range when forced
+    eng = VNEngine(1, 2, [500], True, 16)                            # AUTO: the layer-by-layer route
+    assert eng.kernel_path()[0] == 4
+    eng.close()
 
 
 @pytest.mark.parametrize('kernel', [1, 0, 2], ids=['generic', 'auto', 'fused32'])

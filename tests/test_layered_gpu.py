@@ -1,0 +1,183 @@
+"""
+Networks outside the range of the fused / generic kernels (more than 6 hidden layers, widths above 64, more than 8
+inputs) -- the reference takes any `layerWidth` (TFModel.py:208-221).  They run on the layer-by-layer route
+(vn_layered.hip); same oracle, same bars as tests/test_engine_gpu.py.  The route is also forced (kernel=4) on networks
+the kernels cover, where it must agree with them.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf1_graph as og
+from tests.test_engine_gpu import synth, make_engine, oracle_eval, LOSS_RTOL, GRAD_RTOL, LVEC_RTOL
+
+pytestmark = pytest.mark.gpu
+
+LAYERED = 4
+
+CASES = [
+    # d_in dim widths                 integNum n_k  nB  bDof source integW detJvec
+    (3, 2, [100, 80],                 64,      9,   77, 40,  False, False, False),   # wider than 64
+    (3, 2, [128, 128, 128],           64,      30,  50, 20,  True,  False, True),
+    (2, 1, [20] * 8,                  16,      40,  50, 30,  False, False, False),   # more than 6 hidden layers
+    (3, 2, [30, 70, 12, 65, 9, 40, 33], 36,    17,  12, 5,   True,  True,  True),    # ragged, 7 layers
+    (10, 2, [40, 40],                 64,      12,  30, 10,  False, True,  False),   # more than 8 inputs (many MOR parameters)
+    (3, 2, [256],                     216,     3,   5,  2,   False, True,  False),   # integNum 216, one wide layer
+    (3, 2, [50, 50, 50],              64,      40,  30, 10,  True,  False, False),   # kernel range: forced route
+    (2, 1, [7],                       36,      11,  40, 13,  True,  True,  True),
+]
+
+
+def _setup(case, kernel, act='sigmoid'):
+    d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec = case
+    d = synth(1, d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec)
+    from varnet_amd.engine import VNEngine
+    eng = VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel, activationFun=act)
+    eng.init_params(seed=3)
+    flat = eng.get_params()
+    flat = flat + 0.05 * np.random.default_rng(5).standard_normal(flat.size).astype(np.float32)
+    eng.set_params(flat)
+    eng.set_fe_table(d['N1'], d['dNt1'], d['integW'])
+    eng.set_interior(0, d['Input'], d['gcoef'], d['source'], n_k=n_k, detJ=d['detJ'])
+    eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+    eng.set_weights(d['w'])
+    return eng, d, flat
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_loss_and_grad_parity_layered(case):
+    d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec = case
+    in_range = len(widths) <= 6 and max(widths) <= 64 and d_in <= 8
+    eng, d, flat = _setup(case, LAYERED if in_range else 0)
+    assert eng.kernel_path()[0] == LAYERED
+    ref, gref = oracle_eval(flat, d, d_in, dim, widths, integNum, n_k, bDof, source, integW, detJvec)
+    out, lv = eng.eval_loss(0, lossVec=True)
+    for got, key in zip(out, ['loss', 'BCloss', 'ICloss', 'varLoss']):
+        assert abs(got - ref[key]) <= LOSS_RTOL * abs(ref[key]) + 1e-7, (key, got, ref[key])
+    lref = ref['lossVec'].reshape(-1)
+    assert np.max(np.abs(lv.cpu().numpy() - lref)) <= LVEC_RTOL * np.max(np.abs(lref))
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy()
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
+    err = np.max(np.abs(g[:eng.P] - gref)) / np.max(np.abs(gref))
+    assert err <= GRAD_RTOL, err
+    # run-to-run reproducible (no atomics in the weight-gradient GEMMs)
+    eng.grad(0)
+    torch.cuda.synchronize()
+    assert np.array_equal(gb.cpu().numpy(), g)
+    eng.close()
+
+
+def test_layered_tanh_and_agreement_with_the_kernels():
+    case = (3, 2, [50, 50, 50], 64, 40, 30, 10, True, False, False)
+    grads = []
+    for kernel in (0, LAYERED):
+        eng, d, flat = _setup(case, kernel, act='tanh')
+        gb = eng.bind_grad_buffer()
+        eng.grad(0)
+        torch.cuda.synchronize()
+        grads.append(gb.cpu().numpy().astype(np.float64))
+        eng.close()
+    a, b = grads
+    assert np.max(np.abs(a[:-4] - b[:-4])) <= 3e-5 * np.max(np.abs(a[:-4]))
+    assert abs(a[-4] - b[-4]) <= 1e-5 * abs(a[-4])
+
+
+def test_layered_chunks_and_shard_additivity():
+    """1.28 M rows of a 3 x 96 net do not fit the route's workspace in one piece: the interior set is processed in several
+    chunks, and the same set fed as two halves (chunked differently) sums to the same gradient and loss."""
+    d_in, dim, widths, integNum, n_k, nB, bDof = 3, 2, [96, 96, 96], 64, 20000, 3000, 1700
+    d = synth(7, d_in, dim, widths, integNum, n_k, nB, bDof)
+    from varnet_amd.engine import VNEngine
+    eng = VNEngine(dim, d_in, widths, True, integNum, kernel=0)
+    assert eng.kernel_path()[0] == LAYERED
+    eng.init_params(seed=2)
+    eng.set_fe_table(d['N1'], d['dNt1'], None)
+    eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=n_k, detJ=d['detJ'])
+    eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+    eng.set_weights(d['w'])
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy().astype(np.float64)
+    # shard additivity: the same set as two halves (different chunking) sums to the whole
+    h = n_k // 2 * integNum
+    parts = []
+    for sl, k in ((slice(0, h), n_k // 2), (slice(h, None), n_k - n_k // 2)):
+        eng.set_interior(0, d['Input'][sl], d['gcoef'][sl], None, n_k=k, detJ=d['detJ'])
+        eng.set_weights(d['w'] * np.array([0.5, 0.5, 1.0]))        # BC/IC replicated on both halves at half weight
+        eng.grad(0)
+        torch.cuda.synchronize()
+        parts.append(gb.cpu().numpy().astype(np.float64))
+    s = parts[0] + parts[1]
+    assert np.max(np.abs(s[:eng.P] - g[:eng.P])) <= 2e-5 * np.max(np.abs(g[:eng.P]))
+    assert abs(s[eng.P] - g[eng.P]) <= 1e-5 * abs(g[eng.P])
+    eng.close()
+
+
+@pytest.mark.parametrize('widths,d_in,dim', [([100, 80], 3, 2), ([20] * 8, 2, 1), ([40, 40], 10, 3)])
+def test_forward_and_residual_parity_layered(widths, d_in, dim):
+    rng = np.random.default_rng(0)
+    n = 1000
+    X = rng.uniform(-1, 1, (n, d_in))
+    diff = rng.uniform(0.1, 1, (n, 1)); vel = rng.standard_normal((n, dim))
+    src = rng.standard_normal((n, 1)); ddx = rng.standard_normal((n, dim))
+    eng = make_engine(d_in, dim, widths, 64, False, False)
+    assert eng.kernel_path()[0] == LAYERED
+    eng.init_params(seed=11)
+    flat = eng.get_params().astype(np.float64)
+    uref, rref = og.residual(flat, d_in, widths, torch.float64, X, diff, vel, src, ddx, dim, True)
+    u32 = eng.forward(X.astype(np.float32)).cpu().numpy()
+    assert np.max(np.abs(u32 - uref[:, 0])) < 2e-6 * max(1, np.max(np.abs(uref)))
+    u64 = eng.forward_f64(X).cpu().numpy()
+    assert np.max(np.abs(u64 - uref[:, 0])) < 1e-13
+    u, r = eng.residual(X, diff, vel, src, ddx, fp64=True)
+    assert np.max(np.abs(r.cpu().numpy() - rref[:, 0])) < 1e-11 * max(1, np.max(np.abs(rref)))
+    assert np.max(np.abs(u.cpu().numpy() - uref[:, 0])) < 1e-13
+    u, r = eng.residual(X.astype(np.float32), diff, vel, src, ddx, fp64=False)
+    assert np.max(np.abs(r.cpu().numpy() - rref[:, 0])) < 5e-5 * max(1, np.max(np.abs(rref)))
+    eng.close()
+
+
+def test_adam_trajectory_parity_layered():
+    """100 TF-1 Adam steps of a 2 x 100 net from identical init against the fp64 oracle (<= 1e-2)."""
+    d_in, dim, widths, integNum, n_k, nB, bDof = 2, 1, [100, 100], 16, 64, 60, 40
+    d = synth(2, d_in, dim, widths, integNum, n_k, nB, bDof)
+    eng = make_engine(d_in, dim, widths, integNum, False, False, 0)
+    eng.init_params(seed=1)
+    flat = eng.get_params()
+    eng.set_fe_table(d['N1'], d['dNt1'], None)
+    eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=n_k, detJ=d['detJ'])
+    eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+    eng.set_weights(d['w'])
+    steps = 100
+    losses = torch.zeros(steps, device='cuda')
+    for i in range(steps):
+        eng.train_step(0, losses[i:i + 1])
+    torch.cuda.synchronize()
+    got = losses.cpu().numpy()
+    adam = og.TF1Adam(flat.size, lr=1e-3, dtype=np.float64)
+    th = flat.astype(np.float64)
+    ref = []
+    for i in range(steps):
+        r, g = oracle_eval(th, d, d_in, dim, widths, integNum, n_k, bDof, False, False, False)
+        ref.append(r['loss'])
+        th = adam.step(th, g)
+    ref = np.array(ref)
+    assert np.max(np.abs(got - ref) / np.abs(ref)) <= 1e-2
+    assert np.max(np.abs(eng.get_params() - th)) <= 2e-3 * np.max(np.abs(th))
+    eng.close()
+
+
+def test_varnet_constructor_accepts_a_wide_deep_net(tmp_path):
+    """The kept constructor with a layerWidth the kernels do not cover trains end to end (Operator_1Dt problem)."""
+    from tests.test_varnet_host import op1dt
+    vn = op1dt(layerWidth=[80, 80, 80, 80, 80, 80, 80], discNum=10, tDiscNum=20)
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], epochNum=30, saveFreq=10, verbose=False)
+    assert vn.engine.kernel_path()[0] == LAYERED
+    assert np.isfinite(res.lossAll).all() and res.lossAll[-1] < res.lossAll[0]
+    r64, _, _, _ = vn.residual(fp64=True)
+    r32, _, _, _ = vn.residual()
+    assert np.isfinite(r64) and abs(r64 - r32) <= 1e-3 * abs(r64)

@@ -33,6 +33,12 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(VN_EHIP, "%s: %s", #expr, hipGetErrorString(e_));   \
   } while (0)
 
+#define LAYCHK(call)                                                          \
+  do {                                                                        \
+    char lerr_[384] = "";                                                      \
+    if (call) return fail(VN_EHIP, "layer-by-layer route: %s", lerr_);        \
+  } while (0)
+
 struct Batch {
   const float* Input = nullptr;
   const float* gcoef = nullptr;
@@ -93,6 +99,7 @@ struct vn_engine {
   bool use_fused16 = false;
   VnOptArgs fuse;                    // optimizer step to fold into the next gradient reduction (kind -1: none)
   bool two_pass = false;             // fused kernel twice around the row-wise seed kernel (integ_num > 128)
+  VnLayered* layered = nullptr;      // layer-by-layer route (networks outside the kernels' range, or forced)
   float* tp_losspart = nullptr; long tp_losspart_cap = 0;
   float* fused_losspart = nullptr;   // [ncu*3]
   unsigned long long* stamps = nullptr;   // 8 counters, diagnostic builds
@@ -166,7 +173,7 @@ uint64_t splitmix64(uint64_t& s) {
 }
 
 int refresh_theta64(vn_engine* h) {
-  // fp32 parameters widened on the host side of the stream: tiny (P <= ~2e4), off the hot path
+  // fp32 parameters widened on the host side of the stream: small, off the hot path
   std::vector<float> t(h->net.P);
   HIPCHK(hipMemcpyAsync(t.data(), h->theta, t.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -210,7 +217,13 @@ int fused_forward(vn_engine* h, const float* X, const float* G, long n, float* o
 // forward + weak-form epilogue; with_seeds = also produce backward seeds.
 int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* lossVec, float* lossdst) {
   const long nT = b.n_k * h->cfg.integ_num;
-  if (h->use_fused16 && h->has_fe && !with_seeds) {
+  if (h->layered) {
+    VnRows s0{}, s1{};
+    s0.X = b.Input; s0.G = b.gcoef; s0.u = h->u; s0.ud = h->ud; s0.n = nT;
+    s1.X = bi_x(h, b); s1.G = nullptr; s1.u = h->ub; s1.ud = nullptr; s1.n = h->nB;
+    LAYCHK(vn_layered_forward(h->layered, h->theta, s0, h->stream, lerr_, sizeof lerr_));
+    LAYCHK(vn_layered_forward(h->layered, h->theta, s1, h->stream, lerr_, sizeof lerr_));
+  } else if (h->use_fused16 && h->has_fe && !with_seeds) {
     // splitLoss / trainWeight / the monitors: the fused kernel's forward-only mode for both row sets
     if (int rc = fused_forward(h, b.Input, b.gcoef, nT, h->u, h->ud)) return rc;
     if (int rc = fused_forward(h, bi_x(h, b), nullptr, h->nB, h->ub, nullptr)) return rc;
@@ -403,7 +416,7 @@ int load_rccl() {
 extern "C" {
 
 const char* vn_last_error(void) { return g_err.c_str(); }
-int vn_abi_version(void) { return 2; }   // 2: vn_comm_*, vn_profile_comm, vn_kernel_path, VN_ACT_TANH, VN_ECOMM, n_k == 0 feeds
+int vn_abi_version(void) { return 3; }   // 3: vn_config.widths[16], VN_KERNEL_LAYERED (2: vn_comm_*, vn_kernel_path, tanh, empty feeds)
 
 int vn_create(const vn_config* cfg, vn_engine** out) {
   if (!cfg || !out) return fail(VN_EINVAL, "null argument");
@@ -417,23 +430,37 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
                 e == hipSuccess ? "device count 0" : hipGetErrorString(e));
   if (cfg->device < 0 || cfg->device >= ndev) return fail(VN_EINVAL, "requested processor %d is unavailable!", cfg->device);
   HIPCHK(hipSetDevice(cfg->device));
-  // the generic backward kernel keeps every layer of a tile in LDS; nets it cannot hold are fine as long as the
-  // fused kernel (which the AUTO choice then uses, directly or through the two-pass route) is instantiated for them
-  const bool fused_ok = cfg->kernel != VN_KERNEL_GENERIC && cfg->kernel != VN_KERNEL_FUSED && vn_fused16_net_supported(net);
-  if (!fused_ok && vn_generic_bwd_lds_bytes(net) > 160 * 1024)
-    return fail(VN_EUNSUPPORTED, "network needs %zu B of LDS per tile on the generic kernels (> 160 KiB): reduce depth/width",
-                vn_generic_bwd_lds_bytes(net));
+  // Route.  Networks outside the kernels' range (VN_KMAX_*), and nets whose generic-kernel tile does not fit LDS while
+  // no fused instantiation exists, go layer by layer (vn_layered.hip); VN_KERNEL_LAYERED forces that route.
+  const bool in_range = vn_net_in_kernel_range(net);
+  if (!in_range && cfg->kernel != VN_KERNEL_AUTO && cfg->kernel != VN_KERNEL_LAYERED)
+    return fail(VN_EUNSUPPORTED, "network (%d layers, widest %d, %d inputs) is outside the range of the requested kernel family "
+                "(<= %d layers, width <= %d, <= %d inputs): use VN_KERNEL_AUTO or VN_KERNEL_LAYERED",
+                net.L, net.hmax, net.d_in, VN_KMAX_LAYERS, VN_KMAX_WIDTH, VN_KMAX_DIN);
+  const bool fused_ok = in_range && cfg->kernel != VN_KERNEL_GENERIC && cfg->kernel != VN_KERNEL_FUSED &&
+                        cfg->kernel != VN_KERNEL_LAYERED && vn_fused16_net_supported(net);
+  bool use_layered = cfg->kernel == VN_KERNEL_LAYERED || !in_range;
+  if (!use_layered && !fused_ok && vn_generic_bwd_lds_bytes(net) > 160 * 1024) {
+    if (cfg->kernel == VN_KERNEL_AUTO) use_layered = true;
+    else
+      return fail(VN_EUNSUPPORTED, "network needs %zu B of LDS per tile on the generic kernels (> 160 KiB): reduce depth/width",
+                  vn_generic_bwd_lds_bytes(net));
+  }
   vn_engine* h = new vn_engine();
   h->cfg = *cfg;              // taken literally (lr = 0 is a legal, if useless, TF learning rate: TFModel.py:130)
   h->net = net;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->ncu = prop.multiProcessorCount;
   const size_t P = net.P;
-  const size_t fwd_lds = vn_generic_fwd_lds_bytes(net), bwd_lds = vn_generic_bwd_lds_bytes(net);
-  int fpc = (int)((160 * 1024) / fwd_lds); if (fpc > 4) fpc = 4; if (fpc < 1) fpc = 1;
-  int bpc = (int)((160 * 1024) / bwd_lds); if (bpc > 2) bpc = 2; if (bpc < 1) bpc = 1;
-  h->fwd_grid = h->ncu * fpc;
-  h->bwd_grid = h->ncu * bpc;
+  if (use_layered) {
+    h->fwd_grid = h->bwd_grid = 1;            // one gradient vector, no per-workgroup partials
+  } else {
+    const size_t fwd_lds = vn_generic_fwd_lds_bytes(net), bwd_lds = vn_generic_bwd_lds_bytes(net);
+    int fpc = (int)((160 * 1024) / fwd_lds); if (fpc > 4) fpc = 4; if (fpc < 1) fpc = 1;
+    int bpc = (int)((160 * 1024) / bwd_lds); if (bpc > 2) bpc = 2; if (bpc < 1) bpc = 1;
+    h->fwd_grid = h->ncu * fpc;
+    h->bwd_grid = h->ncu * bpc;
+  }
   hipError_t a = hipSuccess;
   if (a == hipSuccess) a = hipMalloc((void**)&h->theta, P * sizeof(float));
   if (a == hipSuccess) a = hipMalloc((void**)&h->m, P * sizeof(float));
@@ -453,6 +480,20 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
     return fail(VN_ENOMEM, "device allocation failed: %s", hipGetErrorString(a));
   }
   h->gradbuf = h->gradbuf_int;
+  if (use_layered) {
+    char lerr[384] = "";
+    if (vn_layered_create(&h->layered, net, lerr, sizeof lerr)) {
+      vn_destroy(h);
+      return fail(VN_EUNSUPPORTED, "layer-by-layer route unavailable: %s", lerr);
+    }
+    h->prof_name = "vn_layered_backward";
+    h->ev0.resize(PROF_CAP, nullptr);
+    h->ev1.resize(PROF_CAP, nullptr);
+    h->cev0.resize(PROF_CAP, nullptr);
+    h->cev1.resize(PROF_CAP, nullptr);
+    *out = h;
+    return VN_OK;
+  }
   if (cfg->kernel == VN_KERNEL_FUSED && !vn_fused_supported(net, cfg->integ_num)) {
     vn_destroy(h);
     return fail(VN_EUNSUPPORTED, "fused kernel unsupported for this network / integ_num");
@@ -490,6 +531,7 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
 int vn_destroy(vn_engine* h) {
   if (!h) return VN_OK;
   (void)hipSetDevice(h->cfg.device);
+  if (h->layered) { (void)hipStreamSynchronize(h->stream); vn_layered_destroy(h->layered); h->layered = nullptr; }
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   void* ptrs[] = {h->theta, h->m, h->v, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
                   h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart, h->stamps, h->dd_uv, h->dd_ug, h->dd_su, h->dd_sg, h->dd_partial,
@@ -757,6 +799,23 @@ int vn_grad(vn_engine* h, int32_t batch) {
   VnRows s0{}, s1{};
   s0.X = b.Input; s0.G = b.gcoef; s0.ubar = h->ubar; s0.udbar = h->udbar; s0.n = nT;
   s1.X = bi_x(h, b); s1.G = nullptr; s1.ubar = h->ubar_b; s1.udbar = nullptr; s1.n = h->nB;
+  if (h->layered) {
+    // one gradient vector (no per-workgroup partials): the GEMMs accumulate into it chunk by chunk
+    HIPCHK(hipMemsetAsync(h->partial, 0, (size_t)h->net.P * sizeof(float), h->stream));
+    const bool lrec = h->prof_on && h->prof_n < PROF_CAP;
+    if (lrec) {
+      if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
+      HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
+    }
+    LAYCHK(vn_layered_backward(h->layered, h->theta, s0, h->partial, h->stream, lerr_, sizeof lerr_));
+    LAYCHK(vn_layered_backward(h->layered, h->theta, s1, h->partial, h->stream, lerr_, sizeof lerr_));
+    if (lrec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
+    const long nth = b.n_k > h->nB ? b.n_k : h->nB;
+    const int lg = (int)(((nth > 0 ? nth : 1) + 255) / 256);
+    HIPCHK(vn_reduce_launch(h->partial, 1, h->net.P, h->losspart, lg, h->bDof, h->nB, (float)h->w[0], (float)h->w[1],
+                            (float)h->w[2], h->gradbuf, h->stream, h->fuse));
+    return VN_OK;
+  }
   const bool rec = h->prof_on && h->prof_n < PROF_CAP;
   if (rec) {
     if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
@@ -846,6 +905,12 @@ int vn_eval_loss(vn_engine* h, int32_t batch, double out[4], float* lossVec_dev)
 int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
   if (!h || (n > 0 && (!X || !u))) return fail(VN_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->layered) {
+    VnRows sl{};
+    sl.X = X; sl.G = nullptr; sl.u = u; sl.ud = nullptr; sl.n = n;
+    LAYCHK(vn_layered_forward(h->layered, h->theta, sl, h->stream, lerr_, sizeof lerr_));
+    return VN_OK;
+  }
   if (h->use_fused16) return fused_forward(h, X, nullptr, n, u, nullptr);
   VnRows s0{}, s1{};
   s0.X = X; s0.G = nullptr; s0.u = u; s0.ud = nullptr; s0.n = n;
@@ -857,6 +922,10 @@ int vn_forward_f64(vn_engine* h, const double* X, int64_t n, double* u) {
   if (!h || (n > 0 && (!X || !u))) return fail(VN_EINVAL, "null argument");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (int rc = refresh_theta64(h)) return rc;
+  if (h->layered) {
+    LAYCHK(vn_layered_forward_f64(h->layered, h->theta64, X, n, u, h->stream, lerr_, sizeof lerr_));
+    return VN_OK;
+  }
   HIPCHK(vn_pointwise_forward_f64(h->net, h->theta64, X, n, u, h->stream));
   return VN_OK;
 }
@@ -866,6 +935,11 @@ int vn_residual(vn_engine* h, const float* X, const float* diff, const float* ve
   if (!h || (n > 0 && (!X || !diff || !vel || !res))) return fail(VN_EINVAL, "null argument");
   if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "residual supports dim <= 3");
   HIPCHK(hipSetDevice(h->cfg.device));
+  if (h->layered) {
+    LAYCHK(vn_layered_residual_f32(h->layered, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->stream,
+                                   lerr_, sizeof lerr_));
+    return VN_OK;
+  }
   HIPCHK(vn_pointwise_residual_f32(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res,
                                    h->stream));
   return VN_OK;
@@ -877,6 +951,11 @@ int vn_residual_f64(vn_engine* h, const double* X, const double* diff, const dou
   if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "residual supports dim <= 3");
   HIPCHK(hipSetDevice(h->cfg.device));
   if (int rc = refresh_theta64(h)) return rc;
+  if (h->layered) {
+    LAYCHK(vn_layered_residual_f64(h->layered, h->theta64, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->stream,
+                                   lerr_, sizeof lerr_));
+    return VN_OK;
+  }
   HIPCHK(vn_pointwise_residual_f64(h->net, h->theta64, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res,
                                    h->stream));
   return VN_OK;
@@ -969,7 +1048,7 @@ int vn_profile_comm(vn_engine* h, double* mean_ms, int64_t* calls) {
 
 int vn_kernel_path(const vn_engine* h, int32_t* kernel, int32_t* two_pass) {
   if (!h || !kernel) return fail(VN_EINVAL, "null argument");
-  *kernel = h->use_fused16 ? VN_KERNEL_FUSED16 : h->use_fused ? VN_KERNEL_FUSED : h->two_pass ? VN_KERNEL_FUSED16 : VN_KERNEL_GENERIC;
+  *kernel = h->layered ? VN_KERNEL_LAYERED : h->use_fused16 ? VN_KERNEL_FUSED16 : h->use_fused ? VN_KERNEL_FUSED : h->two_pass ? VN_KERNEL_FUSED16 : VN_KERNEL_GENERIC;
   if (two_pass) *two_pass = h->two_pass ? 1 : 0;
   return VN_OK;
 }

@@ -156,10 +156,10 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
   float* sub = T + SS;                       // [TP] ubar
   float* sudb = sub + TP;                    // [TP] udbar
 
-  f32x4 wacc[VN_MAX_LAYERS][4];
-  float bacc[VN_MAX_LAYERS];
+  f32x4 wacc[VN_KMAX_LAYERS][4];
+  float bacc[VN_KMAX_LAYERS];
 #pragma unroll
-  for (int l = 0; l < VN_MAX_LAYERS; ++l) {
+  for (int l = 0; l < VN_KMAX_LAYERS; ++l) {
     bacc[l] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wacc[l][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
 
     // ---- hidden layers, last to first ----
 #pragma unroll
-    for (int l = VN_MAX_LAYERS; l >= 1; --l) {
+    for (int l = VN_KMAX_LAYERS; l >= 1; --l) {
       if (l <= L) {
         const int Hin = net.H[l - 1], Hout = net.H[l];
         const float* W = theta + net.woff[l];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NTHREADS) void vn_generic_bwd_kernel(VnNet net, con
   // ---- write this workgroup's partial gradient (flat parameter layout) ----
   float* out = partial + (long)blockIdx.x * net.P;
 #pragma unroll
-  for (int l = 1; l <= VN_MAX_LAYERS; ++l) {
+  for (int l = 1; l <= VN_KMAX_LAYERS; ++l) {
     if (l <= L) {
       const int Hin = net.H[l - 1], Hout = net.H[l];
       const int ntn = (Hout + 15) >> 4, ntm = (Hin + 15) >> 4;

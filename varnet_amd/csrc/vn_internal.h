@@ -5,7 +5,8 @@
 #include "../../include/varnet_hip.h"
 
 // Network description passed by value to every kernel.  Layer index l = 1..L are the hidden
-// (sigmoid) layers, l = L+1 is the linear output layer; H[0] = d_in, H[L+1] = 1.
+// (sigmoid) layers, l = L+1 is the linear output layer; H[0] = d_in, H[L+1] = 1.  The arrays hold the ABI maximum;
+// the kernels themselves cover VN_KMAX_LAYERS x VN_KMAX_WIDTH (vn_net_in_kernel_range), the rest is vn_layered.hip.
 struct VnNet {
   int d_in, dim, L, P, hmax;
   int act;                       // VN_ACT_SIGMOID | VN_ACT_TANH, uniform over the hidden layers
@@ -43,6 +44,10 @@ struct VnSeedArgs {
   float w0, w1, w2;
   float* part;                              // [gridDim.x * 3] block partials (var, bc, ic)
 };
+
+inline bool vn_net_in_kernel_range(const VnNet& net) {
+  return net.L <= VN_KMAX_LAYERS && net.hmax <= VN_KMAX_WIDTH && net.d_in <= VN_KMAX_DIN;
+}
 
 // ---- generic (any width <= 64, any integ_num) kernels: vn_generic.hip -------------------
 size_t vn_generic_fwd_lds_bytes(const VnNet& net);
@@ -131,3 +136,23 @@ hipError_t vn_pointwise_residual_f64(const VnNet& net, const double* theta, cons
                                      const double* diff, const double* vel, const double* src,
                                      const double* ddx, int time_dependent, long n, double* u,
                                      double* res, hipStream_t s);
+
+// ---- layer-by-layer route for networks outside the kernels' range: vn_layered.hip ------------------
+// Activations of a chunk of rows in HBM, one GEMM per layer over the stacked (value, tangent [, derivative]) streams
+// (rocBLAS through dlopen), elementwise kernels in between.  All calls enqueue on `s`; errors come back as a message.
+struct VnLayered;
+int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errlen);
+void vn_layered_destroy(VnLayered* w);
+// u (and ud along G, if both given) at seg.n rows
+int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipStream_t s, char* err, size_t errlen);
+// grad[0..P) += d loss / d theta from the rows of seg with seeds seg.ubar / seg.udbar (forward recomputed per chunk)
+int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, float* grad, hipStream_t s, char* err,
+                        size_t errlen);
+int vn_layered_forward_f64(VnLayered* w, const double* theta, const double* X, long n, double* u, hipStream_t s,
+                           char* err, size_t errlen);
+int vn_layered_residual_f32(VnLayered* w, const float* theta, const float* X, const float* diff, const float* vel,
+                            const float* src, const float* ddx, int td, long n, float* u, float* res, hipStream_t s,
+                            char* err, size_t errlen);
+int vn_layered_residual_f64(VnLayered* w, const double* theta, const double* X, const double* diff, const double* vel,
+                            const double* src, const double* ddx, int td, long n, double* u, double* res, hipStream_t s,
+                            char* err, size_t errlen);

@@ -1,0 +1,617 @@
+// Layer-by-layer route for networks outside the range of the fused / generic kernels (more than VN_KMAX_LAYERS hidden
+// layers, hidden widths above VN_KMAX_WIDTH, more than VN_KMAX_DIN inputs).  The reference accepts any `layerWidth`
+// (TFModel.py:208-221); this keeps the constructor drop-in for such networks at the price of HBM round trips.
+//
+// Formulation (the same (value, one tangent) recurrences as the kernels, oracle/tangent_ref.py):
+//   forward   z = a_{l-1} W_l + b_l,  zd = ad_{l-1} W_l,   a_l = act(z),  ad_l = act'(z) zd
+//   reverse   zbar = s1 abar + s2r ad adbar,  zdbar = s1 adbar          (s1 = act'(z), s2r = act''/act', both functions of a;
+//             act''(z) zd = s2r s1 zd = s2r ad, so the reverse pass needs only the stored (a, ad), not zd)
+//             abar_{l-1} = zbar W_l^T,  adbar_{l-1} = zdbar W_l^T
+//             dW_l = a_{l-1}^T zbar + ad_{l-1}^T zdbar,   db_l = sum_rows zbar
+// Data layout: the streams of a chunk of rows are STACKED along the row axis -- buffer [S][n][H], read by the GEMMs as
+// one (S n) x H row-major matrix -- so every layer is ONE GEMM forward and TWO in the reverse pass, whatever S is
+// (S = 1: BC/IC rows and vn_forward; S = 2: interior rows; S = 1 + nd1 + dim: the strong residual with its first and
+// second derivative streams).  The GEMMs are rocBLAS (plain library GEMMs on huge-M, small-N/K shapes), resolved with
+// dlopen at first use so that libvarnet_hip.so neither links it nor loads it for networks the kernels cover; atomics
+// are switched off, so results are run-to-run reproducible.  Everything between the GEMMs is hand-written below.
+// Rows are processed in chunks sized to a fixed workspace; the forward is recomputed per chunk in the reverse pass
+// (the seeds need R_k of whole test functions first): 8 F_pt per interior point like the two-pass route.
+#include "vn_internal.h"
+
+#include <dlfcn.h>
+#include <rocblas/rocblas.h>   // types and prototypes only: librocblas is dlopen'ed, never linked
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Blas {
+  void* dl = nullptr;
+  decltype(&rocblas_create_handle) create_handle = nullptr;
+  decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
+  decltype(&rocblas_set_stream) set_stream = nullptr;
+  decltype(&rocblas_set_atomics_mode) set_atomics_mode = nullptr;
+  decltype(&rocblas_sgemm) sgemm = nullptr;
+  decltype(&rocblas_sgemm_strided_batched) sgemm_strided_batched = nullptr;
+  decltype(&rocblas_dgemm) dgemm = nullptr;
+  decltype(&rocblas_sgemv) sgemv = nullptr;
+  decltype(&rocblas_dgemv) dgemv = nullptr;
+  decltype(&rocblas_status_to_string) status_to_string = nullptr;
+};
+Blas g_blas;
+
+int lfail(char* err, size_t n, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (err && n) vsnprintf(err, n, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+int load_blas(char* err, size_t n) {
+  if (g_blas.dl) return 0;
+  const char* names[] = {getenv("VN_ROCBLAS_LIB"), "librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"};
+  void* dl = nullptr;
+  for (const char* nm : names) {
+    if (!nm || !*nm) continue;
+    dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+    if (dl) break;
+  }
+  if (!dl) return lfail(err, n, "rocBLAS not found (%s): set VN_ROCBLAS_LIB; it serves networks beyond %d layers / width %d",
+                        dlerror(), VN_KMAX_LAYERS, VN_KMAX_WIDTH);
+  Blas b;
+  b.dl = dl;
+#define VN_SYM(field, name)                                                     \
+  b.field = (decltype(b.field))dlsym(dl, name);                                 \
+  if (!b.field) { dlclose(dl); return lfail(err, n, "rocBLAS symbol %s missing", name); }
+  VN_SYM(create_handle, "rocblas_create_handle")
+  VN_SYM(destroy_handle, "rocblas_destroy_handle")
+  VN_SYM(set_stream, "rocblas_set_stream")
+  VN_SYM(set_atomics_mode, "rocblas_set_atomics_mode")
+  VN_SYM(sgemm, "rocblas_sgemm")
+  VN_SYM(sgemm_strided_batched, "rocblas_sgemm_strided_batched")
+  VN_SYM(dgemm, "rocblas_dgemm")
+  VN_SYM(sgemv, "rocblas_sgemv")
+  VN_SYM(dgemv, "rocblas_dgemv")
+  VN_SYM(status_to_string, "rocblas_status_to_string")
+#undef VN_SYM
+  g_blas = b;
+  return 0;
+}
+
+template <typename T> struct BlasT;
+template <> struct BlasT<float> {
+  static rocblas_status gemm(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* al,
+                             const float* A, int lda, const float* B, int ldb, const float* be, float* C, int ldc) {
+    return g_blas.sgemm(h, ta, tb, m, n, k, al, A, lda, B, ldb, be, C, ldc);
+  }
+  static rocblas_status gemv(rocblas_handle h, rocblas_operation t, int m, int n, const float* al, const float* A, int lda,
+                             const float* x, const float* be, float* y) {
+    return g_blas.sgemv(h, t, m, n, al, A, lda, x, 1, be, y, 1);
+  }
+};
+template <> struct BlasT<double> {
+  static rocblas_status gemm(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double* al,
+                             const double* A, int lda, const double* B, int ldb, const double* be, double* C, int ldc) {
+    return g_blas.dgemm(h, ta, tb, m, n, k, al, A, lda, B, ldb, be, C, ldc);
+  }
+  static rocblas_status gemv(rocblas_handle h, rocblas_operation t, int m, int n, const double* al, const double* A, int lda,
+                             const double* x, const double* be, double* y) {
+    return g_blas.dgemv(h, t, m, n, al, A, lda, x, 1, be, y, 1);
+  }
+};
+
+#define LHIP(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return lfail(err, errlen, "%s: %s", #expr, hipGetErrorString(e_));    \
+  } while (0)
+#define LBLAS(expr)                                                                             \
+  do {                                                                                          \
+    rocblas_status s_ = (expr);                                                                 \
+    if (s_ != rocblas_status_success) return lfail(err, errlen, "%s: %s", #expr, g_blas.status_to_string(s_)); \
+  } while (0)
+
+// ---- elementwise kernels -------------------------------------------------------------------------------------------
+constexpr int EB = 256;
+
+template <typename T> __device__ __forceinline__ T act_f(T z, int act);
+template <> __device__ __forceinline__ float act_f<float>(float z, int act) {
+  return act == VN_ACT_TANH ? tanhf(z) : 1.0f / (1.0f + expf(-z));
+}
+template <> __device__ __forceinline__ double act_f<double>(double z, int act) {
+  return act == VN_ACT_TANH ? tanh(z) : 1.0 / (1.0 + exp(-z));
+}
+template <typename T> __device__ __forceinline__ T act_s1(T a, int act) { return act == VN_ACT_TANH ? T(1) - a * a : a * (T(1) - a); }
+template <typename T> __device__ __forceinline__ T act_s2r(T a, int act) { return act == VN_ACT_TANH ? T(-2) * a : T(1) - T(2) * a; }
+
+// layer-0 streams of the training pass: stream 0 = X rows, stream 1 = the tangent direction (G in the first `dim`
+// inputs, zero elsewhere: the derivative is taken along the spatial coordinates only, TFModel.py:536-545)
+__global__ __launch_bounds__(EB) void k_pack_train(const float* __restrict__ X, const float* __restrict__ G, long n, int d_in,
+                                                  int dim, int S, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i >= n * d_in) return;
+  const long r = i / d_in;
+  const int k = (int)(i % d_in);
+  out[i] = X[i];
+  if (S == 2) out[n * d_in + i] = (k < dim) ? G[r * dim + k] : 0.f;
+}
+
+// z (+ bias), zd  ->  a, ad in place
+__global__ __launch_bounds__(EB) void k_act_train(float* __restrict__ A, const float* __restrict__ bias, long n, int H, int S,
+                                                 int act) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i >= n * H) return;
+  const int c = (int)(i % H);
+  const float a = act_f<float>(A[i] + bias[c], act);
+  A[i] = a;
+  if (S == 2) A[n * H + i] *= act_s1<float>(a, act);
+}
+
+// adjoints of the last hidden layer: abar = ubar w_o^T, adbar = udbar w_o^T
+__global__ __launch_bounds__(EB) void k_seed_outer(const float* __restrict__ ubar, const float* __restrict__ udbar,
+                                                  const float* __restrict__ wo, long n, int H, int S, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i >= n * H) return;
+  const long r = i / H;
+  const float w = wo[i % H];
+  out[i] = ubar[r] * w;
+  if (S == 2) out[n * H + i] = udbar[r] * w;
+}
+
+// (abar, adbar) -> (zbar, zdbar) in place; A = the layer's stored (a, ad)
+__global__ __launch_bounds__(EB) void k_act_bwd(float* __restrict__ B, const float* __restrict__ A, long n, int H, int S, int act) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i >= n * H) return;
+  const float a = A[i];
+  const float s1 = act_s1<float>(a, act);
+  float zbar = s1 * B[i];
+  if (S == 2) {
+    const float adbar = B[n * H + i];
+    zbar += act_s2r<float>(a, act) * A[n * H + i] * adbar;
+    B[n * H + i] = s1 * adbar;
+  }
+  B[i] = zbar;
+}
+
+// out[r] = (bias ? *bias : 0) + sum_c A[r][c] w[c]: one wave per row, fixed-order butterfly (model value / directional
+// derivative from the last hidden layer; the library gemv runs this shape at 0.5 TB/s)
+__global__ __launch_bounds__(EB) void k_rowdot(const float* __restrict__ A, const float* __restrict__ wv, const float* __restrict__ bias,
+                                              long n, int H, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * (EB / 64) + (threadIdx.x >> 6), nw = (long)gridDim.x * (EB / 64);
+  for (long r = wave; r < n; r += nw) {
+    float acc = 0.f;
+    for (int c = lane; c < H; c += 64) acc += A[r * H + c] * wv[c];
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) out[r] = acc + (bias ? *bias : 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EB) void k_fill(T* __restrict__ p, long n, T v) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+// fill from a device scalar (the output bias)
+template <typename T>
+__global__ __launch_bounds__(EB) void k_fill_from(T* __restrict__ p, long n, const T* __restrict__ v) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i < n) p[i] = *v;
+}
+
+// ---- strong residual: streams 0 = value, 1..nd1 = first derivatives, nd1+1..nd1+dim = second derivatives --------------
+template <typename T>
+__global__ __launch_bounds__(EB) void k_pack_res(const T* __restrict__ X, long n, int d_in, int nd1, int S, T* __restrict__ out) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i >= n * d_in) return;
+  const int k = (int)(i % d_in);
+  out[i] = X[i];
+  for (int s = 1; s < S; ++s) out[(long)s * n * d_in + i] = (s <= nd1 && k == s - 1) ? T(1) : T(0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(EB) void k_act_res(T* __restrict__ A, const T* __restrict__ bias, long n, int H, int nd1, int dim,
+                                               int act) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i >= n * H) return;
+  const long st = n * H;
+  const T s = act_f<T>(A[i] + bias[i % H], act);
+  const T s1 = act_s1<T>(s, act);
+  const T s2 = s1 * act_s2r<T>(s, act);
+  A[i] = s;
+  for (int d = 0; d < dim; ++d) {
+    const T z1 = A[(1 + d) * st + i];
+    A[(1 + nd1 + d) * st + i] = s2 * z1 * z1 + s1 * A[(1 + nd1 + d) * st + i];
+  }
+  for (int d = 0; d < nd1; ++d) A[(1 + d) * st + i] *= s1;
+}
+
+// y = [val | g_0.. | lap_0..] (S x n, from the output gemv) -> u, residual (TFModel.py:750-754)
+template <typename T>
+__global__ __launch_bounds__(EB) void k_res_combine(const T* __restrict__ y, const T* __restrict__ bo, const T* __restrict__ diff,
+                                                   const T* __restrict__ vel, const T* __restrict__ src,
+                                                   const T* __restrict__ ddx, int td, long n, int dim, int nd1,
+                                                   T* __restrict__ u, T* __restrict__ res) {
+  const long r = (long)blockIdx.x * EB + threadIdx.x;
+  if (r >= n) return;
+  T lap = T(0);
+  for (int d = 0; d < dim; ++d) lap += y[(1 + nd1 + d) * n + r];
+  T out = td ? -y[(1 + dim) * n + r] : T(0);
+  out += diff[r] * lap;
+  for (int d = 0; d < dim; ++d) {
+    const T dd = ddx ? ddx[r * dim + d] : T(0);
+    out -= (vel[r * dim + d] - dd) * y[(1 + d) * n + r];
+  }
+  if (src) out += src[r];
+  if (u) u[r] = y[r] + *bo;
+  res[r] = out;
+}
+
+// ---- reductions over the rows of a chunk (hand-written: a library gemv / TN gemm sees a tiny output and millions of
+// rows to sum, and without atomics runs them on a handful of workgroups -- 83 % of the route's time when first measured)
+constexpr int RS_ROWS = 2048;          // rows per workgroup of the column-sum kernel
+
+// part[b][c] = sum over the rows r of block b of A[r][c] * (x ? x[r] : 1)      (A row-major n x H).  A workgroup is 64
+// columns x 4 row lanes (grid.y = column groups): each wave streams 256 contiguous bytes per row, four rows of it in
+// flight per lane; the four row lanes meet in LDS in a fixed order.
+__global__ __launch_bounds__(EB) void k_colsum_part(const float* __restrict__ A, const float* __restrict__ x, long n, int H,
+                                                   float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + tx;
+  const long r0 = (long)blockIdx.x * RS_ROWS;
+  const long r1 = r0 + RS_ROWS < n ? r0 + RS_ROWS : n;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < H) {
+    long r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = A[(r + 4 * k) * H + c];
+        acc[k] += x ? v * x[r + 4 * k] : v;
+      }
+    }
+    for (; r < r1; r += 4) acc[0] += x ? A[r * H + c] * x[r] : A[r * H + c];
+  }
+  red[ty][tx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (ty == 0 && c < H) part[(long)blockIdx.x * H + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+// narrow matrices (H < 8): the column lanes of the kernel above would mostly idle; here a workgroup's threads split
+// the rows, lane = row, and a fixed-order LDS tree adds them (H == 1: the output-bias gradient, sum of ubar)
+__global__ __launch_bounds__(EB) void k_colsum_part_narrow(const float* __restrict__ A, const float* __restrict__ x, long n, int H,
+                                                          float* __restrict__ part) {
+  __shared__ float red[EB];
+  const long r0 = (long)blockIdx.x * RS_ROWS;
+  const long r1 = r0 + RS_ROWS < n ? r0 + RS_ROWS : n;
+  for (int c = 0; c < H; ++c) {
+    float acc = 0.f;
+    for (long r = r0 + threadIdx.x; r < r1; r += EB) acc += x ? A[r * H + c] * x[r] : A[r * H + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int sft = EB / 2; sft > 0; sft >>= 1) {
+      if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(long)blockIdx.x * H + c] = red[0];
+    __syncthreads();
+  }
+}
+// dst[i] += sum_b part[b][i], fixed order
+__global__ __launch_bounds__(EB) void k_sum_parts(const float* __restrict__ part, int nparts, long len, float* __restrict__ dst) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i >= len) return;
+  float acc = 0.f;
+  for (int b = 0; b < nparts; ++b) acc += part[(long)b * len + i];
+  dst[i] += acc;
+}
+
+inline unsigned blocks(long n) { return (unsigned)((n + EB - 1) / EB); }
+
+}  // namespace
+
+struct VnLayered {
+  VnNet net{};
+  rocblas_handle handle = nullptr;
+  long sumH = 0;           // sum of H[0..L]
+  int hmax_all = 0;        // max of H[0..L]
+  // one workspace, carved per call
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  float* part = nullptr;   // partial sums of the row reductions
+  size_t part_elems = 0;
+};
+
+namespace {
+
+constexpr size_t WS_TARGET = (size_t)3 << 30;     // bytes of HBM the route may hold for its chunk buffers
+
+int ensure_ws(VnLayered* w, size_t bytes, char* err, size_t errlen) {
+  if (bytes <= w->ws_bytes) return 0;
+  if (w->ws) (void)hipFree(w->ws);
+  w->ws = nullptr; w->ws_bytes = 0;
+  LHIP(hipMalloc(&w->ws, bytes));
+  w->ws_bytes = bytes;
+  return 0;
+}
+
+int ensure_part(VnLayered* w, size_t elems, char* err, size_t errlen) {
+  if (elems <= w->part_elems) return 0;
+  if (w->part) (void)hipFree(w->part);
+  w->part = nullptr; w->part_elems = 0;
+  LHIP(hipMalloc((void**)&w->part, elems * sizeof(float)));
+  w->part_elems = elems;
+  return 0;
+}
+
+// dst[0..H) += sum over the n rows of A (n x H, row-major) weighted by x (or 1): two launches, fixed summation order
+int colsum_add(VnLayered* w, const float* A, const float* x, long n, int H, float* dst, hipStream_t s, char* err, size_t errlen) {
+  const int nb = (int)((n + RS_ROWS - 1) / RS_ROWS);
+  if (int rc = ensure_part(w, (size_t)nb * H, err, errlen)) return rc;
+  if (H >= 8) hipLaunchKernelGGL(k_colsum_part, dim3(nb, (H + 63) / 64), dim3(EB), 0, s, A, x, n, H, w->part);
+  else hipLaunchKernelGGL(k_colsum_part_narrow, dim3(nb), dim3(EB), 0, s, A, x, n, H, w->part);
+  LHIP(hipGetLastError());
+  hipLaunchKernelGGL(k_sum_parts, dim3(blocks(H)), dim3(EB), 0, s, w->part, nb, (long)H, dst);
+  LHIP(hipGetLastError());
+  return 0;
+}
+
+// dW (Hin x Hout, row-major) += A^T Zbar over M stacked rows.  The rows are cut into groups; one strided-batched GEMM
+// gives a partial product per group (parallelism = groups x output tiles instead of output tiles), a fixed-order sum
+// adds them up.
+int wgrad_add(VnLayered* w, const float* A, const float* Zbar, long M, int Hin, int Hout, float* dW, hipStream_t s, char* err,
+              size_t errlen) {
+  const long tiles = ((Hin + 127) / 128) * (long)((Hout + 127) / 128);
+  long rows = 8192;                                   // rows per group: about 1 000 workgroups for small layers ...
+  while (rows < M && tiles * ((M + rows - 1) / rows) > 2048) rows *= 2;   // ... and no more partials than needed for big ones
+  const int G = (int)(M / rows);                      // full groups; the ragged rest is one more GEMM
+  const long rest = M - (long)G * rows;
+  const int np = G + (rest > 0 ? 1 : 0);
+  const long len = (long)Hin * Hout;
+  if (int rc = ensure_part(w, (size_t)np * len, err, errlen)) return rc;
+  const float one = 1.f, zero = 0.f;
+  // column-major: P_g'(Hout x Hin) = Zbar_g'(Hout x rows) A_g'(Hin x rows)^T
+  if (G > 0)
+    LBLAS(g_blas.sgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rows, &one,
+                                       Zbar, Hout, rows * Hout, A, Hin, rows * Hin, &zero, w->part, Hout, len, G));
+  if (rest > 0)
+    LBLAS(g_blas.sgemm(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rest, &one,
+                       Zbar + (long)G * rows * Hout, Hout, A + (long)G * rows * Hin, Hin, &zero, w->part + (long)G * len, Hout));
+  hipLaunchKernelGGL(k_sum_parts, dim3(blocks(len)), dim3(EB), 0, s, w->part, np, len, dW);
+  LHIP(hipGetLastError());
+  return 0;
+}
+
+// rows per chunk for `per_row` elements of sizeof(T) each
+template <typename T>
+long chunk_rows(long n, long per_row) {
+  long c = (long)(WS_TARGET / ((size_t)per_row * sizeof(T)));
+  if (c < 1024) c = 1024;
+  // the stacked GEMMs take S*c rows in a 32-bit rocblas_int
+  if (c > (1l << 26)) c = 1l << 26;
+  return c < n ? c : n;
+}
+
+// Z(S n x Hout) = A(S n x Hin) W(Hin x Hout), all row-major  ==  column-major  Z'(Hout x M) = W'(Hout x Hin) A'(Hin x M)
+template <typename T>
+rocblas_status gemm_fwd(rocblas_handle h, long M, int Hin, int Hout, const T* A, const T* W, T* Z) {
+  const T one = T(1), zero = T(0);
+  return BlasT<T>::gemm(h, rocblas_operation_none, rocblas_operation_none, Hout, (int)M, Hin, &one, W, Hout, A, Hin, &zero, Z, Hout);
+}
+
+}  // namespace
+
+int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errlen) {
+  *out = nullptr;
+  if (int rc = load_blas(err, errlen)) return rc;
+  VnLayered* w = new VnLayered();
+  w->net = net;
+  for (int l = 0; l <= net.L; ++l) {
+    w->sumH += net.H[l];
+    if (net.H[l] > w->hmax_all) w->hmax_all = net.H[l];
+  }
+  rocblas_status st = g_blas.create_handle(&w->handle);
+  if (st != rocblas_status_success) {
+    delete w;
+    return lfail(err, errlen, "rocblas_create_handle: %s", g_blas.status_to_string(st));
+  }
+  // no atomics: the weight-gradient GEMMs reduce over millions of rows and must give the same bits on every run
+  (void)g_blas.set_atomics_mode(w->handle, rocblas_atomics_not_allowed);
+  *out = w;
+  return 0;
+}
+
+void vn_layered_destroy(VnLayered* w) {
+  if (!w) return;
+  if (w->handle) (void)g_blas.destroy_handle(w->handle);
+  if (w->ws) (void)hipFree(w->ws);
+  if (w->part) (void)hipFree(w->part);
+  delete w;
+}
+
+namespace {
+
+// Forward of one chunk.  act[l] (l = 0..L): [S][c][H_l] stacked (a, ad).
+int chunk_forward(VnLayered* w, const float* theta, const float* X, const float* G, long c, int S, float** act, hipStream_t s,
+                  char* err, size_t errlen) {
+  const VnNet& net = w->net;
+  hipLaunchKernelGGL(k_pack_train, dim3(blocks(c * net.d_in)), dim3(EB), 0, s, X, G, c, net.d_in, net.dim, S, act[0]);
+  LHIP(hipGetLastError());
+  for (int l = 1; l <= net.L; ++l) {
+    LBLAS(gemm_fwd<float>(w->handle, (long)S * c, net.H[l - 1], net.H[l], act[l - 1], theta + net.woff[l], act[l]));
+    hipLaunchKernelGGL(k_act_train, dim3(blocks(c * net.H[l])), dim3(EB), 0, s, act[l], theta + net.boff[l], c, net.H[l], S, net.act);
+    LHIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// carve the chunk buffers out of the workspace; returns elements used
+long carve(VnLayered* w, long c, int S, bool train, float** act, float** adj) {
+  const VnNet& net = w->net;
+  float* p = (float*)w->ws;
+  long used = 0;
+  for (int l = 0; l <= net.L; ++l) {
+    act[l] = p ? p + used : nullptr;
+    used += (long)S * c * net.H[l];
+  }
+  if (train) {
+    for (int i = 0; i < 2; ++i) {
+      adj[i] = p ? p + used : nullptr;
+      used += (long)S * c * w->hmax_all;
+    }
+  }
+  return used;
+}
+
+}  // namespace
+
+int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipStream_t s, char* err, size_t errlen) {
+  if (seg.n <= 0) return 0;
+  const VnNet& net = w->net;
+  const int S = (seg.G && seg.ud) ? 2 : 1;
+  LBLAS(g_blas.set_stream(w->handle, s));
+  const long c = chunk_rows<float>(seg.n, (long)S * w->sumH);
+  float *act[VN_MAX_LAYERS + 2], *adj[2];
+  if (int rc = ensure_ws(w, (size_t)carve(w, c, S, false, act, adj) * sizeof(float), err, errlen)) return rc;
+  carve(w, c, S, false, act, adj);
+  const int HL = net.H[net.L];
+  for (long r0 = 0; r0 < seg.n; r0 += c) {
+    const long cn = (seg.n - r0 < c) ? seg.n - r0 : c;
+    // the stacked layout depends on the chunk length: re-carve for the (shorter) last chunk
+    carve(w, cn, S, false, act, adj);
+    if (int rc = chunk_forward(w, theta, seg.X + r0 * net.d_in, S == 2 ? seg.G + r0 * net.dim : nullptr, cn, S, act, s, err, errlen))
+      return rc;
+    // u = a_L w_o + b_o,  ud = ad_L w_o
+    const unsigned rb = blocks(cn * 16) < 8192u ? blocks(cn * 16) : 8192u;
+    hipLaunchKernelGGL(k_rowdot, dim3(rb), dim3(EB), 0, s, act[net.L], theta + net.woff[net.L + 1], theta + net.boff[net.L + 1], cn, HL,
+                       seg.u + r0);
+    LHIP(hipGetLastError());
+    if (S == 2) {
+      hipLaunchKernelGGL(k_rowdot, dim3(rb), dim3(EB), 0, s, act[net.L] + cn * HL, theta + net.woff[net.L + 1], (const float*)nullptr,
+                         cn, HL, seg.ud + r0);
+      LHIP(hipGetLastError());
+    }
+  }
+  return 0;
+}
+
+int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, float* grad, hipStream_t s, char* err,
+                        size_t errlen) {
+  if (seg.n <= 0) return 0;
+  const VnNet& net = w->net;
+  const int S = (seg.G && seg.udbar) ? 2 : 1;
+  LBLAS(g_blas.set_stream(w->handle, s));
+  const long per_row = (long)S * w->sumH + 2l * S * w->hmax_all;
+  const long c = chunk_rows<float>(seg.n, per_row);
+  float *act[VN_MAX_LAYERS + 2], *adj[2];
+  if (int rc = ensure_ws(w, (size_t)carve(w, c, S, true, act, adj) * sizeof(float), err, errlen)) return rc;
+  const float one = 1.f, zero = 0.f;
+  const int L = net.L, HL = net.H[L];
+  for (long r0 = 0; r0 < seg.n; r0 += c) {
+    const long cn = (seg.n - r0 < c) ? seg.n - r0 : c;
+    carve(w, cn, S, true, act, adj);
+    if (int rc = chunk_forward(w, theta, seg.X + r0 * net.d_in, S == 2 ? seg.G + r0 * net.dim : nullptr, cn, S, act, s, err, errlen))
+      return rc;
+    const float* ubar = seg.ubar + r0;
+    const float* udbar = S == 2 ? seg.udbar + r0 : nullptr;
+    // output layer: dw_o += a_L^T ubar (+ ad_L^T udbar), db_o += sum ubar
+    if (int rc = colsum_add(w, act[L], ubar, cn, HL, grad + net.woff[L + 1], s, err, errlen)) return rc;
+    if (S == 2)
+      if (int rc = colsum_add(w, act[L] + cn * HL, udbar, cn, HL, grad + net.woff[L + 1], s, err, errlen)) return rc;
+    if (int rc = colsum_add(w, ubar, nullptr, cn, 1, grad + net.boff[L + 1], s, err, errlen)) return rc;
+    float* cur = adj[0];
+    float* nxt = adj[1];
+    hipLaunchKernelGGL(k_seed_outer, dim3(blocks(cn * HL)), dim3(EB), 0, s, ubar, udbar, theta + net.woff[L + 1], cn, HL, S, cur);
+    LHIP(hipGetLastError());
+    for (int l = L; l >= 1; --l) {
+      const int Hin = net.H[l - 1], Hout = net.H[l];
+      const long M = (long)S * cn;
+      hipLaunchKernelGGL(k_act_bwd, dim3(blocks(cn * Hout)), dim3(EB), 0, s, cur, act[l], cn, Hout, S, net.act);
+      LHIP(hipGetLastError());
+      // db_l += sum over the value-stream rows of zbar;  dW_l += [a; ad]^T [zbar; zdbar]
+      if (int rc = colsum_add(w, cur, nullptr, cn, Hout, grad + net.boff[l], s, err, errlen)) return rc;
+      if (int rc = wgrad_add(w, act[l - 1], cur, M, Hin, Hout, grad + net.woff[l], s, err, errlen)) return rc;
+      if (l > 1) {
+        // [abar; adbar]_{l-1} (M x Hin) = Zbar (M x Hout) W_l^T  ==  column-major (Hin x M) = W'(Hout x Hin)^T Zbar'(Hout x M)
+        LBLAS(BlasT<float>::gemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, Hin, (int)M, Hout, &one,
+                                 theta + net.woff[l], Hout, cur, Hout, &zero, nxt, Hin));
+        float* t = cur; cur = nxt; nxt = t;
+      }
+    }
+  }
+  return 0;
+}
+
+namespace {
+
+template <typename T>
+int pointwise_streams(VnLayered* w, const T* theta, const T* X, long n, int S, int nd1, int dim, const T* diff, const T* vel,
+                      const T* src, const T* ddx, int td, T* u, T* res, hipStream_t s, char* err, size_t errlen) {
+  if (n <= 0) return 0;
+  const VnNet& net = w->net;
+  LBLAS(g_blas.set_stream(w->handle, s));
+  // two ping-pong buffers of S x c x hmax and the S x c output vector
+  const long per_row = 2l * S * w->hmax_all + S;
+  const long c = chunk_rows<T>(n, per_row);
+  if (int rc = ensure_ws(w, (size_t)per_row * c * sizeof(T), err, errlen)) return rc;
+  T* buf0 = (T*)w->ws;
+  T* buf1 = buf0 + (long)S * c * w->hmax_all;
+  T* y = buf1 + (long)S * c * w->hmax_all;
+  const T one = T(1), zero = T(0);
+  const int HL = net.H[net.L];
+  for (long r0 = 0; r0 < n; r0 += c) {
+    const long cn = (n - r0 < c) ? n - r0 : c;
+    T* cur = buf0;
+    T* nxt = buf1;
+    if (res) {
+      hipLaunchKernelGGL(k_pack_res<T>, dim3(blocks(cn * net.d_in)), dim3(EB), 0, s, X + r0 * net.d_in, cn, net.d_in, nd1, S, cur);
+      LHIP(hipGetLastError());
+    }
+    for (int l = 1; l <= net.L; ++l) {
+      const T* in = (l == 1 && !res) ? X + r0 * net.d_in : cur;
+      LBLAS(gemm_fwd<T>(w->handle, (long)S * cn, net.H[l - 1], net.H[l], in, theta + net.woff[l], nxt));
+      hipLaunchKernelGGL(k_act_res<T>, dim3(blocks(cn * net.H[l])), dim3(EB), 0, s, nxt, theta + net.boff[l], cn, net.H[l],
+                         res ? nd1 : 0, res ? dim : 0, net.act);
+      LHIP(hipGetLastError());
+      T* t = cur; cur = nxt; nxt = t;
+    }
+    if (!res) {
+      hipLaunchKernelGGL(k_fill_from<T>, dim3(blocks(cn)), dim3(EB), 0, s, u + r0, cn, theta + net.boff[net.L + 1]);
+      LHIP(hipGetLastError());
+      LBLAS(BlasT<T>::gemv(w->handle, rocblas_operation_transpose, HL, (int)cn, &one, cur, HL, theta + net.woff[net.L + 1], &one, u + r0));
+    } else {
+      LBLAS(BlasT<T>::gemv(w->handle, rocblas_operation_transpose, HL, (int)(S * cn), &one, cur, HL, theta + net.woff[net.L + 1], &zero, y));
+      hipLaunchKernelGGL(k_res_combine<T>, dim3(blocks(cn)), dim3(EB), 0, s, y, theta + net.boff[net.L + 1], diff + r0,
+                         vel + r0 * dim, src ? src + r0 : nullptr, ddx ? ddx + r0 * dim : nullptr, td, cn, dim, nd1,
+                         u ? u + r0 : nullptr, res + r0);
+      LHIP(hipGetLastError());
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+int vn_layered_forward_f64(VnLayered* w, const double* theta, const double* X, long n, double* u, hipStream_t s, char* err,
+                           size_t errlen) {
+  return pointwise_streams<double>(w, theta, X, n, 1, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, u, nullptr, s, err, errlen);
+}
+
+int vn_layered_residual_f32(VnLayered* w, const float* theta, const float* X, const float* diff, const float* vel,
+                            const float* src, const float* ddx, int td, long n, float* u, float* res, hipStream_t s, char* err,
+                            size_t errlen) {
+  const int dim = w->net.dim, nd1 = dim + (td ? 1 : 0);
+  return pointwise_streams<float>(w, theta, X, n, 1 + nd1 + dim, nd1, dim, diff, vel, src, ddx, td, u, res, s, err, errlen);
+}
+
+int vn_layered_residual_f64(VnLayered* w, const double* theta, const double* X, const double* diff, const double* vel,
+                            const double* src, const double* ddx, int td, long n, double* u, double* res, hipStream_t s,
+                            char* err, size_t errlen) {
+  const int dim = w->net.dim, nd1 = dim + (td ? 1 : 0);
+  return pointwise_streams<double>(w, theta, X, n, 1 + nd1 + dim, nd1, dim, diff, vel, src, ddx, td, u, res, s, err, errlen);
+}

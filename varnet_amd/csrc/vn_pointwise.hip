@@ -8,7 +8,7 @@
 namespace {
 
 constexpr int PT = 64;   // threads per workgroup
-constexpr int HM = VN_MAX_WIDTH > VN_MAX_DIN ? VN_MAX_WIDTH : VN_MAX_DIN;
+constexpr int HM = VN_KMAX_WIDTH > VN_KMAX_DIN ? VN_KMAX_WIDTH : VN_KMAX_DIN;   // per-thread arrays: kernel range only
 
 template <typename T> __device__ __forceinline__ T sig(T z, int act);
 template <> __device__ __forceinline__ float sig<float>(float z, int act) {

@@ -15,10 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VARNET_HIP_LIB selects a diagnostic build of the same ABI (tools/): never a different backend
 LIB_PATH = os.environ.get('VARNET_HIP_LIB', os.path.join(_HERE, 'libvarnet_hip.so'))
 
-VN_MAX_LAYERS = 6
-VN_MAX_WIDTH = 64
-VN_MAX_DIN = 8
-VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED, VN_KERNEL_FUSED16 = 0, 1, 2, 3
+VN_MAX_LAYERS = 16          # what a vn_config may describe (include/varnet_hip.h); beyond the kernels' own range
+VN_MAX_WIDTH = 2048         # (6 layers x 64 wide, 8 inputs) the engine runs layer by layer (VN_KERNEL_LAYERED)
+VN_MAX_DIN = 32
+VN_KMAX_LAYERS, VN_KMAX_WIDTH, VN_KMAX_DIN = 6, 64, 8
+VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED, VN_KERNEL_FUSED16, VN_KERNEL_LAYERED = 0, 1, 2, 3, 4
 VN_COMM_ID_BYTES = 128
 
 
@@ -138,8 +139,9 @@ class VNEngine:
             raise ValueError('unknown optimizer requested!')           # TFModel.py:133-134
         if learning_rate < 0.0:
             raise ValueError('learning rate must be positive!')        # TFModel.py:130
-        if len(layerWidth) > VN_MAX_LAYERS or max(layerWidth) > VN_MAX_WIDTH:
-            raise ValueError('network exceeds engine limits (%d layers x %d)' % (VN_MAX_LAYERS, VN_MAX_WIDTH))
+        if len(layerWidth) > VN_MAX_LAYERS or max(layerWidth) > VN_MAX_WIDTH or inpDim > VN_MAX_DIN:
+            raise ValueError('network exceeds engine limits (%d layers x %d, %d inputs)'
+                             % (VN_MAX_LAYERS, VN_MAX_WIDTH, VN_MAX_DIN))
         cfg = VnConfig()
         cfg.dim, cfg.d_in, cfg.n_layers = dim, inpDim, len(layerWidth)
         for i, wd in enumerate(layerWidth):
