@@ -49,7 +49,10 @@ enum {
   VN_ECOMM = 6     /* an RCCL call failed                                      */
 };
 
-enum { VN_ACT_SIGMOID = 0, VN_ACT_TANH = 1 };   /* activationFun options of the constructor (VarNet.py:97) */
+/* activationFun options of the constructor (VarNet.py:97).  VN_ACT_PER_LAYER: vn_config.layer_act holds one of the two
+ * per hidden layer (the reference accepts a list, TFModel.py:113-119); a list with different entries runs on the
+ * layer-by-layer route, the kernels take one activation for all hidden layers. */
+enum { VN_ACT_SIGMOID = 0, VN_ACT_TANH = 1, VN_ACT_PER_LAYER = 2 };
 enum { VN_OPT_ADAM = 0, VN_OPT_RMSPROP = 1 };   /* tf.train.AdamOptimizer / RMSPropOptimizer (TFModel.py:183-186) */
 /* Kernel families.  AUTO picks the 8-wave fused kernel where it is instantiated: uniform or ragged hidden widths
  * <= 50 with 1..6 layers, <= 64 with 1..5 layers, d_in <= 8, sigmoid or tanh; integ_num <= 128 in one launch, larger
@@ -71,7 +74,7 @@ typedef struct vn_config {
   int32_t d_in;                     /* network inputs (VarNet.py:174-180)                  */
   int32_t n_layers;                 /* hidden layers L                                     */
   int32_t widths[VN_MAX_LAYERS];    /* layerWidth                                          */
-  int32_t activation;               /* VN_ACT_SIGMOID | VN_ACT_TANH, all hidden layers alike */
+  int32_t activation;               /* VN_ACT_SIGMOID | VN_ACT_TANH for all hidden layers, or VN_ACT_PER_LAYER */
   int32_t integ_num;                /* quadrature points per test function (FiniteElement.py:416) */
   int32_t time_dependent;           /* TFModel.py:537,646,655                              */
   int32_t has_source;               /* lossOpt['isSource']  (TFModel.py:656)               */
@@ -80,11 +83,12 @@ typedef struct vn_config {
   int32_t optimizer;                /* VN_OPT_ADAM | VN_OPT_RMSPROP (TFModel.py:183-186)   */
   int32_t kernel;                   /* VN_KERNEL_*                                         */
   double  lr, beta1, beta2, eps;    /* TF-1 Adam defaults 1e-3, .9, .999, 1e-8             */
+  int32_t layer_act[VN_MAX_LAYERS]; /* with VN_ACT_PER_LAYER: VN_ACT_SIGMOID | VN_ACT_TANH of hidden layer i */
 } vn_config;
 
 const char* vn_last_error(void);
 int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_kernel_path, vn_profile_comm;
-                                * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, VN_KERNEL_LAYERED */
+                                * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, layer_act, VN_KERNEL_LAYERED */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
 int vn_create(const vn_config* cfg, vn_engine** out);

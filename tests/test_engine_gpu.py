@@ -349,7 +349,7 @@ def test_engine_argument_errors():
     with pytest.raises(ValueError):
         VNEngine(1, 2, [5], True, 16, activationFun='relu')          # options: 'sigmoid' or 'tanh' (VarNet.py:97)
     with pytest.raises(ValueError):
-        VNEngine(1, 2, [5, 5], True, 16, activationFun=['tanh', 'sigmoid'])
+        VNEngine(1, 2, [5, 5], True, 16, activationFun=['tanh', 'sigmoid', 'tanh'])   # list length != depth (TFModel.py:117)
     with pytest.raises(ValueError):
         VNEngine(1, 2, [5000], True, 16)                             # beyond what a vn_config can describe
     with pytest.raises(VNError):

@@ -181,3 +181,53 @@ def test_varnet_constructor_accepts_a_wide_deep_net(tmp_path):
     r64, _, _, _ = vn.residual(fp64=True)
     r32, _, _, _ = vn.residual()
     assert np.isfinite(r64) and abs(r64 - r32) <= 1e-3 * abs(r64)
+
+
+@pytest.mark.parametrize('widths,acts', [([20, 30, 20], ['tanh', 'sigmoid', 'tanh']), ([100, 80], ['sigmoid', 'tanh'])])
+def test_per_layer_activation_lists(widths, acts):
+    """activationFun as one entry per hidden layer (TFModel.py:113-119): entries that differ run layer by layer;
+    loss, gradient, forward and fp64 residual against the oracle with the same list."""
+    d_in, dim, q, n_k, nB, bDof = 3, 2, 64, 21, 30, 12
+    d = synth(3, d_in, dim, widths, q, n_k, nB, bDof, True, False, False)
+    from varnet_amd.engine import VNEngine
+    eng = VNEngine(dim, d_in, widths, True, q, isSource=True, activationFun=acts)
+    assert eng.kernel_path()[0] == LAYERED
+    eng.init_params(seed=3)
+    flat = eng.get_params() + 0.05 * np.random.default_rng(5).standard_normal(eng.P).astype(np.float32)
+    eng.set_params(flat)
+    eng.set_fe_table(d['N1'], d['dNt1'], None)
+    eng.set_interior(0, d['Input'], d['gcoef'], d['source'], n_k=n_k, detJ=d['detJ'])
+    eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+    eng.set_weights(d['w'])
+    f64 = lambda a: None if a is None else a.astype(np.float64)
+    ref, gref = og.loss_and_grad(
+        flat.astype(np.float64), d_in, widths, torch.float64, Input=f64(d['Input']), gcoef=f64(d['gcoef']),
+        source=f64(d['source']), N=f64(d['N']), dNt=f64(d['dNt']), integW=None, intShape=[n_k, q],
+        detJ=float(d['detJ']), detJvec=False, biInput=f64(d['biInput']), biLabel=f64(d['biLabel']), bDof=bDof,
+        biDimVal=2.0, w=d['w'], dim=dim, time_dependent=True, is_source=True, integWflag=False, activation=acts)
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy()
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
+    assert np.max(np.abs(g[:eng.P] - gref)) / np.max(np.abs(gref)) <= GRAD_RTOL
+    rng = np.random.default_rng(0)
+    n = 500
+    X = rng.uniform(-1, 1, (n, d_in))
+    diff = rng.uniform(0.1, 1, (n, 1)); vel = rng.standard_normal((n, dim))
+    src = rng.standard_normal((n, 1)); ddx = rng.standard_normal((n, dim))
+    uref, rref = og.residual(flat.astype(np.float64), d_in, widths, torch.float64, X, diff, vel, src, ddx, dim, True,
+                             activation=acts)
+    u, r = eng.residual(X, diff, vel, src, ddx, fp64=True)
+    assert np.max(np.abs(r.cpu().numpy() - rref[:, 0])) < 1e-11 * max(1, np.max(np.abs(rref)))
+    assert np.max(np.abs(u.cpu().numpy() - uref[:, 0])) < 1e-13
+    eng.close()
+    # a list whose entries agree is the uniform case and stays on the kernels
+    eng = VNEngine(dim, d_in, [20, 30, 20], True, q, activationFun=['tanh'] * 3)
+    assert eng.kernel_path()[0] == 3
+    eng.close()
+    eng = VNEngine(dim, d_in, [20, 30, 20], True, q, activationFun=['tanh'])
+    assert eng.kernel_path()[0] == 3
+    eng.close()
+    with pytest.raises(ValueError):
+        VNEngine(dim, d_in, [20, 30, 20], True, q, activationFun=['tanh', 'sigmoid'])     # length != depth

@@ -92,6 +92,11 @@ def test_tanh_training_through_varnet(tmp_path):
     uref = og.forward(flat, 2, [20, 20, 20], torch.float64, vn.fixData.uniform_input, activation='tanh')
     assert np.max(np.abs(vn.evaluate() - uref)) < 5e-6
     assert 'tanh' in open(str(tmp_path / 'caseData.txt')).read()
-    with pytest.raises(ValueError):
-        VarNet(pde, layerWidth=[8, 8], activationFun=['tanh', 'sigmoid'], discNum=5, bDiscNum=None, tDiscNum=6)
+    with pytest.raises(ValueError):          # 'activation function list is incompatible with number of layers!' (TFModel.py:117)
+        VarNet(pde, layerWidth=[8, 8], activationFun=['tanh', 'sigmoid', 'tanh'], discNum=5, bDiscNum=None, tDiscNum=6)
     vn.engine.close()
+    # one entry per layer with different entries is legal in the reference: it trains on the layer-by-layer route
+    vm = VarNet(pde, layerWidth=[8, 8], activationFun=['tanh', 'sigmoid'], discNum=5, bDiscNum=None, tDiscNum=6)
+    rm = vm.train(str(tmp_path / 'mixed'), weight=[10., 10., 1.], epochNum=20, saveFreq=10, verbose=False)
+    assert vm.engine.kernel_path()[0] == 4 and np.isfinite(rm.lossAll).all()
+    vm.engine.close()

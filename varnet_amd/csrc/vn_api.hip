@@ -129,13 +129,12 @@ int build_net(const vn_config& c, VnNet& net) {
   if (c.d_in < 1 || c.d_in > VN_MAX_DIN) return fail(VN_EINVAL, "d_in=%d outside [1,%d]", c.d_in, VN_MAX_DIN);
   if (c.dim < 1 || c.dim > c.d_in) return fail(VN_EINVAL, "dim=%d must be in [1,d_in]", c.dim);
   if (c.integ_num < 1) return fail(VN_EINVAL, "integ_num must be positive");
-  if (c.activation != VN_ACT_SIGMOID && c.activation != VN_ACT_TANH)
+  if (c.activation != VN_ACT_SIGMOID && c.activation != VN_ACT_TANH && c.activation != VN_ACT_PER_LAYER)
     return fail(VN_EUNSUPPORTED, "activation must be sigmoid or tanh (VarNet.py:97)");
   if (c.optimizer != VN_OPT_ADAM && c.optimizer != VN_OPT_RMSPROP) return fail(VN_EINVAL, "unknown optimizer requested!");
   if (c.lr < 0.0) return fail(VN_EINVAL, "learning rate must be positive!");  // TFModel.py:130
   memset(&net, 0, sizeof net);
   net.d_in = c.d_in;
-  net.act = c.activation;
   net.dim = c.dim;
   net.L = c.n_layers;
   net.H[0] = c.d_in;
@@ -152,6 +151,15 @@ int build_net(const vn_config& c, VnNet& net) {
   }
   net.P = off;
   net.hmax = hmax;
+  // per-layer list (TFModel.py:113-119): a list whose entries agree is the uniform case
+  bool mixed = false;
+  for (int l = 1; l <= net.L; ++l) {
+    const int a = (c.activation == VN_ACT_PER_LAYER) ? c.layer_act[l - 1] : c.activation;
+    if (a != VN_ACT_SIGMOID && a != VN_ACT_TANH) return fail(VN_EUNSUPPORTED, "activation must be sigmoid or tanh (VarNet.py:97)");
+    net.actl[l] = a;
+    if (a != net.actl[1]) mixed = true;
+  }
+  net.act = mixed ? VN_ACT_PER_LAYER : net.actl[1];
   return VN_OK;
 }
 
@@ -434,9 +442,10 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
   // no fused instantiation exists, go layer by layer (vn_layered.hip); VN_KERNEL_LAYERED forces that route.
   const bool in_range = vn_net_in_kernel_range(net);
   if (!in_range && cfg->kernel != VN_KERNEL_AUTO && cfg->kernel != VN_KERNEL_LAYERED)
-    return fail(VN_EUNSUPPORTED, "network (%d layers, widest %d, %d inputs) is outside the range of the requested kernel family "
-                "(<= %d layers, width <= %d, <= %d inputs): use VN_KERNEL_AUTO or VN_KERNEL_LAYERED",
-                net.L, net.hmax, net.d_in, VN_KMAX_LAYERS, VN_KMAX_WIDTH, VN_KMAX_DIN);
+    return fail(VN_EUNSUPPORTED, "network (%d layers, widest %d, %d inputs%s) is outside the range of the requested kernel family "
+                "(<= %d layers, width <= %d, <= %d inputs, one activation): use VN_KERNEL_AUTO or VN_KERNEL_LAYERED",
+                net.L, net.hmax, net.d_in, net.act == VN_ACT_PER_LAYER ? ", mixed activations" : "", VN_KMAX_LAYERS,
+                VN_KMAX_WIDTH, VN_KMAX_DIN);
   const bool fused_ok = in_range && cfg->kernel != VN_KERNEL_GENERIC && cfg->kernel != VN_KERNEL_FUSED &&
                         cfg->kernel != VN_KERNEL_LAYERED && vn_fused16_net_supported(net);
   bool use_layered = cfg->kernel == VN_KERNEL_LAYERED || !in_range;

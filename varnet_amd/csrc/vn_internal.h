@@ -9,7 +9,8 @@
 // the kernels themselves cover VN_KMAX_LAYERS x VN_KMAX_WIDTH (vn_net_in_kernel_range), the rest is vn_layered.hip.
 struct VnNet {
   int d_in, dim, L, P, hmax;
-  int act;                       // VN_ACT_SIGMOID | VN_ACT_TANH, uniform over the hidden layers
+  int act;                       // VN_ACT_SIGMOID | VN_ACT_TANH, uniform over the hidden layers; VN_ACT_PER_LAYER: see actl
+  int actl[VN_MAX_LAYERS + 2];   // activation of hidden layer l = 1..L (what vn_layered.hip reads)
   int H[VN_MAX_LAYERS + 2];
   int woff[VN_MAX_LAYERS + 2];   // offset of W_l (row-major [H[l-1], H[l]]) in the flat vector
   int boff[VN_MAX_LAYERS + 2];   // offset of b_l
@@ -46,7 +47,7 @@ struct VnSeedArgs {
 };
 
 inline bool vn_net_in_kernel_range(const VnNet& net) {
-  return net.L <= VN_KMAX_LAYERS && net.hmax <= VN_KMAX_WIDTH && net.d_in <= VN_KMAX_DIN;
+  return net.L <= VN_KMAX_LAYERS && net.hmax <= VN_KMAX_WIDTH && net.d_in <= VN_KMAX_DIN && net.act != VN_ACT_PER_LAYER;
 }
 
 // ---- generic (any width <= 64, any integ_num) kernels: vn_generic.hip -------------------

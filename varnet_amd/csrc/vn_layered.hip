@@ -444,7 +444,7 @@ int chunk_forward(VnLayered* w, const float* theta, const float* X, const float*
   LHIP(hipGetLastError());
   for (int l = 1; l <= net.L; ++l) {
     LBLAS(gemm_fwd<float>(w->handle, (long)S * c, net.H[l - 1], net.H[l], act[l - 1], theta + net.woff[l], act[l]));
-    hipLaunchKernelGGL(k_act_train, dim3(blocks(c * net.H[l])), dim3(EB), 0, s, act[l], theta + net.boff[l], c, net.H[l], S, net.act);
+    hipLaunchKernelGGL(k_act_train, dim3(blocks(c * net.H[l])), dim3(EB), 0, s, act[l], theta + net.boff[l], c, net.H[l], S, net.actl[l]);
     LHIP(hipGetLastError());
   }
   return 0;
@@ -531,7 +531,7 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
     for (int l = L; l >= 1; --l) {
       const int Hin = net.H[l - 1], Hout = net.H[l];
       const long M = (long)S * cn;
-      hipLaunchKernelGGL(k_act_bwd, dim3(blocks(cn * Hout)), dim3(EB), 0, s, cur, act[l], cn, Hout, S, net.act);
+      hipLaunchKernelGGL(k_act_bwd, dim3(blocks(cn * Hout)), dim3(EB), 0, s, cur, act[l], cn, Hout, S, net.actl[l]);
       LHIP(hipGetLastError());
       // db_l += sum over the value-stream rows of zbar;  dW_l += [a; ad]^T [zbar; zdbar]
       if (int rc = colsum_add(w, cur, nullptr, cn, Hout, grad + net.boff[l], s, err, errlen)) return rc;
@@ -576,7 +576,7 @@ int pointwise_streams(VnLayered* w, const T* theta, const T* X, long n, int S, i
       const T* in = (l == 1 && !res) ? X + r0 * net.d_in : cur;
       LBLAS(gemm_fwd<T>(w->handle, (long)S * cn, net.H[l - 1], net.H[l], in, theta + net.woff[l], nxt));
       hipLaunchKernelGGL(k_act_res<T>, dim3(blocks(cn * net.H[l])), dim3(EB), 0, s, nxt, theta + net.boff[l], cn, net.H[l],
-                         res ? nd1 : 0, res ? dim : 0, net.act);
+                         res ? nd1 : 0, res ? dim : 0, net.actl[l]);
       LHIP(hipGetLastError());
       T* t = cur; cur = nxt; nxt = t;
     }

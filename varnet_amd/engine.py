@@ -30,7 +30,7 @@ class VnConfig(C.Structure):
                 ('has_source', C.c_int32), ('has_integw', C.c_int32), ('device', C.c_int32),
                 ('optimizer', C.c_int32), ('kernel', C.c_int32),
                 ('lr', C.c_double), ('beta1', C.c_double), ('beta2', C.c_double),
-                ('eps', C.c_double)]
+                ('eps', C.c_double), ('layer_act', C.c_int32 * VN_MAX_LAYERS)]
 
 
 _lib = None
@@ -129,11 +129,18 @@ class VNEngine:
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise VNError('no GPU visible: the VarNet HIP engine has no CPU fallback')
-        act = activationFun[0] if isinstance(activationFun, (list, tuple)) else activationFun
-        if isinstance(activationFun, (list, tuple)) and any(a != act for a in activationFun):
-            raise ValueError('one activation function for all hidden layers: per-layer lists must be uniform')
-        act = str(act).lower()
-        if act not in ('sigmoid', 'tanh'):
+        # a name for all hidden layers, a one-entry list, or one entry per layer (TFModel.py:113-119)
+        depth = len(layerWidth)
+        if isinstance(activationFun, str):
+            acts = [activationFun] * depth
+        elif isinstance(activationFun, (list, tuple)) and len(activationFun) == 1:
+            acts = list(activationFun) * depth
+        elif len(activationFun) != depth:
+            raise ValueError('activation function list is incompatible with number of layers!')
+        else:
+            acts = list(activationFun)
+        acts = [str(a).lower() for a in acts]
+        if any(a not in ('sigmoid', 'tanh') for a in acts):
             raise ValueError('activation function must be \'sigmoid\' or \'tanh\' (VarNet.py:97)')
         if optimizer_name.lower() not in ('adam', 'rmsprop'):
             raise ValueError('unknown optimizer requested!')           # TFModel.py:133-134
@@ -146,7 +153,12 @@ class VNEngine:
         cfg.dim, cfg.d_in, cfg.n_layers = dim, inpDim, len(layerWidth)
         for i, wd in enumerate(layerWidth):
             cfg.widths[i] = int(wd)
-        cfg.activation = 1 if act == 'tanh' else 0
+        if all(a == acts[0] for a in acts):
+            cfg.activation = 1 if acts[0] == 'tanh' else 0
+        else:                                        # different entries: the engine runs such a net layer by layer
+            cfg.activation = 2
+        for i, a in enumerate(acts):
+            cfg.layer_act[i] = 1 if a == 'tanh' else 0
         cfg.integ_num = int(integNum)
         cfg.time_dependent = int(bool(timeDependent))
         cfg.has_source = int(bool(isSource))
