@@ -469,7 +469,7 @@ class ManageTrainData:
         eng, q = self.vn.engine, self.integNum
         torch = eng.torch
         if self.shuffled:                         # one upload of the permutation per shuffle, not one per block
-            perm_dev = torch.as_tensor(self.batchInd, device=eng.device, dtype=torch.long)
+            perm_dev = self._upload_perm(torch, eng.device)
             rows_all = (perm_dev[:, None] * q + torch.arange(q, device=eng.device)[None, :]).reshape(-1)
         for mb, d in enumerate(self.mor):
             if self.shuffled:                     # one gather per array and parameter batch; the blocks are views of it
@@ -492,6 +492,27 @@ class ManageTrainData:
                     ix = torch.as_tensor(perm, device=eng.device, dtype=torch.long)
                     eng.set_batch_bic(self.engine_batch(mb, bi), d['biInput'].index_select(0, ix),
                                       d['biLabel'].index_select(0, ix))
+
+    def _upload_perm(self, torch, device):
+        """Test-function permutation -> device.  On the GPU through one of two persistent pinned buffers and an
+        asynchronous copy (a pageable upload would wait for the running epoch; allocating pinned memory per shuffle costs
+        tens of ms); a buffer is rewritten only after the event behind its last copy has completed."""
+        if device.type != 'cuda':
+            return torch.as_tensor(self.batchInd, device=device, dtype=torch.long)
+        if not hasattr(self, '_pin'):
+            n = len(self.batchInd)
+            self._pin = [torch.empty(n, dtype=torch.long).pin_memory() for _ in range(2)]
+            self._pin_ev = [None, None]
+            self._pin_i = 0
+        i = self._pin_i = 1 - self._pin_i
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()
+        self._pin[i].numpy()[:] = self.batchInd
+        out = self._pin[i].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._pin_ev[i] = ev
+        return out
 
     def shuffleTrainData(self):
         """
@@ -1165,6 +1186,13 @@ class VarNet:
                 for mb in range(fd.MORbatchNum):
                     tData.select_mor(mb)
                     self.optimIter(tData, mb, loss_buf[i])
+            # The reshuffle that follows this epoch (VarNetUtility.py:957-1017 at VarNet.py:1354) is prepared BEFORE the
+            # loss is read back: its host work and gathers then run while the GPU is still busy with the epoch.  Safe:
+            # engine and gathers share one stream (old buffers are reused in stream order), the NumPy draws keep their
+            # order (no other consumer between the two points with uniform sampling).
+            early_shuffle = (nblk == 1 and smpScheme == 'uniform' and shuffleData and epoch % shuffleFreq == 0)
+            if early_shuffle:
+                tData.shuffleTrainData()
             losses = loss_buf[:nblk].tolist()                        # one host sync per block (per epoch when lossLag = 0)
             blk_time = time.perf_counter() - t0
             first = epoch
@@ -1172,7 +1200,7 @@ class VarNet:
                 epoch = first + i
                 current_loss = float(losses[i])
                 epoch_time += blk_time / nblk
-                if shuffleData and epoch % shuffleFreq == 0:
+                if shuffleData and epoch % shuffleFreq == 0 and not early_shuffle:
                     tData.shuffleTrainData()
 
                 if epoch % saveFreq == 0:
