@@ -47,9 +47,12 @@ def _setup(case, kernel, act='sigmoid'):
 @pytest.mark.parametrize('case', CASES)
 def test_loss_and_grad_parity_layered(case):
     d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec = case
-    in_range = len(widths) <= 6 and max(widths) <= 64 and d_in <= 8
-    eng, d, flat = _setup(case, LAYERED if in_range else 0)
+    eng, d, flat = _setup(case, LAYERED)
     assert eng.kernel_path()[0] == LAYERED
+    if len(widths) > 8 or max(widths) > 64 or d_in > 8 or (len(widths) > 6 and max(widths) > 32):
+        auto = _setup(case, 0)[0]                   # AUTO resolves to this route for nets beyond the kernels
+        assert auto.kernel_path()[0] == LAYERED
+        auto.close()
     ref, gref = oracle_eval(flat, d, d_in, dim, widths, integNum, n_k, bDof, source, integW, detJvec)
     out, lv = eng.eval_loss(0, lossVec=True)
     for got, key in zip(out, ['loss', 'BCloss', 'ICloss', 'varLoss']):
@@ -117,7 +120,7 @@ def test_layered_chunks_and_shard_additivity():
     eng.close()
 
 
-@pytest.mark.parametrize('widths,d_in,dim', [([100, 80], 3, 2), ([20] * 8, 2, 1), ([40, 40], 10, 3)])
+@pytest.mark.parametrize('widths,d_in,dim', [([100, 80], 3, 2), ([20] * 9, 2, 1), ([40, 40], 10, 3)])
 def test_forward_and_residual_parity_layered(widths, d_in, dim):
     rng = np.random.default_rng(0)
     n = 1000
@@ -231,3 +234,48 @@ def test_per_layer_activation_lists(widths, acts):
     eng.close()
     with pytest.raises(ValueError):
         VNEngine(dim, d_in, [20, 30, 20], True, q, activationFun=['tanh', 'sigmoid'])     # length != depth
+
+
+DEEP = [
+    # 7 and 8 hidden layers up to 32 wide are instantiated in the 8-wave fused kernel (no generic kernels for them)
+    (2, 1, [20] * 8,                     16,  40, 50, 30, False, False, False),
+    (3, 2, [32] * 7,                     64,  30, 50, 20, True,  False, True),
+    (3, 2, [32] * 8,                     36,  17, 12, 5,  True,  True,  False),
+    (3, 2, [20, 10, 20, 7, 20, 13, 20],  216, 5,  9,  4,  False, True,  False),   # two-pass route
+]
+
+
+@pytest.mark.parametrize('act', ['sigmoid', 'tanh'])
+@pytest.mark.parametrize('case', DEEP)
+def test_deep_narrow_nets_on_the_fused_kernel(case, act):
+    d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec = case
+    eng, d, flat = _setup(case, 0, act=act)
+    assert eng.kernel_path()[0] == 3                      # 8-wave fused kernel (two-pass for integNum 216)
+    f64 = lambda a: None if a is None else a.astype(np.float64)
+    ref, gref = og.loss_and_grad(
+        flat.astype(np.float64), d_in, widths, torch.float64, Input=f64(d['Input']), gcoef=f64(d['gcoef']),
+        source=f64(d['source']), N=f64(d['N']), dNt=f64(d['dNt']), integW=f64(d['integW']), intShape=[n_k, integNum],
+        detJ=(f64(d['detJ']) if detJvec else float(d['detJ'])), detJvec=detJvec, biInput=f64(d['biInput']),
+        biLabel=f64(d['biLabel']), bDof=bDof, biDimVal=2.0, w=d['w'], dim=dim, time_dependent=True,
+        is_source=source, integWflag=integW, activation=act)
+    out, lv = eng.eval_loss(0, lossVec=True)
+    for got, key in zip(out, ['loss', 'BCloss', 'ICloss', 'varLoss']):
+        assert abs(got - ref[key]) <= LOSS_RTOL * abs(ref[key]) + 1e-7, (key, got, ref[key])
+    lref = ref['lossVec'].reshape(-1)
+    assert np.max(np.abs(lv.cpu().numpy() - lref)) <= LVEC_RTOL * np.max(np.abs(lref))
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g = gb.cpu().numpy()
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
+    assert np.max(np.abs(g[:eng.P] - gref)) / np.max(np.abs(gref)) <= GRAD_RTOL
+    # forward / residual entry points of such an engine (pointwise kernels, fused forward)
+    rng = np.random.default_rng(0)
+    X = rng.uniform(-1, 1, (300, d_in))
+    uref = og.forward(flat.astype(np.float64), d_in, widths, torch.float64, X, activation=act)
+    assert np.max(np.abs(eng.forward(X.astype(np.float32)).cpu().numpy() - uref[:, 0])) < 3e-6 * max(1, np.max(np.abs(uref)))
+    assert np.max(np.abs(eng.forward_f64(X).cpu().numpy() - uref[:, 0])) < 1e-12
+    eng.close()
+    from varnet_amd.engine import VNEngine, VNError
+    with pytest.raises(VNError):
+        VNEngine(dim, d_in, widths, True, integNum, kernel=1)     # no generic kernels beyond 6 layers

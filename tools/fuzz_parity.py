@@ -48,7 +48,7 @@ for case in range(ncases):
     d = synth(1000 + case, d_in, dim, widths, q, n_k, nB, bDof, src, iw, djv)
     rows = bool(rng.random() < 0.2)
     grads, routes = [], []
-    in_range = L <= 6 and max(widths) <= 64 and d_in <= 8
+    in_range = L <= 6 and max(widths) <= 64 and d_in <= 8       # the generic kernels' range (AUTO also runs 7-8 x <= 32 fused)
     kernels = [4, 0]                            # the layer-by-layer route is the reference: it runs every case
     if in_range:
         try:

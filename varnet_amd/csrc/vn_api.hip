@@ -99,6 +99,7 @@ struct vn_engine {
   bool use_fused16 = false;
   VnOptArgs fuse;                    // optimizer step to fold into the next gradient reduction (kind -1: none)
   bool two_pass = false;             // fused kernel twice around the row-wise seed kernel (integ_num > 128)
+  bool fused_only = false;           // 7-8 hidden layers: no generic kernels for this net
   VnLayered* layered = nullptr;      // layer-by-layer route (networks outside the kernels' range, or forced)
   float* tp_losspart = nullptr; long tp_losspart_cap = 0;
   float* fused_losspart = nullptr;   // [ncu*3]
@@ -216,6 +217,7 @@ int fused_forward(vn_engine* h, const float* X, const float* G, long n, float* o
   f.w0 = f.w1 = f.w2 = 0.f;
   f.partial = h->partial; f.losspart = h->fused_losspart ? h->fused_losspart : h->tp_losspart; f.stamps = nullptr;
   f.mode = 1; f.dir = G ? -1 : 0; f.ostride = 1; f.out_u = out_u; f.out_ud = G ? out_ud : nullptr;
+  if (!f.losspart || !f.partial) return fail(VN_ESTATE, "fused forward without its work buffers");   // the kernel stores to both
   const long tiles = (n + 127) / 128;
   const int grid = (int)(tiles < h->ncu ? tiles : h->ncu);
   HIPCHK(vn_fused16_launch(f, grid, h->stream));
@@ -231,7 +233,7 @@ int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* l
     s1.X = bi_x(h, b); s1.G = nullptr; s1.u = h->ub; s1.ud = nullptr; s1.n = h->nB;
     LAYCHK(vn_layered_forward(h->layered, h->theta, s0, h->stream, lerr_, sizeof lerr_));
     LAYCHK(vn_layered_forward(h->layered, h->theta, s1, h->stream, lerr_, sizeof lerr_));
-  } else if (h->use_fused16 && h->has_fe && !with_seeds) {
+  } else if (((h->use_fused16 || h->two_pass) && h->has_fe && !with_seeds) || h->fused_only) {
     // splitLoss / trainWeight / the monitors: the fused kernel's forward-only mode for both row sets
     if (int rc = fused_forward(h, b.Input, b.gcoef, nT, h->u, h->ud)) return rc;
     if (int rc = fused_forward(h, bi_x(h, b), nullptr, h->nB, h->ub, nullptr)) return rc;
@@ -439,8 +441,14 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
   if (cfg->device < 0 || cfg->device >= ndev) return fail(VN_EINVAL, "requested processor %d is unavailable!", cfg->device);
   HIPCHK(hipSetDevice(cfg->device));
   // Route.  Networks outside the kernels' range (VN_KMAX_*), and nets whose generic-kernel tile does not fit LDS while
-  // no fused instantiation exists, go layer by layer (vn_layered.hip); VN_KERNEL_LAYERED forces that route.
-  const bool in_range = vn_net_in_kernel_range(net);
+  // no fused instantiation exists, go layer by layer (vn_layered.hip); VN_KERNEL_LAYERED forces that route.  One
+  // extension of the range: 7 and 8 hidden layers up to 32 wide are instantiated in the 8-wave fused kernel (deep,
+  // narrow nets); the generic kernels do not cover them, so every path of such an engine runs on the fused kernel.
+  const bool generic_range = vn_net_in_kernel_range(net);
+  const bool deep_fused = !generic_range && net.L <= 8 && net.hmax <= VN_KMAX_WIDTH && net.d_in <= VN_KMAX_DIN &&
+                          net.act != VN_ACT_PER_LAYER && vn_fused16_net_supported(net) &&
+                          (cfg->kernel == VN_KERNEL_AUTO || cfg->kernel == VN_KERNEL_FUSED16);
+  const bool in_range = generic_range || deep_fused;
   if (!in_range && cfg->kernel != VN_KERNEL_AUTO && cfg->kernel != VN_KERNEL_LAYERED)
     return fail(VN_EUNSUPPORTED, "network (%d layers, widest %d, %d inputs%s) is outside the range of the requested kernel family "
                 "(<= %d layers, width <= %d, <= %d inputs, one activation): use VN_KERNEL_AUTO or VN_KERNEL_LAYERED",
@@ -520,12 +528,15 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
                  (cfg->kernel != VN_KERNEL_GENERIC && vn_fused_supported(net, cfg->integ_num));
   h->two_pass = !h->use_fused && tp_ok && (cfg->kernel == VN_KERNEL_FUSED16 || cfg->kernel == VN_KERNEL_AUTO);
   if (h->two_pass) h->prof_name = "vn_fused16_kernel";
-  if (h->use_fused) {
+  h->fused_only = deep_fused;
+  if (h->use_fused || h->two_pass) {
+    // (the forward-only mode of the 8-wave kernel writes its per-workgroup loss partials here too: vn_forward and
+    // vn_eval_loss of a two-pass engine must not find it NULL)
     if (hipMalloc((void**)&h->fused_losspart, (size_t)h->ncu * 3 * sizeof(float)) != hipSuccess) {
       vn_destroy(h);
       return fail(VN_ENOMEM, "device allocation failed");
     }
-    h->prof_name = h->use_fused16 ? "vn_fused16_kernel" : "vn_fused_kernel";
+    h->prof_name = (h->use_fused16 || h->two_pass) ? "vn_fused16_kernel" : "vn_fused_kernel";
     if (hipMalloc((void**)&h->stamps, 8 * sizeof(unsigned long long)) == hipSuccess)
       (void)hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   }
@@ -920,7 +931,7 @@ int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
     LAYCHK(vn_layered_forward(h->layered, h->theta, sl, h->stream, lerr_, sizeof lerr_));
     return VN_OK;
   }
-  if (h->use_fused16) return fused_forward(h, X, nullptr, n, u, nullptr);
+  if (h->use_fused16 || h->two_pass || h->fused_only) return fused_forward(h, X, nullptr, n, u, nullptr);
   VnRows s0{}, s1{};
   s0.X = X; s0.G = nullptr; s0.u = u; s0.ud = nullptr; s0.n = n;
   HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));
