@@ -88,11 +88,15 @@ def test_layered_tanh_and_agreement_with_the_kernels():
     assert abs(a[-4] - b[-4]) <= 1e-5 * abs(a[-4])
 
 
-def test_layered_chunks_and_shard_additivity():
-    """1.28 M rows of a 3 x 96 net do not fit the route's workspace in one piece: the interior set is processed in several
+@pytest.mark.parametrize('keep', [True, False], ids=['kept-activations', 'recompute'])
+def test_layered_chunks_and_shard_additivity(keep, monkeypatch):
+    """Both forms of the reverse pass: reading the activations the forward kept in HBM, and recomputing them per chunk
+    (VN_LAYERED_NOKEEP=1, what happens when they do not fit).  1.28 M rows of a 3 x 96 net do not fit the route's workspace in one piece: the interior set is processed in several
     chunks, and the same set fed as two halves (chunked differently) sums to the same gradient and loss."""
     d_in, dim, widths, integNum, n_k, nB, bDof = 3, 2, [96, 96, 96], 64, 20000, 3000, 1700
     d = synth(7, d_in, dim, widths, integNum, n_k, nB, bDof)
+    if not keep:
+        monkeypatch.setenv('VN_LAYERED_NOKEEP', '1')
     from varnet_amd.engine import VNEngine
     eng = VNEngine(dim, d_in, widths, True, integNum, kernel=0)
     assert eng.kernel_path()[0] == LAYERED
@@ -118,6 +122,12 @@ def test_layered_chunks_and_shard_additivity():
     assert np.max(np.abs(s[:eng.P] - g[:eng.P])) <= 2e-5 * np.max(np.abs(g[:eng.P]))
     assert abs(s[eng.P] - g[eng.P]) <= 1e-5 * abs(g[eng.P])
     eng.close()
+    # the two forms of the reverse pass give the same bits (same chunks, same kernels, same order)
+    key = 'layered_chunks_grad'
+    prev = getattr(test_layered_chunks_and_shard_additivity, key, None)
+    if prev is not None:
+        assert np.array_equal(prev, g)
+    setattr(test_layered_chunks_and_shard_additivity, key, g)
 
 
 @pytest.mark.parametrize('widths,d_in,dim', [([100, 80], 3, 2), ([20] * 9, 2, 1), ([40, 40], 10, 3)])

@@ -33,10 +33,15 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(VN_EHIP, "%s: %s", #expr, hipGetErrorString(e_));   \
   } while (0)
 
+// (a failed call leaves earlier launches of the same step in flight: drain them before the caller unwinds)
 #define LAYCHK(call)                                                          \
   do {                                                                        \
     char lerr_[384] = "";                                                      \
-    if (call) return fail(VN_EHIP, "layer-by-layer route: %s", lerr_);        \
+    (void)hipGetLastError();                                                  \
+    if (call) {                                                               \
+      (void)hipStreamSynchronize(h->stream);                                  \
+      return fail(VN_EHIP, "layer-by-layer route: %s", lerr_);                \
+    }                                                                         \
   } while (0)
 
 struct Batch {
@@ -231,8 +236,8 @@ int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* l
     VnRows s0{}, s1{};
     s0.X = b.Input; s0.G = b.gcoef; s0.u = h->u; s0.ud = h->ud; s0.n = nT;
     s1.X = bi_x(h, b); s1.G = nullptr; s1.u = h->ub; s1.ud = nullptr; s1.n = h->nB;
-    LAYCHK(vn_layered_forward(h->layered, h->theta, s0, h->stream, lerr_, sizeof lerr_));
-    LAYCHK(vn_layered_forward(h->layered, h->theta, s1, h->stream, lerr_, sizeof lerr_));
+    LAYCHK(vn_layered_forward(h->layered, h->theta, s0, h->stream, lerr_, sizeof lerr_, with_seeds ? 0 : -1));
+    LAYCHK(vn_layered_forward(h->layered, h->theta, s1, h->stream, lerr_, sizeof lerr_, with_seeds ? 1 : -1));
   } else if (((h->use_fused16 || h->two_pass) && h->has_fe && !with_seeds) || h->fused_only) {
     // splitLoss / trainWeight / the monitors: the fused kernel's forward-only mode for both row sets
     if (int rc = fused_forward(h, b.Input, b.gcoef, nT, h->u, h->ud)) return rc;
@@ -827,8 +832,8 @@ int vn_grad(vn_engine* h, int32_t batch) {
       if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
       HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
     }
-    LAYCHK(vn_layered_backward(h->layered, h->theta, s0, h->partial, h->stream, lerr_, sizeof lerr_));
-    LAYCHK(vn_layered_backward(h->layered, h->theta, s1, h->partial, h->stream, lerr_, sizeof lerr_));
+    LAYCHK(vn_layered_backward(h->layered, h->theta, s0, h->partial, h->stream, lerr_, sizeof lerr_, 0));
+    LAYCHK(vn_layered_backward(h->layered, h->theta, s1, h->partial, h->stream, lerr_, sizeof lerr_, 1));
     if (lrec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
     const long nth = b.n_k > h->nB ? b.n_k : h->nB;
     const int lg = (int)(((nth > 0 ? nth : 1) + 255) / 256);

@@ -145,10 +145,13 @@ struct VnLayered;
 int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errlen);
 void vn_layered_destroy(VnLayered* w);
 // u (and ud along G, if both given) at seg.n rows
-int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipStream_t s, char* err, size_t errlen);
-// grad[0..P) += d loss / d theta from the rows of seg with seeds seg.ubar / seg.udbar (forward recomputed per chunk)
+// keep_slot >= 0: keep the activations of these rows for the vn_layered_backward call with the same slot (if they fit)
+int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipStream_t s, char* err, size_t errlen,
+                       int keep_slot = -1);
+// grad[0..P) += d loss / d theta from the rows of seg with seeds seg.ubar / seg.udbar (forward recomputed per chunk
+// unless the slot holds the activations of exactly these rows)
 int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, float* grad, hipStream_t s, char* err,
-                        size_t errlen);
+                        size_t errlen, int keep_slot = -1);
 int vn_layered_forward_f64(VnLayered* w, const double* theta, const double* X, long n, double* u, hipStream_t s,
                            char* err, size_t errlen);
 int vn_layered_residual_f32(VnLayered* w, const float* theta, const float* X, const float* diff, const float* vel,

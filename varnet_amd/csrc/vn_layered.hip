@@ -14,8 +14,10 @@
 // second derivative streams).  The GEMMs are rocBLAS (plain library GEMMs on huge-M, small-N/K shapes), resolved with
 // dlopen at first use so that libvarnet_hip.so neither links it nor loads it for networks the kernels cover; atomics
 // are switched off, so results are run-to-run reproducible.  Everything between the GEMMs is hand-written below.
-// Rows are processed in chunks sized to a fixed workspace; the forward is recomputed per chunk in the reverse pass
-// (the seeds need R_k of whole test functions first): 8 F_pt per interior point like the two-pass route.
+// Rows are processed in chunks sized to a fixed workspace.  The seeds need R_k of whole test functions first, so a gradient
+// evaluation is forward (all rows) -> seed kernel -> reverse (all rows): the forward KEEPS the activations of all rows in
+// HBM when they fit half of the free memory (6.4 M rows of a 3 x 256 net: 39 GB of the 288) and the reverse pass reads
+// them -- 6 F_pt per interior point; otherwise the reverse pass recomputes them per chunk (8 F_pt).
 #include "vn_internal.h"
 
 #include <dlfcn.h>
@@ -110,10 +112,27 @@ template <> struct BlasT<double> {
     hipError_t e_ = (expr);                                                                     \
     if (e_ != hipSuccess) return lfail(err, errlen, "%s: %s", #expr, hipGetErrorString(e_));    \
   } while (0)
+// rocBLAS probes its lazily loaded code objects with lookups that fail benignly ("Cannot find the function ...") and leave
+// the HIP runtime's sticky last-error set: it is cleared after every library call, or the next launch check of a kernel
+// of this file reports the library's stale error (seen as 'invalid argument' on the first 128-wide GEMM of a process).
 #define LBLAS(expr)                                                                             \
   do {                                                                                          \
     rocblas_status s_ = (expr);                                                                 \
+    (void)hipGetLastError();                                                                    \
     if (s_ != rocblas_status_success) return lfail(err, errlen, "%s: %s", #expr, g_blas.status_to_string(s_)); \
+  } while (0)
+
+// VN_LAYERED_TRACE=1: stage markers on stderr with a stream sync in front of each (diagnosis of a fault: which stage)
+static bool g_trace = [] { const char* t = getenv("VN_LAYERED_TRACE"); return t && *t && *t != '0'; }();
+#define LTRACE(s_, ...)                                                        \
+  do {                                                                         \
+    if (g_trace) {                                                             \
+      hipError_t te_ = hipStreamSynchronize(s_);                               \
+      fprintf(stderr, "[vn_layered] sync=%d ", (int)te_);                      \
+      fprintf(stderr, __VA_ARGS__);                                            \
+      fprintf(stderr, "\n");                                                   \
+      fflush(stderr);                                                          \
+    }                                                                          \
   } while (0)
 
 // ---- elementwise kernels -------------------------------------------------------------------------------------------
@@ -325,6 +344,15 @@ struct VnLayered {
   size_t ws_bytes = 0;
   float* part = nullptr;   // partial sums of the row reductions
   size_t part_elems = 0;
+  // Activations of a whole row set kept from the forward of a gradient evaluation to its reverse pass (slot 0: interior
+  // rows, slot 1: BC/IC rows): 288 GB of HBM hold them for every problem size the kernels' route is measured on, and
+  // the reverse pass then skips its forward recompute (6 F_pt per point instead of 8).  Falls back to recompute when
+  // they would not fit half of the free memory.
+  struct Kept {
+    float* buf = nullptr; size_t cap = 0;       // elements
+    const float* X = nullptr; long n = 0, c = 0; int S = 0; bool valid = false;
+  } kept[2];
+  bool never_keep = false;                      // VN_LAYERED_NOKEEP=1: always recompute (tests run both ways)
 };
 
 namespace {
@@ -353,9 +381,11 @@ int ensure_part(VnLayered* w, size_t elems, char* err, size_t errlen) {
 int colsum_add(VnLayered* w, const float* A, const float* x, long n, int H, float* dst, hipStream_t s, char* err, size_t errlen) {
   const int nb = (int)((n + RS_ROWS - 1) / RS_ROWS);
   if (int rc = ensure_part(w, (size_t)nb * H, err, errlen)) return rc;
+  LTRACE(s, "colsum A=%p x=%p n=%ld H=%d nb=%d part=%p dst=%p", (const void*)A, (const void*)x, n, H, nb, (void*)w->part, (void*)dst);
   if (H >= 8) hipLaunchKernelGGL(k_colsum_part, dim3(nb, (H + 63) / 64), dim3(EB), 0, s, A, x, n, H, w->part);
   else hipLaunchKernelGGL(k_colsum_part_narrow, dim3(nb), dim3(EB), 0, s, A, x, n, H, w->part);
   LHIP(hipGetLastError());
+  LTRACE(s, "colsum partial kernel done");
   hipLaunchKernelGGL(k_sum_parts, dim3(blocks(H)), dim3(EB), 0, s, w->part, nb, (long)H, dst);
   LHIP(hipGetLastError());
   return 0;
@@ -411,6 +441,8 @@ int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errle
   if (int rc = load_blas(err, errlen)) return rc;
   VnLayered* w = new VnLayered();
   w->net = net;
+  const char* nk = getenv("VN_LAYERED_NOKEEP");
+  w->never_keep = nk && *nk && *nk != '0';
   for (int l = 0; l <= net.L; ++l) {
     w->sumH += net.H[l];
     if (net.H[l] > w->hmax_all) w->hmax_all = net.H[l];
@@ -431,6 +463,7 @@ void vn_layered_destroy(VnLayered* w) {
   if (w->handle) (void)g_blas.destroy_handle(w->handle);
   if (w->ws) (void)hipFree(w->ws);
   if (w->part) (void)hipFree(w->part);
+  for (auto& k : w->kept) if (k.buf) (void)hipFree(k.buf);
   delete w;
 }
 
@@ -450,15 +483,19 @@ int chunk_forward(VnLayered* w, const float* theta, const float* X, const float*
   return 0;
 }
 
-// carve the chunk buffers out of the workspace; returns elements used
-long carve(VnLayered* w, long c, int S, bool train, float** act, float** adj) {
+// carve the chunk buffers out of `base` (activations) and the workspace (adjoints); returns elements used of each
+long carve_act(const VnLayered* w, float* base, long c, int S, float** act) {
   const VnNet& net = w->net;
-  float* p = (float*)w->ws;
   long used = 0;
   for (int l = 0; l <= net.L; ++l) {
-    act[l] = p ? p + used : nullptr;
+    act[l] = base ? base + used : nullptr;
     used += (long)S * c * net.H[l];
   }
+  return used;
+}
+long carve(VnLayered* w, long c, int S, bool train, float** act, float** adj, bool act_elsewhere = false) {
+  float* p = (float*)w->ws;
+  long used = act_elsewhere ? 0 : carve_act(w, p, c, S, act);
   if (train) {
     for (int i = 0; i < 2; ++i) {
       adj[i] = p ? p + used : nullptr;
@@ -468,24 +505,54 @@ long carve(VnLayered* w, long c, int S, bool train, float** act, float** adj) {
   return used;
 }
 
+// room for the activations of all n rows in slot `slot`, cut into chunks of c rows?  (never more than half of what is free)
+bool kept_reserve(VnLayered* w, int slot, long n, long c, int S) {
+  if (w->never_keep) return false;
+  VnLayered::Kept& k = w->kept[slot];
+  const size_t need = (size_t)((n + c - 1) / c) * (size_t)S * c * w->sumH;
+  if (need > k.cap) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    if ((need - k.cap) * sizeof(float) > fr / 2) return false;
+    if (k.buf) (void)hipFree(k.buf);
+    k.buf = nullptr; k.cap = 0;
+    if (hipMalloc((void**)&k.buf, need * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    k.cap = need;
+  }
+  return true;
+}
+
 }  // namespace
 
-int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipStream_t s, char* err, size_t errlen) {
+int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipStream_t s, char* err, size_t errlen,
+                       int keep_slot) {
+  if (keep_slot >= 0) w->kept[keep_slot].valid = false;
   if (seg.n <= 0) return 0;
   const VnNet& net = w->net;
   const int S = (seg.G && seg.ud) ? 2 : 1;
   LBLAS(g_blas.set_stream(w->handle, s));
-  const long c = chunk_rows<float>(seg.n, (long)S * w->sumH);
+  // with keep_slot >= 0 the chunking is the reverse pass's, and the activations go to the slot instead of the workspace
+  long c = chunk_rows<float>(seg.n, (long)S * w->sumH);
+  bool keep = false;
+  if (keep_slot >= 0) {
+    const long cb = chunk_rows<float>(seg.n, (long)S * w->sumH + 2l * S * w->hmax_all);
+    keep = kept_reserve(w, keep_slot, seg.n, cb, S);
+    if (keep) c = cb;
+  }
   float *act[VN_MAX_LAYERS + 2], *adj[2];
-  if (int rc = ensure_ws(w, (size_t)carve(w, c, S, false, act, adj) * sizeof(float), err, errlen)) return rc;
-  carve(w, c, S, false, act, adj);
+  if (!keep) {
+    if (int rc = ensure_ws(w, (size_t)carve(w, c, S, false, act, adj) * sizeof(float), err, errlen)) return rc;
+  }
   const int HL = net.H[net.L];
-  for (long r0 = 0; r0 < seg.n; r0 += c) {
+  long k = 0;
+  for (long r0 = 0; r0 < seg.n; r0 += c, ++k) {
     const long cn = (seg.n - r0 < c) ? seg.n - r0 : c;
-    // the stacked layout depends on the chunk length: re-carve for the (shorter) last chunk
-    carve(w, cn, S, false, act, adj);
+    // the stacked layout depends on the chunk length: carve per chunk (the last one is shorter)
+    if (keep) carve_act(w, w->kept[keep_slot].buf + (size_t)k * S * c * w->sumH, cn, S, act);
+    else carve(w, cn, S, false, act, adj);
     if (int rc = chunk_forward(w, theta, seg.X + r0 * net.d_in, S == 2 ? seg.G + r0 * net.dim : nullptr, cn, S, act, s, err, errlen))
       return rc;
+    LTRACE(s, "fwd chunk %ld rows %ld keep=%d act0=%p", k, cn, (int)keep, (void*)act[0]);
     // u = a_L w_o + b_o,  ud = ad_L w_o
     const unsigned rb = blocks(cn * 16) < 8192u ? blocks(cn * 16) : 8192u;
     hipLaunchKernelGGL(k_rowdot, dim3(rb), dim3(EB), 0, s, act[net.L], theta + net.woff[net.L + 1], theta + net.boff[net.L + 1], cn, HL,
@@ -497,26 +564,39 @@ int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipS
       LHIP(hipGetLastError());
     }
   }
+  if (keep) {
+    VnLayered::Kept& kp = w->kept[keep_slot];
+    kp.X = seg.X; kp.n = seg.n; kp.c = c; kp.S = S; kp.valid = true;
+  }
   return 0;
 }
 
 int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, float* grad, hipStream_t s, char* err,
-                        size_t errlen) {
+                        size_t errlen, int keep_slot) {
   if (seg.n <= 0) return 0;
   const VnNet& net = w->net;
   const int S = (seg.G && seg.udbar) ? 2 : 1;
   LBLAS(g_blas.set_stream(w->handle, s));
   const long per_row = (long)S * w->sumH + 2l * S * w->hmax_all;
-  const long c = chunk_rows<float>(seg.n, per_row);
+  long c = chunk_rows<float>(seg.n, per_row);
+  // activations kept by the forward of this gradient evaluation (same rows, same stacking): no recompute
+  VnLayered::Kept* kp = keep_slot >= 0 ? &w->kept[keep_slot] : nullptr;
+  const bool kept = kp && kp->valid && kp->X == seg.X && kp->n == seg.n && kp->S == S;
+  if (kept) c = kp->c;
+  if (kp) kp->valid = false;                        // theta moves after this step
   float *act[VN_MAX_LAYERS + 2], *adj[2];
-  if (int rc = ensure_ws(w, (size_t)carve(w, c, S, true, act, adj) * sizeof(float), err, errlen)) return rc;
+  if (int rc = ensure_ws(w, (size_t)carve(w, c, S, true, act, adj, kept) * sizeof(float), err, errlen)) return rc;
   const float one = 1.f, zero = 0.f;
   const int L = net.L, HL = net.H[L];
-  for (long r0 = 0; r0 < seg.n; r0 += c) {
+  long k = 0;
+  for (long r0 = 0; r0 < seg.n; r0 += c, ++k) {
     const long cn = (seg.n - r0 < c) ? seg.n - r0 : c;
-    carve(w, cn, S, true, act, adj);
-    if (int rc = chunk_forward(w, theta, seg.X + r0 * net.d_in, S == 2 ? seg.G + r0 * net.dim : nullptr, cn, S, act, s, err, errlen))
+    carve(w, cn, S, true, act, adj, kept);
+    if (kept) carve_act(w, kp->buf + (size_t)k * S * c * w->sumH, cn, S, act);
+    else if (int rc = chunk_forward(w, theta, seg.X + r0 * net.d_in, S == 2 ? seg.G + r0 * net.dim : nullptr, cn, S, act, s, err,
+                                    errlen))
       return rc;
+    LTRACE(s, "bwd chunk %ld rows %ld kept=%d act0=%p actL=%p adj=%p,%p ws=%p/%zu", k, cn, (int)kept, (void*)act[0], (void*)act[L], (void*)adj[0], (void*)adj[1], w->ws, w->ws_bytes);
     const float* ubar = seg.ubar + r0;
     const float* udbar = S == 2 ? seg.udbar + r0 : nullptr;
     // output layer: dw_o += a_L^T ubar (+ ad_L^T udbar), db_o += sum ubar
@@ -524,6 +604,7 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
     if (S == 2)
       if (int rc = colsum_add(w, act[L] + cn * HL, udbar, cn, HL, grad + net.woff[L + 1], s, err, errlen)) return rc;
     if (int rc = colsum_add(w, ubar, nullptr, cn, 1, grad + net.boff[L + 1], s, err, errlen)) return rc;
+    LTRACE(s, "bwd output-layer sums done");
     float* cur = adj[0];
     float* nxt = adj[1];
     hipLaunchKernelGGL(k_seed_outer, dim3(blocks(cn * HL)), dim3(EB), 0, s, ubar, udbar, theta + net.woff[L + 1], cn, HL, S, cur);
@@ -533,9 +614,11 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
       const long M = (long)S * cn;
       hipLaunchKernelGGL(k_act_bwd, dim3(blocks(cn * Hout)), dim3(EB), 0, s, cur, act[l], cn, Hout, S, net.actl[l]);
       LHIP(hipGetLastError());
+      LTRACE(s, "bwd layer %d act_bwd done", l);
       // db_l += sum over the value-stream rows of zbar;  dW_l += [a; ad]^T [zbar; zdbar]
       if (int rc = colsum_add(w, cur, nullptr, cn, Hout, grad + net.boff[l], s, err, errlen)) return rc;
       if (int rc = wgrad_add(w, act[l - 1], cur, M, Hin, Hout, grad + net.woff[l], s, err, errlen)) return rc;
+      LTRACE(s, "bwd layer %d colsum + wgrad done", l);
       if (l > 1) {
         // [abar; adbar]_{l-1} (M x Hin) = Zbar (M x Hout) W_l^T  ==  column-major (Hin x M) = W'(Hout x Hin)^T Zbar'(Hout x M)
         LBLAS(BlasT<float>::gemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, Hin, (int)M, Hout, &one,
