@@ -420,9 +420,12 @@ int load_rccl() {
   return VN_OK;
 }
 
+// (the collective library probes peers / IPC handles with HIP calls that may fail benignly; their stale last-error
+// must not be reported by the launch check of the next kernel of this library)
 #define RCCLCHK(expr)                                                                        \
   do {                                                                                       \
     ncclResult_t r_ = (expr);                                                                \
+    (void)hipGetLastError();                                                                 \
     if (r_ != ncclSuccess) return fail(VN_ECOMM, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
   } while (0)
 
@@ -789,6 +792,7 @@ int vn_bind_grad_buffer(vn_engine* h, float* dev) {
 
 int vn_grad(vn_engine* h, int32_t batch) {
   if (!h) return fail(VN_EINVAL, "null handle");
+  (void)hipGetLastError();   // a stale last-error of another library on this thread is not ours to report
   if (int rc = check_batch(h, batch)) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   const Batch& b = h->batches[batch];
@@ -856,6 +860,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
 }
 
 static int apply_impl(vn_engine* h, float* loss_acc) {
+  (void)hipGetLastError();   // a stale last-error of another library on this thread is not ours to report
   HIPCHK(hipSetDevice(h->cfg.device));
   h->step += 1;
   if (h->cfg.optimizer == VN_OPT_RMSPROP) {
@@ -917,6 +922,7 @@ int vn_train_step(vn_engine* h, int32_t batch, float* loss_out_dev) {
 
 int vn_eval_loss(vn_engine* h, int32_t batch, double out[4], float* lossVec_dev) {
   if (!h || !out) return fail(VN_EINVAL, "null argument");
+  (void)hipGetLastError();   // a stale last-error of another library on this thread is not ours to report
   if (int rc = check_batch(h, batch)) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   if (int rc = run_forward_and_seed(h, h->batches[batch], false, lossVec_dev, h->lossbuf)) return rc;
@@ -929,6 +935,7 @@ int vn_eval_loss(vn_engine* h, int32_t batch, double out[4], float* lossVec_dev)
 
 int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
   if (!h || (n > 0 && (!X || !u))) return fail(VN_EINVAL, "null argument");
+  (void)hipGetLastError();   // a stale last-error of another library on this thread is not ours to report
   HIPCHK(hipSetDevice(h->cfg.device));
   if (h->layered) {
     VnRows sl{};
@@ -945,6 +952,7 @@ int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
 
 int vn_forward_f64(vn_engine* h, const double* X, int64_t n, double* u) {
   if (!h || (n > 0 && (!X || !u))) return fail(VN_EINVAL, "null argument");
+  (void)hipGetLastError();   // a stale last-error of another library on this thread is not ours to report
   HIPCHK(hipSetDevice(h->cfg.device));
   if (int rc = refresh_theta64(h)) return rc;
   if (h->layered) {
