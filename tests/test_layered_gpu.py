@@ -25,6 +25,9 @@ CASES = [
     (3, 2, [256],                     216,     3,   5,  2,   False, True,  False),   # integNum 216, one wide layer
     (3, 2, [50, 50, 50],              64,      40,  30, 10,  True,  False, False),   # kernel range: forced route
     (2, 1, [7],                       36,      11,  40, 13,  True,  True,  True),
+    (3, 2, [2048, 700],               16,      5,   9,  4,   False, False, False),   # the widest a vn_config describes
+    (2, 1, [12] * 16,                 16,      20,  30, 10,  True,  False, False),   # ... and the deepest
+    (32, 3, [24, 24],                 64,      6,   20, 8,   False, True,  False),   # ... and the most inputs
 ]
 
 
