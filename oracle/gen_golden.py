@@ -15,6 +15,8 @@ session (tests/test_problem_layer.py::test_survey_known_answers).
 import os
 import sys
 
+sys.dont_write_bytecode = True      # importing the reference must not write __pycache__ into /root/reference (read-only input)
+
 import numpy as np
 
 REF = '/root/reference'

@@ -28,6 +28,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True      # importing the reference must not write __pycache__ into /root/reference (read-only input)
+
 import numpy as np
 
 REF = '/root/reference'
