@@ -103,6 +103,8 @@ CASES = [
     (3, 2, [64, 64, 64, 64],     64,      40,  70,  30,  True,  False, True),    # 64 wide, several tiles
     (2, 1, [64, 40, 64],         16,      77,  33,  11,  False, False, False),   # 64 wide next to narrower layers
     (3, 2, [64],                 36,      21,  30,  10,  False, True,  False),   # one 64-wide layer: output bias per lane
+    (3, 2, [64] * 6,             64,      12,  30,  10,  True,  False, False),   # six 64-wide layers: flush image over the weight images
+    (3, 2, [60, 64, 51, 64, 56, 63], 36,  17,  12,  5,   False, True,  True),
 ]
 
 
@@ -111,7 +113,7 @@ def _skip_unsupported(kernel, widths, integNum):
                         (max(widths) > 20 and len(widths) < 2) or (max(widths) > 32 and len(widths) < 3) or
                         len(widths) > (5 if max(widths) > 32 else 4)):
         pytest.skip('fused32 not instantiated for this shape')
-    if kernel == 3 and len(widths) > (5 if max(widths) > 50 else 6):   # integNum > 128: two-pass
+    if kernel == 3 and len(widths) > 6:   # integNum > 128: two-pass
         pytest.skip('fused16 not instantiated for this shape')
 
 
@@ -605,14 +607,16 @@ def test_empty_tower_feed(kernel):
     eng.close()
 
 
-def test_six_wide_layers_run_on_the_generic_kernels():
-    """6 layers wider than 50 have no fused instantiation (LDS); at widths > 61 the generic backward kernel switches to the
-    65-float row stride to fit 160 KiB.  Checked against the fp64 oracle."""
+@pytest.mark.parametrize('kernel,path', [(0, 3), (1, 1)], ids=['auto', 'generic'])
+def test_six_wide_layers(kernel, path):
+    """6 layers wider than 50: on the 8-wave fused kernel (its flush image lies over the dead weight images to fit the
+    160 KB), and on the generic kernels, whose backward kernel switches to the 65-float row stride at widths > 61.
+    Checked against the fp64 oracle."""
     from varnet_amd.engine import VNEngine
     for widths in ([64] * 6, [55, 60, 52, 64, 51, 58]):
         d = synth(9, 3, 2, widths, 16, 30, 40, 15)
-        eng = VNEngine(2, 3, widths, True, 16)
-        assert eng.kernel_path()[0] == 1
+        eng = VNEngine(2, 3, widths, True, 16, kernel=kernel)
+        assert eng.kernel_path()[0] == path
         eng.init_params(seed=2)
         flat = eng.get_params()
         eng.set_fe_table(d['N1'], d['dNt1'], None)

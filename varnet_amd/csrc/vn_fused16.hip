@@ -80,7 +80,13 @@ struct Lay {
   static constexpr int T_IMG = 2 * t_rows(KS) * TSW;
   static constexpr int T_H13 = (KS == 13) ? 27 * (NW * 64 + 4) : 0;         // lane-major images of the 50-wide path (H13)
   static constexpr int T_MAX = T_IMG > T_H13 ? T_IMG : T_H13;
-  static constexpr int T_SZ = al4(T_MAX > G_SZ ? T_MAX : G_SZ);
+  // The gradient image of the final flush normally shares the transposition region.  Where it is larger than that
+  // region AND the layout would then exceed the 160 KB (six 64-wide layers), it is laid over the weight images
+  // instead, which are dead once the tile loop has ended (G_LOW; it must end below sInt, which the flush still uses).
+  static constexpr int T_SZ_SHARED = al4(T_MAX > G_SZ ? T_MAX : G_SZ);
+  static constexpr bool G_LOW = (T_OFF + T_SZ_SHARED > 160 * 256) && G_SZ <= MISC_OFF;
+  static constexpr int T_SZ = G_LOW ? al4(T_MAX) : T_SZ_SHARED;
+  static constexpr int G_OFF = G_LOW ? 0 : T_OFF;
   // Weight-gradient accumulators of the first NST hidden layers live in LDS between their uses
   // (2 x f32x4 per lane and layer): registers are short while the forward pass stores activations,
   // and what the compiler spills instead goes to scratch, i.e. through L2 to HBM.
@@ -775,7 +781,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   float* TA = lds + LY::T_OFF;
   float* TB = TA + t_rows(KS) * TSW;
   const unsigned t_base_bytes = (unsigned)((LY::T_OFF + wave * 64) * 4);      // lane-major images: this wave's columns
-  float* Gacc = lds + LY::T_OFF;
+  float* Gacc = lds + LY::G_OFF;
 
   FIXSTAMP(0);
   // ------------------------------------------------------------------ prologue: LDS images
@@ -1275,7 +1281,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     for (int i = 0; i < 8; ++i) A.stamps[i] = stamp_acc[i];
 #endif
   __syncthreads();
-  for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
+  for (int i = tid; i < (LY::G_LOW ? LY::G_SZ : LY::T_SZ); i += NTHREADS) lds[LY::G_OFF + i] = 0.f;
   __syncthreads();
   // Accumulators -> LDS gradient image, every sum in a fixed order (bitwise reproducible).
   if constexpr (HID13) {
@@ -1423,7 +1429,7 @@ int pick_ks(int hmax) {
   X(1, 5) X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(6, 5) X(7, 5) X(8, 5)  \
   X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8) X(7, 8) X(8, 8)  \
   X(1, 13) X(2, 13) X(3, 13) X(4, 13) X(5, 13) X(6, 13)  \
-  X(1, 16) X(2, 16) X(3, 16) X(4, 16) X(5, 16)
+  X(1, 16) X(2, 16) X(3, 16) X(4, 16) X(5, 16) X(6, 16)
 
 size_t vn_fused16_lds_bytes(const VnNet& net) {
   const int ks = pick_ks(net.hmax);
