@@ -55,7 +55,7 @@ enum {
 enum { VN_ACT_SIGMOID = 0, VN_ACT_TANH = 1, VN_ACT_PER_LAYER = 2 };
 enum { VN_OPT_ADAM = 0, VN_OPT_RMSPROP = 1 };   /* tf.train.AdamOptimizer / RMSPropOptimizer (TFModel.py:183-186) */
 /* Kernel families.  AUTO picks the 8-wave fused kernel where it is instantiated: uniform or ragged hidden widths
- * <= 32 with 1..8 layers, <= 64 with 1..6 layers, d_in <= 8, sigmoid or tanh; integ_num <= 128 in one launch, larger
+ * <= 50 with 1..8 layers, <= 64 with 1..6 layers, d_in <= 8, sigmoid or tanh; integ_num <= 128 in one launch, larger
  * through the two-pass route.  The generic kernels serve VN_KERNEL_GENERIC requests (the independent cross-check of the
  * tests); networks beyond VN_KMAX_* run on the layer-by-layer route. */
 enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 /* 4 waves, 32x32x2 */,

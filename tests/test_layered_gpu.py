@@ -52,7 +52,7 @@ def test_loss_and_grad_parity_layered(case):
     d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec = case
     eng, d, flat = _setup(case, LAYERED)
     assert eng.kernel_path()[0] == LAYERED
-    if len(widths) > 8 or max(widths) > 64 or d_in > 8 or (len(widths) > 6 and max(widths) > 32):
+    if len(widths) > 8 or max(widths) > 64 or d_in > 8 or (len(widths) > 6 and max(widths) > 50):
         auto = _setup(case, 0)[0]                   # AUTO resolves to this route for nets beyond the kernels
         assert auto.kernel_path()[0] == LAYERED
         auto.close()
@@ -250,11 +250,13 @@ def test_per_layer_activation_lists(widths, acts):
 
 
 DEEP = [
-    # 7 and 8 hidden layers up to 32 wide are instantiated in the 8-wave fused kernel (no generic kernels for them)
+    # 7 and 8 hidden layers up to 50 wide are instantiated in the 8-wave fused kernel (no generic kernels for them)
     (2, 1, [20] * 8,                     16,  40, 50, 30, False, False, False),
     (3, 2, [32] * 7,                     64,  30, 50, 20, True,  False, True),
     (3, 2, [32] * 8,                     36,  17, 12, 5,  True,  True,  False),
     (3, 2, [20, 10, 20, 7, 20, 13, 20],  216, 5,  9,  4,  False, True,  False),   # two-pass route
+    (3, 2, [50] * 7,                     64,  30, 50, 20, False, False, False),   # 50 wide: heavy register spilling, still the kernel
+    (3, 2, [50, 33, 50, 40, 50, 21, 50, 50], 36, 17, 12, 5, True, True, True),
 ]
 
 

@@ -450,7 +450,7 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
   HIPCHK(hipSetDevice(cfg->device));
   // Route.  Networks outside the kernels' range (VN_KMAX_*), and nets whose generic-kernel tile does not fit LDS while
   // no fused instantiation exists, go layer by layer (vn_layered.hip); VN_KERNEL_LAYERED forces that route.  One
-  // extension of the range: 7 and 8 hidden layers up to 32 wide are instantiated in the 8-wave fused kernel (deep,
+  // extension of the range: 7 and 8 hidden layers up to 50 wide are instantiated in the 8-wave fused kernel (deep,
   // narrow nets); the generic kernels do not cover them, so every path of such an engine runs on the fused kernel.
   const bool generic_range = vn_net_in_kernel_range(net);
   const bool deep_fused = !generic_range && net.L <= 8 && net.hmax <= VN_KMAX_WIDTH && net.d_in <= VN_KMAX_DIN &&

@@ -1428,7 +1428,7 @@ int pick_ks(int hmax) {
 #define VN_FUSED16_CASES(X) \
   X(1, 5) X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(6, 5) X(7, 5) X(8, 5)  \
   X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8) X(7, 8) X(8, 8)  \
-  X(1, 13) X(2, 13) X(3, 13) X(4, 13) X(5, 13) X(6, 13)  \
+  X(1, 13) X(2, 13) X(3, 13) X(4, 13) X(5, 13) X(6, 13) X(7, 13) X(8, 13)  \
   X(1, 16) X(2, 16) X(3, 16) X(4, 16) X(5, 16) X(6, 16)
 
 size_t vn_fused16_lds_bytes(const VnNet& net) {
