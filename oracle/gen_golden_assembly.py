@@ -117,6 +117,12 @@ def record(store, key, vn, RVU, batchNum, batchLen, pu):
     store[g + 'hVec'] = np.reshape(fd.hVec, -1)
     store[g + 'integW'] = np.zeros(0) if fd.integW is None else np.asarray(fd.integW, dtype=float)
     store[g + 'uniform_input'] = fd.uniform_input
+    # what the monitors feed (VarNetUtility.py:370-411): exact field, PDE data and grad(diffusivity) on uniform_input
+    store[g + 'cEx'] = np.zeros(0) if fd.cEx is None else np.asarray(fd.cEx, dtype=float)
+    uid = fd.uniform_inpData
+    for nm, arr in zip(('u_diff', 'u_vel', 'u_src'), uid):
+        store[g + nm] = np.zeros(0) if arr is None else np.asarray(arr, dtype=float)
+    store[g + 'd_diff'] = np.asarray(fd.d_diff, dtype=float)
     # per (mini-batch, tower) feed: rows of Input / gcoef and the intShape the tower receives
     for bi, fdict in enumerate(tData.optimFeedicts):
         for ti, tw in enumerate(vn.tfData.compTowers):
@@ -149,9 +155,9 @@ def main():
     def pde1(td=True):
         if td:
             return RA.ADPDE(RD.Domain1D(), diff=0.1 / np.pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
-                            IC=lambda x: -np.sin(np.pi * x))
+                            IC=lambda x: -np.sin(np.pi * x), cEx=lambda x, t: -np.sin(np.pi * (x - t)) * np.exp(-0.3 * t))
         return RA.ADPDE(RD.Domain1D(), diff=0.1 / np.pi, vel=1.0, source=lambda x: 1.0 + x ** 2,
-                        timeDependent=False, BCs=[[0., 1., 0.5], [0., 2., 1.0]])
+                        timeDependent=False, BCs=[[0., 1., 0.5], [0., 2., 1.0]], cEx=lambda x: 0.5 + 0.25 * (x + 1.0) ** 2)
 
     def pde2(source=False):
         verts = np.array([[0.0, -0.5], [0.0, -0.2], [0.0, 0.2], [0.0, 0.5], [2.0, 0.5], [2.0, -0.5]])
@@ -161,6 +167,7 @@ def main():
             kw['source'] = lambda x, t: np.sin(x[:, 0:1]) * (1.0 + t)
             kw['diff'] = lambda x, t: 1e-3 * (1.0 + x[:, 1:2] ** 2)
             kw['vel'] = lambda x, t: np.hstack([1.0 + 0.0 * t, 0.1 * x[:, 0:1]])
+            kw['d_diff'] = lambda x, t: np.hstack([0.0 * x[:, 0:1], 2e-3 * x[:, 1:2]])
         else:
             kw['diff'], kw['vel'] = 1e-3, [1., 0.]
         return RA.ADPDE(RD.PolygonDomain2D(verts), tInterval=[0, 1.5], BCs=BC, IC=0.0, **kw)

@@ -33,9 +33,9 @@ def cpu_engine(monkeypatch):
 def pde1(td=True):
     if td:
         return ADPDE(Domain1D(), diff=0.1 / np.pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
-                     IC=lambda x: -np.sin(np.pi * x))
+                     IC=lambda x: -np.sin(np.pi * x), cEx=lambda x, t: -np.sin(np.pi * (x - t)) * np.exp(-0.3 * t))
     return ADPDE(Domain1D(), diff=0.1 / np.pi, vel=1.0, source=lambda x: 1.0 + x ** 2, timeDependent=False,
-                 BCs=[[0., 1., 0.5], [0., 2., 1.0]])
+                 BCs=[[0., 1., 0.5], [0., 2., 1.0]], cEx=lambda x: 0.5 + 0.25 * (x + 1.0) ** 2)
 
 
 def pde2(source=False):
@@ -46,6 +46,7 @@ def pde2(source=False):
         kw['source'] = lambda x, t: np.sin(x[:, 0:1]) * (1.0 + t)
         kw['diff'] = lambda x, t: 1e-3 * (1.0 + x[:, 1:2] ** 2)
         kw['vel'] = lambda x, t: np.hstack([1.0 + 0.0 * t, 0.1 * x[:, 0:1]])
+        kw['d_diff'] = lambda x, t: np.hstack([0.0 * x[:, 0:1], 2e-3 * x[:, 1:2]])
     else:
         kw['diff'], kw['vel'] = 1e-3, [1., 0.]
     return ADPDE(PolygonDomain2D(verts), tInterval=[0, 1.5], BCs=BC, IC=0.0, **kw)
@@ -103,6 +104,17 @@ def check_case(key, vn, bn, bl, pu):
     else:
         assert fd.integW is None
     np.testing.assert_allclose(fd.uniform_input, G[g + 'uniform_input'], **TOL)
+    # monitor inputs (VarNetUtility.py:370-411): exact field, PDE data and grad(diffusivity) on uniform_input
+    if G[g + 'cEx'].size:
+        np.testing.assert_allclose(fd.cEx, G[g + 'cEx'], **TOL)
+    else:
+        assert fd.cEx is None
+    for nm, arr in zip(('u_diff', 'u_vel', 'u_src'), fd.uniform_inpData):
+        if G[g + nm].size:
+            np.testing.assert_allclose(np.asarray(arr, dtype=float), G[g + nm], **TOL)
+        else:
+            assert arr is None
+    np.testing.assert_allclose(np.asarray(fd.d_diff, dtype=float), G[g + 'd_diff'], **TOL)
     # (mini-batch, tower) feeds
     q = fd.integNum
     for bi in range(td.batchNum):
