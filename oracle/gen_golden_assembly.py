@@ -73,6 +73,16 @@ class Tower:
 PU = [1]
 
 
+def OPT_RESIDUAL(X):
+    """Stand-in for |strong residual| on rows [x, y, t] (smpScheme='optimal' fixture)."""
+    return np.abs(np.sin(3.0 * X[:, 0:1]) * (0.2 + X[:, 2:3]) + 0.3 * X[:, 1:2]) + 0.05
+
+
+def OPT_MODEL(X):
+    """Stand-in for the model value on boundary / initial rows [x, y, t]."""
+    return 0.3 * np.cos(2.0 * X[:, 0:1]) + 0.1 * X[:, 2:3] - 0.2 * X[:, 1:2]
+
+
 class TowerRecord:
     """Stands where the reference constructs TFNN (VarNet.py:200): only `processorNum` and `compTowers` are read
     by the host code exercised here (VarNetUtility.py:832-833)."""
@@ -144,6 +154,9 @@ def main():
     os.environ.setdefault('MPLBACKEND', 'Agg')
     sys.path.insert(0, REF)
     install_placeholders()
+    if not hasattr(np, 'asscalar'):
+        # the reference was written against NumPy < 1.23 (`np.asscalar` in VarNet.py:328, Domain.py); the call it made
+        np.asscalar = lambda a: np.asarray(a).item()
     import VarNet as RV                      # the reference's own module, unmodified
     import VarNetUtility as RVU
     import Domain as RD
@@ -222,6 +235,37 @@ def main():
             assert key == '1dt' and 'same number of dimensions' in str(e), e
             continue
         st['rand_%s_Input' % key], st['rand_%s_biInput' % key], st['rand_%s_biDof' % key] = Input, biInput, np.array(biDof)
+
+    # smpScheme='optimal' (VarNet.py:1696-1966): the reference's own optTrainPoints / optBiTrainPoints / updateOptimData
+    # from a fixed NumPy seed, with the two device fields they consult replaced by closed-form stand-ins -- |strong
+    # residual| (self.residual) and the model value on boundary rows (sess.run(model(Input))) -- so that the host policy
+    # (thinning / adding, rejection sampling per segment, support scaling, sorting, FE rows of the added points) is what
+    # gets pinned.  (2D+t only: the reference's 1-D random meshes raise, see above.)
+    class FakeSess:
+        def run(self, fetch, feed):
+            tag, key = fetch
+            assert tag == 'model'
+            return OPT_MODEL(feed[key])
+
+    # (the thinning branch, addTrainPts=False, needs a grid on which ceil(frac2 * discNum) really drops points: on the
+    # 4 x 3 grid nothing is dropped, biDof1 is all zeros and the reference's rejectionSampling raises on its empty lists)
+    for name, (frac, add, supp, disc, bdisc, tdisc) in (('add', (0.25, True, 1.0, [4, 3], 3, 4)), ('add_supp', (0.25, True, 0.5, [4, 3], 3, 4)),
+                                                        ('keep', (0.5, False, 1.0, [8, 6], 6, 8))):
+        PU[0] = 1
+        vo = RV.VarNet(pde2(), layerWidth=[5], discNum=disc, bDiscNum=bdisc, tDiscNum=tdisc, integPnum=2)
+        fdo = vo.fixData
+        fdo.setFEdata()
+        vo.residual = lambda Input=None, *a, _v=vo, **k: (None, OPT_RESIDUAL(_v.fixData.uniform_input if Input is None else Input), None, None)
+        vo.tfData.model = lambda t: ('model', t)
+        vo.tfData.sess = FakeSess()
+        np.random.seed(2024)
+        Input, _, biInput, biDof = vo.optTrainPoints(frac, add, supp)
+        g = 'opt_%s_' % name
+        st[g + 'Input'], st[g + 'biInput'], st[g + 'biDof'] = Input, biInput, np.array(biDof)
+        st[g + 'scalars'] = np.array([fdo.nt, fdo.nT, fdo.bDofsum, float(bool(fdo.detJvec))], dtype=float)
+        st[g + 'detJ'] = np.reshape(np.asarray(fdo.detJ, dtype=float), -1)
+        st[g + 'N'], st[g + 'dNx'], st[g + 'dNt'] = fdo.N, fdo.dNx, np.asarray(fdo.dNt, dtype=float)
+        st[g + 'fd_biDof'] = np.array(fdo.biDof)
 
     # MOR batches (Operator_1DtMOR.py:166-204 in small): kappa as third network input, 3 values; the reference walks
     # the batches through trainData(batch, MORdiscArg, tData) -- first pass computes, with saveMORdata=True the

@@ -323,3 +323,31 @@ def test_iteration_report_and_pickle_match_reference(tmp_path):
     dump = pickle.load(open(os.path.join(str(tmp_path), 'trainData.vn'), 'rb'))
     ref_keys = set(str(k) for k in G['iter_pickle_keys'])
     assert ref_keys <= set(dump.keys()), ref_keys - set(dump.keys())      # the build adds `lossAll`, nothing is missing
+
+
+@pytest.mark.parametrize('name,frac,add,supp,grid', [('add', 0.25, True, 1.0, ([4, 3], 3, 4)), ('add_supp', 0.25, True, 0.5, ([4, 3], 3, 4)),
+                                                     ('keep', 0.5, False, 1.0, ([8, 6], 6, 8))])
+def test_optimal_sampling_policy_matches_reference(name, frac, add, supp, grid):
+    """smpScheme='optimal' (VarNet.py:1696-1966, VarNetUtility.py:466-545): with the two device fields replaced by the
+    same closed-form stand-ins on both sides and the same NumPy seed, optTrainPoints / optBiTrainPoints /
+    updateOptimData give the reference's training points, boundary points, counts and FE rows."""
+    res = lambda X: np.abs(np.sin(3.0 * X[:, 0:1]) * (0.2 + X[:, 2:3]) + 0.3 * X[:, 1:2]) + 0.05
+    mod = lambda X: 0.3 * np.cos(2.0 * X[:, 0:1]) + 0.1 * X[:, 2:3] - 0.2 * X[:, 1:2]
+    vn = VarNet(pde2(), layerWidth=[5], discNum=grid[0], bDiscNum=grid[1], tDiscNum=grid[2], integPnum=2)
+    fd = vn.fixData
+    vn.residual = lambda Input=None, *a, **k: (None, res(fd.uniform_input if Input is None else Input), None, None)
+    vn._model_on = lambda X: mod(np.asarray(X, dtype=float))
+    np.random.seed(2024)
+    Input, _, biInput, biDof = vn.optTrainPoints(frac, add, supp)
+    g = 'opt_%s_' % name
+    np.testing.assert_allclose(Input, G[g + 'Input'], **TOL)
+    np.testing.assert_allclose(biInput, G[g + 'biInput'], **TOL)
+    assert [int(b) for b in biDof] == [int(b) for b in G[g + 'biDof']]
+    sc = G[g + 'scalars']
+    assert (fd.nt, fd.nT, int(fd.bDofsum), bool(fd.detJvec)) == (int(sc[0]), int(sc[1]), int(sc[2]), bool(sc[3]))
+    np.testing.assert_allclose(np.reshape(np.asarray(fd.detJ, dtype=float), -1), G[g + 'detJ'], rtol=1e-14)
+    Nr, dNxr, dNtr = fd.rows()
+    np.testing.assert_allclose(Nr, G[g + 'N'], **TOL)
+    np.testing.assert_allclose(dNxr, G[g + 'dNx'], **TOL)
+    np.testing.assert_allclose(dNtr, G[g + 'dNt'], **TOL)
+    assert [int(b) for b in fd.biDof] == [int(b) for b in G[g + 'fd_biDof']]

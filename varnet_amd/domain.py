@@ -127,7 +127,7 @@ class PolygonDomain2D(Domain):
             dof = int(discNum[d])
             h = (lim[1, d] - lim[0, d]) / (dof + 1)
             he.append(h)
-            tol = h if discTol is None else float(discTol[d])
+            tol = h if discTol is None else float(np.reshape(discTol[d], -1)[0])
             axes.append(_axis_nodes(lim[0, d], lim[1, d], dof, rf, sortflg, tol))
         he = np.array(he)
         X, Y = np.meshgrid(axes[0], axes[1], indexing='xy')       # x fastest
