@@ -63,7 +63,7 @@ def install_placeholders():
 class Tower:
     """Keys of one tower's feed dict (the reference uses TF placeholders as dict keys, VarNetUtility.py:840-854)."""
     FIELDS = ('Input', 'biInput', 'biLabel', 'gcoef', 'source', 'N', 'dNt', 'bDof', 'intShape', 'integW',
-              'biDimVal', 'detJvec', 'detJ', 'w')
+              'biDimVal', 'detJvec', 'detJ', 'w', 'residual', 'diff', 'vel', 'diff_dx')
 
     def __init__(self, i):
         for f in self.FIELDS:
@@ -78,6 +78,39 @@ def OPT_RESIDUAL(X):
     return np.abs(np.sin(3.0 * X[:, 0:1]) * (0.2 + X[:, 2:3]) + 0.3 * X[:, 1:2]) + 0.05
 
 
+def MON_MODEL(X):
+    """Stand-in for the model value on monitor rows (any number of input columns)."""
+    X = np.asarray(X, dtype=float)
+    return 0.3 * np.cos(2.0 * X[:, 0:1]) + 0.1 * X[:, -1:] + 0.05 * np.sum(X, axis=1, keepdims=True)
+
+
+def MON_RESIDUAL(X, diff, vel, source, diff_dx, dim):
+    """Stand-in for the strong-residual node: a closed form of EVERYTHING the reference feeds it, so that a wrong
+    feed shows in the value (TFModel.py:743-754 takes the same five arrays)."""
+    X = np.asarray(X, dtype=float)
+    adv = np.sum((np.asarray(vel, dtype=float) - np.asarray(diff_dx, dtype=float)) * X[:, :dim], axis=1, keepdims=True)
+    return np.asarray(diff, dtype=float) * np.sin(X[:, 0:1]) - adv + np.asarray(source, dtype=float) + 0.1 * X[:, -1:]
+
+
+class MonitorSess:
+    """`sess.run` of ManageTrainData.runSession (VarNetUtility.py:1098-1142): records what is fed, answers in closed form."""
+
+    def __init__(self, tower, dim):
+        self.t, self.dim, self.feeds = tower, dim, []
+
+    def run(self, fetches, feed_dict=None):
+        f = feed_dict
+        self.feeds.append({k: (None if v is None else np.array(v, dtype=float)) for k, v in f.items()})
+        out = []
+        for node in fetches:
+            if node == self.t.residual:
+                out.append(MON_RESIDUAL(f[self.t.Input], f[self.t.diff], f[self.t.vel], f[self.t.source], f[self.t.diff_dx], self.dim))
+            else:
+                assert node[0] == 'model'
+                out.append(MON_MODEL(f[node[1]]))
+        return out
+
+
 def OPT_MODEL(X):
     """Stand-in for the model value on boundary / initial rows [x, y, t]."""
     return 0.3 * np.cos(2.0 * X[:, 0:1]) + 0.1 * X[:, 2:3] - 0.2 * X[:, 1:2]
@@ -90,6 +123,8 @@ class TowerRecord:
     def __init__(self, *a, **k):
         self.processorNum = PU[0]
         self.compTowers = [Tower(i) for i in range(PU[0])]
+        if len(a) > 1:
+            self.dim, self.inpDim = a[0], a[1]             # TFNN(dim, inpDim, ...) keeps its arguments (VarNet.py:201)
 
 
 class Log:
@@ -181,6 +216,7 @@ def main():
             kw['diff'] = lambda x, t: 1e-3 * (1.0 + x[:, 1:2] ** 2)
             kw['vel'] = lambda x, t: np.hstack([1.0 + 0.0 * t, 0.1 * x[:, 0:1]])
             kw['d_diff'] = lambda x, t: np.hstack([0.0 * x[:, 0:1], 2e-3 * x[:, 1:2]])
+            kw['cEx'] = lambda x, t: np.exp(-t) * np.sin(x[:, 0:1]) * (1.0 + x[:, 1:2])
         else:
             kw['diff'], kw['vel'] = 1e-3, [1., 0.]
         return RA.ADPDE(RD.PolygonDomain2D(verts), tInterval=[0, 1.5], BCs=BC, IC=0.0, **kw)
@@ -267,6 +303,50 @@ def main():
         st[g + 'N'], st[g + 'dNx'], st[g + 'dNt'] = fdo.N, fdo.dNx, np.asarray(fdo.dNt, dtype=float)
         st[g + 'fd_biDof'] = np.array(fdo.biDof)
 
+    # evaluate / residual (VarNet.py:1510-1692): the host side of the monitors -- which rows, PDE data and grad(kappa)
+    # reach the graph (uniform grid, user points, one time, MOR batch or explicit MOR arguments) and what is made of
+    # the answer (norm over the grid, l2 error, average over the MOR batches) -- with the graph replaced by MonitorSess
+    def monitor_calls(vn, tag, calls):
+        tw = vn.tfData.compTowers[0]
+        sess = MonitorSess(tw, vn.dim)
+        vn.tfData.sess, vn.tfData.model = sess, (lambda t: ('model', t))
+        vn.fixData.setFEdata()
+        for name, fn in calls:
+            sess.feeds.clear()
+            out = fn(vn)
+            g = 'mon_%s_%s_' % (tag, name)
+            if isinstance(out, tuple):                       # residual(): (res, resVec, err, cApp)
+                st[g + 'res'] = np.float64(out[0])
+                st[g + 'resVec'], st[g + 'cApp'] = out[1], out[3]
+                st[g + 'err'] = np.float64(np.nan if out[2] is None else out[2])
+            else:
+                st[g + 'cApp'] = out
+            st[g + 'ncalls'] = np.int64(len(sess.feeds))
+            for i, fdict in enumerate(sess.feeds):
+                for fld in ('Input', 'diff', 'vel', 'source', 'diff_dx'):
+                    v = fdict.get(getattr(tw, fld))
+                    if v is not None:
+                        st[g + 'c%d_%s' % (i, fld)] = v
+
+    xs2 = np.array([[0.3, -0.1], [1.7, 0.4], [0.9, 0.0], [1.2, -0.45]])
+    rows2 = np.hstack([xs2, np.array([[0.2], [1.1], [0.7], [1.4]])])
+    PU[0] = 1
+    vn_v = RV.VarNet(pde2(source=True), layerWidth=[5], discNum=[4, 3], bDiscNum=3, tDiscNum=4, integPnum=2)
+    monitor_calls(vn_v, '2dt_var', [
+        ('eval_grid', lambda v: v.evaluate()),
+        ('eval_pts_t', lambda v: v.evaluate(xs2, 0.37)),
+        ('eval_pts_tvec', lambda v: v.evaluate(xs2, rows2[:, 2:3])),
+        ('eval_space_only', lambda v: v.evaluate(t=0.5)),
+        ('res_grid', lambda v: v.residual()),
+        ('res_rows', lambda v: v.residual(rows2)),
+    ])
+    vn_st = RV.VarNet(pde1(td=False), layerWidth=[5], discNum=7, bDiscNum=None, tDiscNum=[], integPnum=2)
+    monitor_calls(vn_st, '1d_steady', [
+        ('eval_grid', lambda v: v.evaluate()),
+        ('eval_pts', lambda v: v.evaluate(np.array([[-0.5], [0.25], [0.8]]))),
+        ('res_grid', lambda v: v.residual()),
+    ])
+
     # MOR batches (Operator_1DtMOR.py:166-204 in small): kappa as third network input, 3 values; the reference walks
     # the batches through trainData(batch, MORdiscArg, tData) -- first pass computes, with saveMORdata=True the
     # second pass reloads the stored fields (VarNetUtility.py:660-752).  Recorded per batch: what the towers are fed.
@@ -299,6 +379,19 @@ def main():
                 st[g + 'mb1_Input'] = fd0
         st['1dt_mor_scalars'] = np.array([fdm.MORbatchNum, fdm.nt, fdm.integNum, tD.batchNum, tD.batchLen], dtype=float)
         st['1dt_mor_disc'] = fdm.MORdiscArg[0]
+    # the monitors of the parametric problem: one batch, explicit MOR arguments, and the average over all batches
+    mor = RM.MOR(diffFun, ['D'], [[0.003, 0.033]])
+    pde_m = RA.ADPDE(RD.Domain1D(), diff=diffFun, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                     IC=lambda x: -np.sin(np.pi * x), MORvar=mor, cEx=lambda x, t: -np.sin(np.pi * (x - t)) * np.exp(-0.3 * t))
+    vn_mm = RV.VarNet(pde_m, layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, MORdiscScheme=disc, integPnum=2)
+    vn_mm.tfData = TowerRecord(1, 3)
+    xs1 = np.array([[-0.6], [0.1], [0.75]])
+    monitor_calls(vn_mm, '1dt_mor', [
+        ('eval_batch1', lambda v: v.evaluate(batch=1)),
+        ('eval_pts_arg', lambda v: v.evaluate(xs1, 0.8, MORarg=np.array([[0.012]]))),
+        ('res_batch2', lambda v: v.residual(batch=2)),
+        ('res_all', lambda v: v.residual()),
+    ])
 
     # caseData.txt as the reference's TrainResult.initializeCase writes it (VarNetUtility.py:1217-1464): the case header of a
     # 1D+t run with mini-batches and of a 2D+t run with non-uniform sampling options -- kept as text lines (an OUTPUT
