@@ -63,7 +63,7 @@ def install_placeholders():
 class Tower:
     """Keys of one tower's feed dict (the reference uses TF placeholders as dict keys, VarNetUtility.py:840-854)."""
     FIELDS = ('Input', 'biInput', 'biLabel', 'gcoef', 'source', 'N', 'dNt', 'bDof', 'intShape', 'integW',
-              'biDimVal', 'detJvec', 'detJ', 'w', 'residual', 'diff', 'vel', 'diff_dx')
+              'biDimVal', 'detJvec', 'detJ', 'w', 'residual', 'diff', 'vel', 'diff_dx', 'BCloss', 'ICloss')
 
     def __init__(self, i):
         for f in self.FIELDS:
@@ -109,6 +109,54 @@ class MonitorSess:
                 assert node[0] == 'model'
                 out.append(MON_MODEL(f[node[1]]))
         return out
+
+
+class TrainSess:
+    """`sess` for a whole run of the reference's VarNet.train (VarNet.py:1193-1421): every graph node the loop fetches is
+    answered from a script -- the training losses from a prescribed list, the loss components and the loss field as closed
+    forms of what is fed, model and strong residual as in MonitorSess -- and every training step is logged."""
+
+    def __init__(self, tfd, dim, losses):
+        self.tf, self.t, self.dim, self.losses, self.k, self.steps = tfd, tfd.compTowers[0], dim, list(losses), 0, []
+
+    def run(self, fetches, feed_dict=None):
+        f = feed_dict
+        if isinstance(fetches, tuple) and len(fetches) == 2 and fetches[0] == 'model':      # sess.run(model(Input), {...})
+            return MON_MODEL(f[fetches[1]])
+        out = []
+        for node in fetches:
+            if isinstance(node, list) and not node:                     # lossVec_tf = [] when the field is not wanted
+                out.append([])
+            elif node == self.tf.optMinimize:
+                out.append(None)
+            elif node == self.tf.loss:
+                X = np.asarray(f[self.t.Input])
+                self.steps.append([X.shape[0], float(X[0, 0]), float(X[-1, -1]), float(np.asarray(f[self.t.biInput])[0, 0])])
+                out.append(self.losses[self.k])
+                self.k += 1
+            elif node == self.t.BCloss:
+                out.append(2.0)
+            elif node == self.t.ICloss:
+                out.append(3.0)
+            elif node == self.tf.varLoss:
+                out.append(1e-3 * np.asarray(f[self.t.Input]).shape[0])
+            elif node == self.tf.lossVec:
+                n_k, q = [int(v) for v in f[self.t.intShape]]
+                out.append(np.asarray(f[self.t.Input])[::q, 0:1][:n_k].copy())
+            elif node == self.t.residual:
+                out.append(MON_RESIDUAL(f[self.t.Input], f[self.t.diff], f[self.t.vel], f[self.t.source], f[self.t.diff_dx], self.dim))
+            else:
+                assert node[0] == 'model', node
+                out.append(MON_MODEL(f[node[1]]))
+        return out
+
+
+class SaverRec:
+    def __init__(self):
+        self.saved = []
+
+    def save(self, sess, path, global_step=None):
+        self.saved.append(int(global_step))
 
 
 def OPT_MODEL(X):
@@ -441,6 +489,57 @@ def main():
             st['iter_avgtime'] = np.array([tr.avgtime0, tr.avgtime])
             dump = pickle.load(open(os.path.join(folder, 'trainData.vn'), 'rb'))
             st['iter_pickle_keys'] = np.array(sorted(dump.keys()))
+
+    # The epoch loop itself (VarNet.py:1193-1421) against a scripted session: the order of the training steps, the
+    # shuffle points, the stop rule, the checkpoint policy, what iterOutput records, and -- in the residual-driven case --
+    # when the training points are redrawn, the re-weighting (adjustWeight) and the rebuilt feeds.
+    import contextlib as _ctx, io as _io, time as _time
+    if not hasattr(_time, 'clock'):
+        _time.clock = _time.perf_counter                  # the reference was written for Python < 3.8 (VarNet.py:1349)
+
+    def scripted_train(tag, mk, losses, dim, **targ):
+        PU[0] = 1
+        v = mk()
+        t = v.tfData
+        t.loss, t.optMinimize, t.varLoss, t.lossVec, t.graph = 'loss', 'optMinimize', 'varLoss', 'lossVec', None
+        t.layerWidth, t.activationFun = [5], ['sigmoid']
+        t.model_count = ParamCount((v.dim + 1) * 5 + 5 + 5 + 1)
+        t.processors, t.controller, t.optimizer_name, t.learning_rate = ['/device:GPU:0'], '/device:GPU:0', 'Adam', 0.001
+        t.saver = SaverRec()
+        sess = TrainSess(t, dim, losses)
+        t.sess = sess
+
+        class ModelBoth:                                   # tfData.model: callable on a placeholder AND asked for count_params
+            def __call__(self, key):
+                return ('model', key)
+
+            def count_params(self):
+                return t.model_count.count_params()
+        t.model = ModelBoth()
+        folder = tempfile.mkdtemp()
+        np.random.seed(31337)
+        with _ctx.redirect_stdout(_io.StringIO()):
+            v.train(folder, verbose=False, **targ)
+        tr = v.trainRes
+        g = 'loop_%s_' % tag
+        st[g + 'steps'] = np.array(sess.steps, dtype=float)
+        st[g + 'saved'] = np.array(t.saver.saved, dtype=float)
+        st[g + 'iterSmp'], st[g + 'loss'] = np.array(tr.iterSmp, dtype=float), np.array(tr.loss, dtype=float)
+        st[g + 'lossComp'] = np.array([np.reshape(c, -1) for c in tr.lossComp], dtype=float)
+        st[g + 'residual'] = np.array(tr.residual, dtype=float)
+        st[g + 'error'] = np.array(getattr(tr, 'error', []), dtype=float)
+        st[g + 'inpIter'] = np.array(tr.inpIter, dtype=float)
+        st[g + 'trainWeight'] = np.array(tr.trainWeight, dtype=float)
+        st[g + 'nsteps'] = np.float64(sess.k)
+
+    L = 1000.0 / (1.0 + np.arange(400.0))                 # the scripted training losses, one per sess.run of a mini-batch
+    scripted_train('uniform', lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2), L, 1,
+                   weight=[10., 10., 1.], smpScheme='uniform', epochNum=9, tol=2 * 1000.0 / 14.5, saveFreq=2, batchNum=2,
+                   shuffleData=True, shuffleFreq=3)
+    scripted_train('optimal', lambda: RV.VarNet(pde2(), layerWidth=[5], discNum=[4, 3], bDiscNum=3, tDiscNum=4, integPnum=2), L, 2,
+                   weight=[5., 1., 1.], smpScheme='optimal', frac=0.25, addTrainPts=True, suppFactor=1.0, epochNum=8, tol=1e-9,
+                   saveFreq=2, multiTrainUpd=False, trainUpdelay=3, tolUpd=1e9, reinitrain=False, adjustWeight=True)
+    # (saveFreq=1 cannot be scripted: TrainResult.iterOutput then never sets avgtime0 and raises, VarNetUtility.py:1582,1607)
 
     # (8) trainWeight arithmetic: the three branches on fixed loss triples, time-dependent and steady
     triples = np.array([[0.37, 1.9, 42.0], [1e-3, 5.0, 0.2], [12.5, 0.04, 3.3e3]])

@@ -10,6 +10,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from varnet_amd.domain import Domain1D, PolygonDomain2D
 from varnet_amd.adpde import ADPDE
@@ -477,3 +478,92 @@ def test_monitor_calls_match_reference_mor():
         ('res_batch2', lambda v: v.residual(batch=2)),
         ('res_all', lambda v: v.residual()),
     ])
+
+
+# ---- the epoch loop against a scripted device (VarNet.py:1193-1421) --------------------------------------------------
+class ScriptedEngine(OracleEngine):
+    """OracleEngine whose training steps answer from the script the fixture generator gave the reference's session
+    (TrainSess in oracle/gen_golden_assembly.py): prescribed training losses, loss components / loss field / model /
+    residual as closed forms of what is registered.  Nothing is computed, every step is logged."""
+
+    def arm(self, losses):
+        self.script, self.k, self.steps = list(losses), 0, []
+
+    def _bi(self, batch):
+        return self.bbic[batch][0] if batch in getattr(self, 'bbic', {}) else self.bic[0]
+
+    def grad(self, batch=0):                      # the loop's step on an engine without train_epoch: grad -> SUM -> apply
+        X = self.batches[batch][0]
+        self.steps.append([X.shape[0], float(X[0, 0]), float(X[-1, -1]), float(np.asarray(self._bi(batch))[0, 0])])
+        gb = self.bind_grad_buffer()
+        gb[self.P] = self.script[self.k]
+        self.k += 1
+
+    def apply(self):
+        pass
+
+    def eval_loss(self, batch=0, lossVec=False):
+        X, _, _, n_k, _, _, _ = self.batches[batch]
+        bc, ic, var = 2.0, 3.0, 1e-3 * X.shape[0]
+        lv = torch.as_tensor(X[::self.integNum, 0][:n_k].copy()) if lossVec else None
+        return [self.w[0] * bc + self.w[1] * ic + self.w[2] * var, bc, ic, var], lv
+
+    def forward(self, X):
+        X = X.numpy() if isinstance(X, torch.Tensor) else np.asarray(X, dtype=float)
+        return torch.as_tensor(_mon_model(X).reshape(-1))
+
+    def residual(self, X, diff, vel, source=None, diff_dx=None, fp64=False):
+        X = np.asarray(X, dtype=float)
+        n = X.shape[0]
+        src = np.zeros((n, 1)) if source is None else np.reshape(source, (n, 1))
+        ddx = np.zeros((n, self.dim)) if diff_dx is None else np.reshape(diff_dx, (n, self.dim))
+        r = _mon_residual(X, np.reshape(diff, (n, 1)), np.reshape(vel, (n, self.dim)), src, ddx, self.dim)
+        return torch.as_tensor(_mon_model(X).reshape(-1)), torch.as_tensor(r.reshape(-1))
+
+
+def _scripted_train(monkeypatch, tmp_path, tag, vn, **targ):
+    fd = vn.fixData
+
+    def make(self, processors):
+        e = ScriptedEngine(self.dim, self.inpDim, self.layerWidth, self.PDE.timeDependent, self.fixData.integNum,
+                           isSource=self.lossOpt['isSource'], integWflag=self.lossOpt['integWflag'], learning_rate=self.learning_rate)
+        e.arm(1000.0 / (1.0 + np.arange(400.0)))
+        return e
+    monkeypatch.setattr(VarNet, '_make_engine', make)
+    vn.engine = vn._make_engine(None)
+    vn.engine.set_fe_table(fd.N, fd.dNt, fd.integW)
+    saved = []
+    orig_save = vn.saveModel
+    vn.saveModel = lambda epoch: (saved.append(int(epoch)), orig_save(epoch))[1]
+    np.random.seed(31337)
+    res = vn.train(str(tmp_path), verbose=False, **targ)
+    g = 'loop_%s_' % tag
+    eng = vn.engine
+    assert eng.k == int(G[g + 'nsteps'])
+    np.testing.assert_allclose(np.array(eng.steps, dtype=float), G[g + 'steps'], **TOL)
+    assert saved == [int(v) for v in G[g + 'saved']]
+    np.testing.assert_allclose(res.iterSmp, G[g + 'iterSmp'])
+    np.testing.assert_allclose(res.loss, G[g + 'loss'], rtol=1e-6)               # fp32 loss read-back on this side
+    np.testing.assert_allclose(np.array([np.reshape(c, -1) for c in res.lossComp], dtype=float), G[g + 'lossComp'], rtol=1e-12)
+    np.testing.assert_allclose(np.array(res.residual, dtype=float), G[g + 'residual'], rtol=1e-12)
+    if vn.PDE.cEx is not None:
+        np.testing.assert_allclose(np.array(res.error, dtype=float), G[g + 'error'], rtol=1e-12)
+    np.testing.assert_allclose(np.array(res.inpIter, dtype=float), G[g + 'inpIter'])
+    np.testing.assert_allclose(np.asarray(res.trainWeight, dtype=float), G[g + 'trainWeight'], rtol=1e-12)
+
+
+def test_epoch_loop_matches_reference_uniform(monkeypatch, tmp_path):
+    """Two mini-batches, reshuffle every third epoch, checkpoints every second, stop rule: the same order of training
+    steps (rows fed, before and after the shuffles), the same checkpoints, the same records as the reference's loop."""
+    vn = build('1dt', 2)
+    _scripted_train(monkeypatch, tmp_path, 'uniform', vn, weight=[10., 10., 1.], smpScheme='uniform', epochNum=9,
+                    tol=2 * 1000.0 / 14.5, saveFreq=2, batchNum=2, shuffleData=True, shuffleFreq=3)
+
+
+def test_epoch_loop_matches_reference_optimal(monkeypatch, tmp_path):
+    """Residual-driven sampling inside the loop: the epoch at which the training set is redrawn, the rebuilt feeds, the
+    re-weighting (adjustWeight) and the records."""
+    vn = build('2dt', 2)
+    _scripted_train(monkeypatch, tmp_path, 'optimal', vn, weight=[5., 1., 1.], smpScheme='optimal', frac=0.25, addTrainPts=True,
+                    suppFactor=1.0, epochNum=8, tol=1e-9, saveFreq=2, multiTrainUpd=False, trainUpdelay=3, tolUpd=1e9,
+                    reinitrain=False, adjustWeight=True)

@@ -228,8 +228,12 @@ def test_minibatch_epoch_equals_manual_steps(tmp_path):
     vn = op1dt(layerWidth=[6], discNum=5, tDiscNum=6)
     res = vn.train(str(tmp_path), weight=[1., 1., 1.], epochNum=2, saveFreq=100, verbose=False, batchNum=3)
     assert vn.engine.step == 6
+    # the record holds the per-feed weights: the reference's trainRes.trainWeight is the array updateDictFields divided in
+    # place (tests/test_assembly_golden.py::test_epoch_loop_matches_reference_uniform pins this against the reference)
     tw = res.trainWeight
-    np.testing.assert_allclose(vn.engine.w, [tw[0] / 3, tw[1] / 3, tw[2]])
+    np.testing.assert_allclose(vn.engine.w, tw)
+    lossVal = np.reshape(res.lossComp[0], -1)
+    np.testing.assert_allclose(3 * tw[0] * lossVal[0] + 3 * tw[1] * lossVal[1] + tw[2] * lossVal[2], 1e6, rtol=1e-9)
 
 
 def test_mor_pipeline(tmp_path):

@@ -1155,7 +1155,10 @@ class VarNet:
             return tW, w_e, lv
 
         trainW, w_eff, lossVal = set_train_weights(tData, weight)
-        trainRes.trainWeight = trainW.copy()
+        # what the reference stores is the array `updateDictFields('trainW', ...)` has divided IN PLACE by batchNum * puNum
+        # (VarNet.py:1324-1325 keeps a reference to it, VarNetUtility.py:900-901 rewrites its BC/IC entries): the record in
+        # trainData.vn therefore holds the per-feed weights, not trainWeight's return value
+        trainRes.trainWeight = np.array(w_eff, dtype=float)
         trainRes.lossComp.append(lossVal)
         self.tData = tData
         tData0 = tData                                         # uniform set for universal cost comparison
