@@ -240,6 +240,9 @@ def main():
     if not hasattr(np, 'asscalar'):
         # the reference was written against NumPy < 1.23 (`np.asscalar` in VarNet.py:328, Domain.py); the call it made
         np.asscalar = lambda a: np.asarray(a).item()
+    for _alias, _ty in (('int', int), ('float', float), ('bool', bool), ('complex', complex), ('int0', np.intp)):
+        if not hasattr(np, _alias):                   # ... and the scalar aliases NumPy 1.24 removed (UtilityFunc.py:857)
+            setattr(np, _alias, _ty)
     import VarNet as RV                      # the reference's own module, unmodified
     import VarNetUtility as RVU
     import Domain as RD
@@ -540,6 +543,55 @@ def main():
                    weight=[5., 1., 1.], smpScheme='optimal', frac=0.25, addTrainPts=True, suppFactor=1.0, epochNum=8, tol=1e-9,
                    saveFreq=2, multiTrainUpd=False, trainUpdelay=3, tolUpd=1e9, reinitrain=False, adjustWeight=True)
     # (saveFreq=1 cannot be scripted: TrainResult.iterOutput then never sets avgtime0 and raises, VarNetUtility.py:1582,1607)
+
+    # saveNNparam (VarNet.py:2179-2260): per-layer [W (out x in), b (out x 1)], the timeFirst column move, the MATLAB and
+    # Diffpack files.  The trainable variables come from `tf.trainable_variables()` + `sess.run`: a list of named tokens
+    # and a session that hands out fixed arrays stand in for them.
+    class Var:
+        def __init__(self, name, val):
+            self.name, self.val = name, val
+
+    class VarSess:
+        def run(self, v):
+            return np.array(v.val)            # a session hands out copies
+
+    class NullCtx:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    class GraphRec:
+        def as_default(self):
+            return NullCtx()
+
+    import scipy.io as _spio
+    PU[0] = 1
+    v = RV.VarNet(pde1(), layerWidth=[6, 5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2)
+    rngp = np.random.default_rng(12)
+    vars_, fan = [], 2
+    for i, h in enumerate([6, 5, 1]):
+        nm = 'output' if i == 2 else 'dense_%d' % i
+        vars_ += [Var(nm + '/kernel:0', rngp.standard_normal((fan, h))), Var(nm + '/bias:0', rngp.standard_normal(h))]
+        fan = h
+    st['nnp_theta'] = np.concatenate([x.val.reshape(-1) for x in vars_])
+    t = v.tfData
+    t.depth, t.sess, t.graph = 2, VarSess(), GraphRec()
+    RV.tf = types.SimpleNamespace(trainable_variables=lambda: list(vars_))       # the one tf call of this routine
+    folder = tempfile.mkdtemp()
+    v.trainRes = types.SimpleNamespace(folderpath=folder)
+    for tfirst in (False, True):
+        layers = v.saveNNparam(dpOut=True, matOut=True, verbose=False, timeFirst=tfirst)
+        for li, (W, b) in enumerate(layers):
+            st['nnp_tf%d_W%d' % (int(tfirst), li)], st['nnp_tf%d_b%d' % (int(tfirst), li)] = W, b
+        files = sorted(os.listdir(os.path.join(folder, 'NN_parameters')))
+        st['nnp_files'] = np.array(files)
+        st['nnp_tf%d_W1_m' % int(tfirst)] = np.array(open(os.path.join(folder, 'NN_parameters', 'W1.m')).read().split('\n'))
+        st['nnp_tf%d_B2_m' % int(tfirst)] = np.array(open(os.path.join(folder, 'NN_parameters', 'B2.m')).read().split('\n'))
+        st['nnp_tf%d_W1_mat' % int(tfirst)] = _spio.loadmat(os.path.join(folder, 'NN_parameters', 'W1.mat'))['W1']
+        st['nnp_tf%d_B3_mat' % int(tfirst)] = _spio.loadmat(os.path.join(folder, 'NN_parameters', 'B3.mat'))['B3']
+    RV.tf = sys.modules['tensorflow']
 
     # (8) trainWeight arithmetic: the three branches on fixed loss triples, time-dependent and steady
     triples = np.array([[0.37, 1.9, 42.0], [1e-3, 5.0, 0.2], [12.5, 0.04, 3.3e3]])

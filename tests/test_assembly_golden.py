@@ -567,3 +567,25 @@ def test_epoch_loop_matches_reference_optimal(monkeypatch, tmp_path):
     _scripted_train(monkeypatch, tmp_path, 'optimal', vn, weight=[5., 1., 1.], smpScheme='optimal', frac=0.25, addTrainPts=True,
                     suppFactor=1.0, epochNum=8, tol=1e-9, saveFreq=2, multiTrainUpd=False, trainUpdelay=3, tolUpd=1e9,
                     reinitrain=False, adjustWeight=True)
+
+
+def test_save_nn_param_matches_reference(tmp_path):
+    """saveNNparam (VarNet.py:2179-2260): layers, the timeFirst column move, the MATLAB (.mat) and Diffpack (.m) files."""
+    import types
+    import scipy.io as spio
+    vn = VarNet(pde1(), layerWidth=[6, 5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2)
+    vn.engine.set_params(G['nnp_theta'].astype(np.float64))
+    vn.engine.get_params = lambda: G['nnp_theta'].astype(np.float64)          # keep fp64: the files print every digit
+    vn.trainRes = types.SimpleNamespace(folderpath=str(tmp_path))
+    for tfirst in (False, True):
+        layers = vn.saveNNparam(dpOut=True, matOut=True, verbose=False, timeFirst=tfirst)
+        assert len(layers) == 3
+        for li, (W, b) in enumerate(layers):
+            np.testing.assert_allclose(W, G['nnp_tf%d_W%d' % (int(tfirst), li)], **TOL)
+            np.testing.assert_allclose(b, G['nnp_tf%d_b%d' % (int(tfirst), li)], **TOL)
+        folder = os.path.join(str(tmp_path), 'NN_parameters')
+        assert sorted(os.listdir(folder)) == list(G['nnp_files'])
+        for name in ('W1', 'B2'):
+            assert open(os.path.join(folder, name + '.m')).read().split('\n') == list(G['nnp_tf%d_%s_m' % (int(tfirst), name)])
+        np.testing.assert_allclose(spio.loadmat(os.path.join(folder, 'W1.mat'))['W1'], G['nnp_tf%d_W1_mat' % int(tfirst)], **TOL)
+        np.testing.assert_allclose(spio.loadmat(os.path.join(folder, 'B3.mat'))['B3'], G['nnp_tf%d_B3_mat' % int(tfirst)], **TOL)
