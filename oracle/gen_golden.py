@@ -46,6 +46,7 @@ def main():
         fe[k + 'elemCoord'] = f.elemCoord
         fe[k + 'delta'] = f.delta
         fe[k + 'IntegW'] = np.zeros(0) if f.IntegW is None else f.IntegW
+        fe[k + 'massVec'], fe[k + 'massDelta'] = f.massVec, f.massDelta      # FiniteElement.py:121-123, 438-499
         hVec = np.array([[0.3], [0.05], [0.7]])[:D]
         integNum, nT, detJ, delta, iw, N, dN = f.basisTot(3, hVec)
         fe[k + 'bt_hVec'] = hVec

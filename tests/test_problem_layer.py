@@ -33,6 +33,9 @@ def test_fe_tables_match_reference(D, ip):
         assert f.IntegW is None
     else:
         np.testing.assert_allclose(f.IntegW, g[k + 'IntegW'], **TOL)
+    np.testing.assert_allclose(f.massVec, g[k + 'massVec'], **TOL)          # FiniteElement.py:438-499
+    np.testing.assert_allclose(f.massDelta, g[k + 'massDelta'], **TOL)
+    np.testing.assert_allclose(np.sum(f.massVec), 2.0 ** D, rtol=1e-13)     # the hat function integrates to 2^D (reference cell)
     integNum, nT, detJ, delta, iw, N, dN = f.basisTot(3, g[k + 'bt_hVec'])
     np.testing.assert_allclose([integNum, nT, detJ], g[k + 'bt_scalars'], **TOL)
     np.testing.assert_allclose(delta, g[k + 'bt_delta'], **TOL)

@@ -46,6 +46,7 @@ class FE:
         self.elemCoord = self.elemTranslation()
         self.delta = self.integPtranslation()
         self.IntegW = self.integWeight()
+        self.massVec, self.massDelta = self.massVector()
 
     # ------------------------------------------------------------------------------------
     @staticmethod
@@ -100,6 +101,24 @@ class FE:
             return None
         w = np.prod(self._grid(self.integW, self.dim), axis=1)
         return np.repeat(w[None, :], self.basisNum, axis=0)
+
+    def massVector(self):
+        """
+        Row of the mass matrix that belongs to the training point (FiniteElement.py:438-499; kept as the attributes
+        `massVec [3^D]`, `massDelta [D, 3^D]`, the reference's alternative treatment of nodal source values; nothing
+        on the training path uses it): R_j = sum over the 2^D elements around the point of int N N_j, without |J|.
+        Element e and its corner i meet at the node with offsets elemCoord[:, e, i] in {-1, 0, 1}^D; node index =
+        sum_d (offset_d + 1) * 3^d  (the reference's Fortran-order index matrix).
+        """
+        w = np.ones(self.IntegPnum) if self.IntegW is None else self.IntegW[0, :]
+        R = np.einsum('q,eq,iq->ei', w, self.basVal, self.basVal)             # single-element mass matrix
+        idx = self.elemCoord.astype(int) + 1                                   # [D, e, i] in {0, 1, 2}
+        node = np.tensordot(3 ** np.arange(self.dim), idx, axes=(0, 0))        # [e, i]
+        mvec = np.zeros(self.nodeNum)
+        np.add.at(mvec, node.reshape(-1), R.reshape(-1))
+        mdelta = np.zeros((self.dim, self.nodeNum))
+        mdelta[:, node.reshape(-1)] = self.elemCoord.reshape(self.dim, -1)
+        return mvec, mdelta
 
     # ------------------------------------------------------------------------------------
     def basisTable(self, hVec):
