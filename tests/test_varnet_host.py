@@ -424,3 +424,23 @@ def test_loss_lag_is_only_a_readback_schedule(tmp_path):
     res = vn.train(str(tmp_path / 'stop'), weight=[10., 10., 1.], epochNum=60, tol=0.95e6, saveFreq=100, verbose=False, lossLag=6)
     assert res.lossAll[-1] < 0.95e6 and all(v >= 0.95e6 for v in res.lossAll[:-1])
     assert len(res.lossAll) <= vn.engine.step <= len(res.lossAll) + 5
+
+
+def test_iter_plot_writes_the_reference_files(tmp_path):
+    """TrainResult.iterPlot (VarNetUtility.py:1634-1756): the five convergence plots under the reference's file names,
+    refreshed by iterOutput every 10 * saveFreq epochs; the epoch prefix when pltReplace is False."""
+    from varnet_amd.varnet import TrainResult
+    tr = TrainResult(str(tmp_path), True, verbose=False, saveFreq=2, pltReplace=True)
+    tr.trainWeight = np.array([10.0, 5.0, 1.0])
+    tr.lossComp.append(np.array([1.0, 2.0, 3.0]))
+    tr.inpIter = [8]
+    for ep in range(1, 21):
+        tr.iterOutput(ep, 100.0 / ep, 90.0 / ep, 0.01 * ep, 0.5 / ep, 0.2 / ep, np.array([1.0, 2.0, 3.0]) / ep, None)
+    plots = sorted(os.listdir(tr.plotpath))
+    assert plots == ['error.png', 'loss.png', 'lossComp.png', 'res_history.png', 'scaled_lossComp.png']
+    assert all(os.path.getsize(os.path.join(tr.plotpath, f)) > 1000 for f in plots)
+    tr.pltReplace = False
+    tr.iterPlot(pltFrmt='pdf')
+    assert '20_loss.pdf' in os.listdir(tr.plotpath)
+    with pytest.raises(ValueError):
+        tr.iterPlot(pltFrmt='bmp')

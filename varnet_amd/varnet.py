@@ -415,6 +415,74 @@ class TrainResult:
             if self.verbose:
                 print(msg, end='')
             self.writeCase(msg)
+            # The reference redraws its five figures here (1.2 s at 300 dpi).  Its epochs take seconds; here 10 * saveFreq
+            # epochs can pass in milliseconds, so a refresh is skipped while the last one is younger than `plotEvery`
+            # seconds and VarNet.train flushes the pending one when it returns: same files, same final content.
+            self._plot_dirty = True
+            if time.perf_counter() - getattr(self, '_plot_last', -1e30) >= getattr(self, 'plotEvery', 30.0):
+                self.iterPlot()
+
+    def flushPlots(self):
+        if getattr(self, '_plot_dirty', False):
+            self.iterPlot()
+
+    def iterPlot(self, plotpath=None, pltFrmt='png'):
+        """
+        Convergence plots the reference refreshes every 10 * saveFreq epochs (VarNetUtility.py:1634-1756), same file
+        names: `loss`, `lossComp`, `scaled_lossComp`, `res_history` and, with an exact solution, `error` (prefixed by
+        the epoch when pltReplace is False); dashed red lines mark the epochs at which the training set was redrawn.
+        """
+        if pltFrmt not in ('png', 'jpg', 'pdf', 'eps'):
+            raise ValueError('invalid plot format!')
+        self._plot_dirty = False
+        self._plot_last = time.perf_counter()
+        if self.folderpath is None or not self.iterSmp:          # a tower other than rank 0 keeps no files
+            return
+        import matplotlib
+        matplotlib.use('Agg', force=False)
+        import matplotlib.pyplot as plt
+        ext = '.' + pltFrmt
+        plotpath = self.plotpath if plotpath is None else plotpath
+        os.makedirs(plotpath, exist_ok=True)
+        pre = '' if self.pltReplace else '{}_'.format(self.iterSmp[-1])
+        png = pltFrmt == 'png'
+        it = np.asarray(self.iterSmp, dtype=float)
+        it0 = np.concatenate([[0.0], it])
+        comp = np.array([np.reshape(c, -1) for c in self.lossComp], dtype=float)
+
+        def finish(fig, name, ylabel, title, legend=None):
+            ax = fig.gca()
+            ax.set_xlabel('epochs')
+            ax.set_ylabel(ylabel)
+            ax.set_title(title if png else '')
+            if legend:
+                ax.legend(legend)
+            ax.grid(True)
+            fig.savefig(os.path.join(plotpath, pre + name + ext), dpi=300)
+            plt.close(fig)
+
+        fig = plt.figure()
+        fig.gca().semilogy(it, np.asarray(self.loss, dtype=float))
+        for i in (self.inpIter or []):
+            fig.gca().axvline(i, color='r', linestyle='--')
+        finish(fig, 'loss', 'loss function', 'convergence plot (variable grid)')
+        fig = plt.figure()
+        for col, c in zip(range(3), 'brg'):
+            fig.gca().semilogy(it0, comp[:, col], c)
+        finish(fig, 'lossComp', 'loss components', 'loss components plot', ['BC', 'IC', 'integral term'])
+        fig = plt.figure()
+        tot = np.asarray(self.trainWeight, dtype=float) * comp
+        for col, c in zip(range(3), 'brg'):
+            fig.gca().semilogy(it0, tot[:, col], c)
+        fig.gca().semilogy(it0, np.sum(tot, axis=1), 'k')
+        finish(fig, 'scaled_lossComp', 'loss components', 'scaled loss components plot', ['BC', 'IC', 'integral term', 'total loss'])
+        fig = plt.figure()
+        fig.gca().semilogy(it, np.asarray(self.residual, dtype=float))
+        finish(fig, 'res_history', 'residual', 'residual convergence plot')
+        if self.error is not None:
+            fig = plt.figure()
+            fig.gca().semilogy(it, np.asarray(self.error, dtype=float))
+            finish(fig, 'error', 'error', 'normalized solution error')
 
 
 # ======================================================================================
@@ -1250,6 +1318,7 @@ class VarNet:
                             weight = [5 * wv for wv in weight[:-1]] + [weight[-1]]
                         trainW, w_eff, _ = set_train_weights(tData, weight)
             epoch = first + nblk
+        trainRes.flushPlots()
         return trainRes
 
     # -- checkpoints ----------------------------------------------------------------------------------
