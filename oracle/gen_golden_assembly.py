@@ -593,6 +593,48 @@ def main():
         st['nnp_tf%d_B3_mat' % int(tfirst)] = _spio.loadmat(os.path.join(folder, 'NN_parameters', 'B3.mat'))['B3']
     RV.tf = sys.modules['tensorflow']
 
+    # Error behaviour of the kept constructor / methods: exception class and message of the reference for a list of
+    # invalid calls (tests/test_assembly_golden.py replays the same list on the build).
+    def err_of(fn):
+        try:
+            with _ctx.redirect_stdout(_io.StringIO()):
+                fn()
+        except Exception as e:                               # noqa: BLE001 -- the class is what is recorded
+            return '%s: %s' % (type(e).__name__, e)
+        return 'no error'
+
+    PU[0] = 1
+    v1 = RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2)
+    v1.tfData.sess, v1.tfData.model = MonitorSess(v1.tfData.compTowers[0], 1), (lambda t: ('model', t))
+    v1.tfData.graph, v1.tfData.saver = None, SaverRec()
+    v1.fixData.setFEdata()
+    vm_ = RV.VarNet(pde_m, layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, MORdiscScheme=disc, integPnum=2)
+    vm_.tfData = TowerRecord(1, 3)
+    vm_.tfData.sess, vm_.tfData.model = MonitorSess(vm_.tfData.compTowers[0], 1), (lambda t: ('model', t))
+    vm_.fixData.setFEdata()
+    tmpf = tempfile.mkdtemp()
+    calls = {
+        'ctor_layerWidth_not_list': lambda: RV.VarNet(pde1(), layerWidth=5, discNum=5, bDiscNum=None, tDiscNum=6),
+        'ctor_unknown_model': lambda: RV.VarNet(pde1(), layerWidth=[5], modelId='CNN', discNum=5, bDiscNum=None, tDiscNum=6),
+        'ctor_no_tDiscNum': lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=[]),
+        'ctor_bDiscNum_list': lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, tDiscNum=6),
+        'ctor_mor_without_scheme': lambda: RV.VarNet(pde_m, layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6),
+        'ctor_integPnum_4': lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=4),
+        'train_bad_scheme': lambda: v1.train(tmpf, smpScheme='adaptive', epochNum=1),
+        'train_weight_length': lambda: v1.train(tmpf, weight=[1., 2.], epochNum=1),
+        'train_batchNum_and_batchLen': lambda: v1.train(tmpf, weight=[1., 1., 1.], epochNum=1, batchNum=2, batchLen=5),
+        'eval_wrong_dim': lambda: v1.evaluate(np.zeros([3, 2]), 0.5),
+        'eval_t_mismatch': lambda: v1.evaluate(np.zeros([3, 1]), np.zeros([2, 1])),
+        'eval_mor_nothing_given': lambda: vm_.evaluate(),
+        'eval_mor_batch_too_high': lambda: vm_.evaluate(batch=7),
+        'eval_mor_arg_dim': lambda: vm_.evaluate(np.zeros([3, 1]), 0.5, MORarg=np.zeros([1, 2])),
+        'res_batch_too_high': lambda: vm_.residual(batch=7),
+        'simres_no_plotpath': lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6).simRes(),
+        'load_no_folder': lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6).loadModel(),
+    }
+    for name, fn in calls.items():
+        st['err_' + name] = np.array(err_of(fn))
+
     # (8) trainWeight arithmetic: the three branches on fixed loss triples, time-dependent and steady
     triples = np.array([[0.37, 1.9, 42.0], [1e-3, 5.0, 0.2], [12.5, 0.04, 3.3e3]])
     weights = [[10., 10., 1.], [5., 1., 1.], [1., 2., 3.]]
