@@ -632,6 +632,24 @@ def main():
         'simres_no_plotpath': lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6).simRes(),
         'load_no_folder': lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6).loadModel(),
     }
+    calls.update({
+        'pde_diff_type': lambda: RA.ADPDE(RD.Domain1D(), diff='k', vel=1.0),
+        'pde_vel_type': lambda: RA.ADPDE(RD.Domain1D(), diff=1.0, vel='v'),
+        'pde_source_type': lambda: RA.ADPDE(RD.Domain1D(), diff=1.0, vel=1.0, source='s'),
+        'pde_bcs_not_list': lambda: RA.ADPDE(RD.Domain1D(), diff=1.0, vel=1.0, BCs=(1, 2)),
+        'pde_bcs_count': lambda: RA.ADPDE(RD.Domain1D(), diff=1.0, vel=1.0, BCs=[[0., 1., 0.]]),
+        'pde_no_ic': lambda: RA.ADPDE(RD.Domain1D(), diff=1.0, vel=1.0, tInterval=[0, 1.0]),
+        'pde_cex_type': lambda: RA.ADPDE(RD.Domain1D(), diff=1.0, vel=1.0, cEx=3.0),
+        'pde_ddiff_type': lambda: RA.ADPDE(RD.Domain1D(), diff=1.0, vel=1.0, d_diff='g'),
+        'dom1d_interval': lambda: RD.Domain1D(np.array([[0., 1.], [2., 3.]])),
+        'dom1d_discnum': lambda: RD.Domain1D().getMesh([4, 5]),
+        'dom2d_vertices': lambda: RD.PolygonDomain2D(np.array([[0., 0., 0.], [1., 0., 0.], [0., 1., 0.]])),
+        'dom2d_obstacle': lambda: RD.PolygonDomain2D(np.array([[0., 0.], [1., 0.], [0., 1.]]), np.array([[.2, .2], [.3, .2], [.2, .3]])),
+        'dom2d_discnum': lambda: RD.PolygonDomain2D(np.array([[0., 0.], [1., 0.], [0., 1.]])).getMesh([4, 5, 6], 3),
+        'dom2d_isinside_dim': lambda: RD.PolygonDomain2D(np.array([[0., 0.], [1., 0.], [0., 1.]])).isInside(np.zeros([3, 3])),
+        'mor_handles_not_list': lambda: RM.MOR(diffFun, ['D'], [[0.003, 0.033]]) and RM.MOR('f', ['D'], [[0.003, 0.033]]),
+        'mor_handle_not_callable': lambda: RM.MOR([3.0], ['D'], [[0.003, 0.033]]),
+    })
     for name, fn in calls.items():
         st['err_' + name] = np.array(err_of(fn))
 

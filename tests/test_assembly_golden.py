@@ -639,6 +639,25 @@ def test_error_behaviour_matches_reference(tmp_path):
         'simres_no_plotpath': lambda: VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6).simRes(plot=True),
         'load_no_folder': lambda: VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6).loadModel(),
     }
+    tri = np.array([[0., 0.], [1., 0.], [0., 1.]])
+    calls.update({
+        'pde_diff_type': lambda: ADPDE(Domain1D(), diff='k', vel=1.0),
+        'pde_vel_type': lambda: ADPDE(Domain1D(), diff=1.0, vel='v'),
+        'pde_source_type': lambda: ADPDE(Domain1D(), diff=1.0, vel=1.0, source='s'),
+        'pde_bcs_not_list': lambda: ADPDE(Domain1D(), diff=1.0, vel=1.0, BCs=(1, 2)),
+        'pde_bcs_count': lambda: ADPDE(Domain1D(), diff=1.0, vel=1.0, BCs=[[0., 1., 0.]]),
+        'pde_no_ic': lambda: ADPDE(Domain1D(), diff=1.0, vel=1.0, tInterval=[0, 1.0]),
+        'pde_cex_type': lambda: ADPDE(Domain1D(), diff=1.0, vel=1.0, cEx=3.0),
+        'pde_ddiff_type': lambda: ADPDE(Domain1D(), diff=1.0, vel=1.0, d_diff='g'),
+        'dom1d_interval': lambda: Domain1D(np.array([[0., 1.], [2., 3.]])),
+        'dom1d_discnum': lambda: Domain1D().getMesh([4, 5]),
+        'dom2d_vertices': lambda: PolygonDomain2D(np.array([[0., 0., 0.], [1., 0., 0.], [0., 1., 0.]])),
+        'dom2d_obstacle': lambda: PolygonDomain2D(tri, np.array([[.2, .2], [.3, .2], [.2, .3]])),
+        'dom2d_discnum': lambda: PolygonDomain2D(tri).getMesh([4, 5, 6], 3),
+        'dom2d_isinside_dim': lambda: PolygonDomain2D(tri).isInside(np.zeros([3, 3])),
+        'mor_handles_not_list': lambda: MOR('f', ['D'], [[0.003, 0.033]]),
+        'mor_handle_not_callable': lambda: MOR([3.0], ['D'], [[0.003, 0.033]]),
+    })
     diffs = {}
     for name, fn in calls.items():
         got, want = err_of(fn), str(G['err_' + name])
