@@ -534,6 +534,10 @@ def main():
         st[g + 'inpIter'] = np.array(tr.inpIter, dtype=float)
         st[g + 'trainWeight'] = np.array(tr.trainWeight, dtype=float)
         st[g + 'nsteps'] = np.float64(sess.k)
+        lv = tr.lossVec                                   # list over MOR batches of the stacked loss field (or None)
+        st[g + 'lossVec_len'] = np.float64(-1 if lv is None else len(lv))
+        if lv is not None:
+            st[g + 'lossVec0'] = np.asarray(lv[0], dtype=float)
 
     L = 1000.0 / (1.0 + np.arange(400.0))                 # the scripted training losses, one per sess.run of a mini-batch
     scripted_train('uniform', lambda: RV.VarNet(pde1(), layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, integPnum=2), L, 1,

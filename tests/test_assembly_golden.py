@@ -550,6 +550,11 @@ def _scripted_train(monkeypatch, tmp_path, tag, vn, **targ):
         np.testing.assert_allclose(np.array(res.error, dtype=float), G[g + 'error'], rtol=1e-12)
     np.testing.assert_allclose(np.array(res.inpIter, dtype=float), G[g + 'inpIter'])
     np.testing.assert_allclose(np.asarray(res.trainWeight, dtype=float), G[g + 'trainWeight'], rtol=1e-12)
+    if int(G[g + 'lossVec_len']) < 0:
+        assert res.lossVec is None
+    else:                                               # the loss field kept for simRes: a list over MOR batches
+        assert len(res.lossVec) == int(G[g + 'lossVec_len'])
+        np.testing.assert_allclose(np.asarray(res.lossVec[0], dtype=float).reshape(-1, 1), G[g + 'lossVec0'].reshape(-1, 1), **TOL)
 
 
 def test_epoch_loop_matches_reference_uniform(monkeypatch, tmp_path):
