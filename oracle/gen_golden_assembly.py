@@ -547,6 +547,24 @@ def main():
                    weight=[5., 1., 1.], smpScheme='optimal', frac=0.25, addTrainPts=True, suppFactor=1.0, epochNum=8, tol=1e-9,
                    saveFreq=2, multiTrainUpd=False, trainUpdelay=3, tolUpd=1e9, reinitrain=False, adjustWeight=True)
     # (saveFreq=1 cannot be scripted: TrainResult.iterOutput then never sets avgtime0 and raises, VarNetUtility.py:1582,1607)
+    # parametric problem: the kappa batches inside an epoch, mini-batches inside a kappa batch, one reshuffle for all
+    # batches, the saveMORdata store (VarNet.py:1350-1357)
+    import MOR as RM_
+
+    def diffFun_(x, t=0, D=0.01):
+        return D * np.ones([np.shape(x)[0], 1])
+
+    def disc_(discNum=3):
+        return np.array([0.003 * (11 ** (n / (discNum - 1))) for n in range(discNum)])[np.newaxis].T
+
+    def mk_mor():
+        pde_ = RA.ADPDE(RD.Domain1D(), diff=diffFun_, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                        IC=lambda x: -np.sin(np.pi * x), MORvar=RM_.MOR(diffFun_, ['D'], [[0.003, 0.033]]))
+        v = RV.VarNet(pde_, layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, MORdiscScheme=disc_, integPnum=2)
+        v.tfData = TowerRecord(1, 3)
+        return v
+    scripted_train('mor', mk_mor, L, 1, weight=[10., 10., 1.], smpScheme='uniform', epochNum=5, tol=1e-9, saveFreq=2,
+                   batchNum=2, shuffleData=True, shuffleFreq=2, saveMORdata=True)
 
     # saveNNparam (VarNet.py:2179-2260): per-layer [W (out x in), b (out x 1)], the timeFirst column move, the MATLAB and
     # Diffpack files.  The trainable variables come from `tf.trainable_variables()` + `sess.run`: a list of named tokens

@@ -677,3 +677,21 @@ def test_error_behaviour_matches_reference(tmp_path):
         if got != want:
             diffs[name] = (got, want)
     assert not diffs, diffs
+
+
+def test_epoch_loop_matches_reference_mor(monkeypatch, tmp_path):
+    """Parametric problem: kappa batches inside an epoch, two mini-batches inside each, one reshuffle for all batches,
+    saveMORdata: the same order of steps and rows as the reference's loop."""
+    from varnet_amd.mor import MOR
+
+    def diffFun(x, t=0, D=0.01):
+        return D * np.ones([np.shape(x)[0], 1])
+
+    def disc(discNum=3):
+        return np.array([0.003 * (11 ** (n / (discNum - 1))) for n in range(discNum)])[np.newaxis].T
+
+    pde = ADPDE(Domain1D(), diff=diffFun, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                IC=lambda x: -np.sin(np.pi * x), MORvar=MOR(diffFun, ['D'], [[0.003, 0.033]]))
+    vn = VarNet(pde, layerWidth=[5], discNum=5, bDiscNum=None, tDiscNum=6, MORdiscScheme=disc, integPnum=2)
+    _scripted_train(monkeypatch, tmp_path, 'mor', vn, weight=[10., 10., 1.], smpScheme='uniform', epochNum=5, tol=1e-9,
+                    saveFreq=2, batchNum=2, shuffleData=True, shuffleFreq=2, saveMORdata=True)
