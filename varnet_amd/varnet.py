@@ -438,9 +438,12 @@ class TrainResult:
         self._plot_last = time.perf_counter()
         if self.folderpath is None or not self.iterSmp:          # a tower other than rank 0 keeps no files
             return
-        import matplotlib
-        matplotlib.use('Agg', force=False)
-        import matplotlib.pyplot as plt
+        try:
+            import matplotlib
+            matplotlib.use('Agg', force=False)
+            import matplotlib.pyplot as plt
+        except ImportError:                                   # no plotting library: the records in trainData.vn remain
+            return
         ext = '.' + pltFrmt
         plotpath = self.plotpath if plotpath is None else plotpath
         os.makedirs(plotpath, exist_ok=True)
