@@ -47,9 +47,21 @@ def _setup(case, kernel, act='sigmoid'):
     return eng, d, flat
 
 
+def _tile_kernels_take(widths, d_in):
+    """vn_wide_supported (vn_wide.hip): up to 4 hidden layers of width <= 128, or 5-6 of width <= 96, at most 32 inputs"""
+    return d_in <= 32 and max(widths) <= 128 and (len(widths) <= 4 or (len(widths) <= 6 and max(widths) <= 96))
+
+
+@pytest.mark.parametrize('impl', ['tile-kernels', 'gemms'])
 @pytest.mark.parametrize('case', CASES)
-def test_loss_and_grad_parity_layered(case):
+def test_loss_and_grad_parity_layered(case, impl, monkeypatch):
+    """Both implementations of the route against the fp64 oracle: the tile kernels of vn_wide.hip (nets up to 128 wide) and the
+    GEMM form (every net; VN_LAYERED_NOWIDE=1 keeps a net the tile kernels would take on it)."""
     d_in, dim, widths, integNum, n_k, nB, bDof, source, integW, detJvec = case
+    if impl == 'gemms':
+        monkeypatch.setenv('VN_LAYERED_NOWIDE', '1')
+    elif not _tile_kernels_take(widths, d_in):
+        pytest.skip('beyond the tile kernels: covered by the gemms variant')
     eng, d, flat = _setup(case, LAYERED)
     assert eng.kernel_path()[0] == LAYERED
     if len(widths) > 8 or max(widths) > 64 or d_in > 8 or (len(widths) > 6 and max(widths) > 50):
@@ -92,11 +104,14 @@ def test_layered_tanh_and_agreement_with_the_kernels():
 
 
 @pytest.mark.parametrize('keep', [True, False], ids=['kept-activations', 'recompute'])
-def test_layered_chunks_and_shard_additivity(keep, monkeypatch):
+@pytest.mark.parametrize('widths', [[96, 96, 96], [160, 144]], ids=['tile-kernels', 'gemms'])
+def test_layered_chunks_and_shard_additivity(widths, keep, monkeypatch):
     """Both forms of the reverse pass: reading the activations the forward kept in HBM, and recomputing them per chunk
-    (VN_LAYERED_NOKEEP=1, what happens when they do not fit).  1.28 M rows of a 3 x 96 net do not fit the route's workspace in one piece: the interior set is processed in several
-    chunks, and the same set fed as two halves (chunked differently) sums to the same gradient and loss."""
-    d_in, dim, widths, integNum, n_k, nB, bDof = 3, 2, [96, 96, 96], 64, 20000, 3000, 1700
+    (VN_LAYERED_NOKEEP=1, what happens when they do not fit).  1.28 M rows do not fit the route's workspace in one piece: the
+    interior set is processed in several chunks, and the same set fed as two halves (chunked differently) sums to the same
+    gradient and loss.  Up to 128 wide the kept form runs on the tile kernels of vn_wide.hip and the recompute form on
+    the GEMMs (two implementations: agreement to fp32 rounding); beyond, both forms are the GEMMs and give the same bits."""
+    d_in, dim, integNum, n_k, nB, bDof = 3, 2, 64, 20000, 3000, 1700
     d = synth(7, d_in, dim, widths, integNum, n_k, nB, bDof)
     if not keep:
         monkeypatch.setenv('VN_LAYERED_NOKEEP', '1')
@@ -126,10 +141,14 @@ def test_layered_chunks_and_shard_additivity(keep, monkeypatch):
     assert abs(s[eng.P] - g[eng.P]) <= 1e-5 * abs(g[eng.P])
     eng.close()
     # the two forms of the reverse pass give the same bits (same chunks, same kernels, same order)
-    key = 'layered_chunks_grad'
+    key = 'layered_chunks_grad_%d' % widths[0]
     prev = getattr(test_layered_chunks_and_shard_additivity, key, None)
     if prev is not None:
-        assert np.array_equal(prev, g)
+        if max(widths) > 128:
+            assert np.array_equal(prev, g)
+        else:
+            assert np.max(np.abs(prev[:-4] - g[:-4])) <= 3e-5 * np.max(np.abs(g[:-4]))
+            assert abs(prev[-4] - g[-4]) <= 1e-5 * abs(g[-4])
     setattr(test_layered_chunks_and_shard_additivity, key, g)
 
 

@@ -160,3 +160,18 @@ int vn_layered_residual_f32(VnLayered* w, const float* theta, const float* X, co
 int vn_layered_residual_f64(VnLayered* w, const double* theta, const double* X, const double* diff, const double* vel,
                             const double* src, const double* ddx, int td, long n, double* u, double* res, hipStream_t s,
                             char* err, size_t errlen);
+
+// ---- tile kernels of the layer-by-layer route for hidden widths <= 128: vn_wide.hip -------------------------------
+// A workgroup carries 32 points through all layers with the activations in LDS; the forward stores (a, ad) of every layer
+// in HBM for the reverse kernel.  vn_layered.hip hands qualifying networks over (VN_LAYERED_NOWIDE=1 keeps them on the GEMMs).
+struct VnWide;
+bool vn_wide_supported(const VnNet& net);
+int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen);
+void vn_wide_destroy(VnWide* w);
+// u (and ud) at seg.n rows; keep_slot >= 0 and may_keep: store the activations for vn_wide_backward (if they fit)
+int vn_wide_forward(VnWide* w, const float* theta, const VnRows& seg, int keep_slot, bool may_keep, hipStream_t s, char* err,
+                    size_t errlen);
+bool vn_wide_has_kept(const VnWide* w, int slot, const VnRows& seg);
+// grad[0..P) += d loss / d theta from the rows of seg (needs the activations stored by the forward of the same rows)
+int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* grad, int keep_slot, hipStream_t s, char* err,
+                     size_t errlen);

@@ -353,6 +353,7 @@ struct VnLayered {
     const float* X = nullptr; long n = 0, c = 0; int S = 0; bool valid = false;
   } kept[2];
   bool never_keep = false;                      // VN_LAYERED_NOKEEP=1: always recompute (tests run both ways)
+  VnWide* wide = nullptr;                       // tile kernels for the training passes of nets up to 128 wide (vn_wide.hip)
 };
 
 namespace {
@@ -454,12 +455,19 @@ int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errle
   }
   // no atomics: the weight-gradient GEMMs reduce over millions of rows and must give the same bits on every run
   (void)g_blas.set_atomics_mode(w->handle, rocblas_atomics_not_allowed);
+  if (vn_wide_supported(net)) {
+    if (int rc = vn_wide_create(&w->wide, net, err, errlen)) {
+      vn_layered_destroy(w);
+      return rc;
+    }
+  }
   *out = w;
   return 0;
 }
 
 void vn_layered_destroy(VnLayered* w) {
   if (!w) return;
+  vn_wide_destroy(w->wide);
   if (w->handle) (void)g_blas.destroy_handle(w->handle);
   if (w->ws) (void)hipFree(w->ws);
   if (w->part) (void)hipFree(w->part);
@@ -528,6 +536,7 @@ int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipS
                        int keep_slot) {
   if (keep_slot >= 0) w->kept[keep_slot].valid = false;
   if (seg.n <= 0) return 0;
+  if (w->wide) return vn_wide_forward(w->wide, theta, seg, keep_slot, !w->never_keep, s, err, errlen);
   const VnNet& net = w->net;
   const int S = (seg.G && seg.ud) ? 2 : 1;
   LBLAS(g_blas.set_stream(w->handle, s));
@@ -574,6 +583,8 @@ int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipS
 int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, float* grad, hipStream_t s, char* err,
                         size_t errlen, int keep_slot) {
   if (seg.n <= 0) return 0;
+  // activations stored by the tile kernels' forward: their reverse kernel; else the GEMMs below recompute per chunk
+  if (w->wide && vn_wide_has_kept(w->wide, keep_slot, seg)) return vn_wide_backward(w->wide, theta, seg, grad, keep_slot, s, err, errlen);
   const VnNet& net = w->net;
   const int S = (seg.G && seg.udbar) ? 2 : 1;
   LBLAS(g_blas.set_stream(w->handle, s));

@@ -1,0 +1,552 @@
+// Tile kernels of the layer-by-layer route for hidden widths up to 128 (vn_layered.hip hands such networks over).
+//
+// Why: with one GEMM per layer a 128-wide layer moves 16 B of HBM per 2*128 FLOP in each direction -- the GEMM route is
+// HBM-bound there (3 x 128 at 6.4 M points: 91 ms = 0.18 of the fp32 MFMA peak).  Here a workgroup carries a tile of 32
+// points (64 columns: value | tangent) through ALL layers with the activations in LDS, so HBM sees the inputs, the
+// outputs and one write + one read of the stored activations (a_l, ad_l), nothing else.
+//
+// Same (value, one tangent) recurrences as every other route (oracle/tangent_ref.py; TFModel.py:536 input gradient,
+// :653-661 integrand, :709 parameter gradient):
+//   forward  z = W^T a + b, zd = W^T ad, a' = act(z), ad' = act'(z) zd
+//   reverse  zdbar = s1 adbar, zbar = s1 abar + s2r ad adbar, abar_{l-1} = W zbar, dW = a zbar^T + ad zdbar^T
+//
+// Geometry (8 waves, v_mfma_f32_16x16x4_f32):
+//   * activations of a tile: LDS matrix [feature][64 columns], row stride 81 (row-wise and transposed reads both
+//     spread over the banks);
+//   * a layer is D[feature x column] = W^T[feature x k] A[k x column]: wave w owns the 16 features of row tile w and all
+//     four column tiles (value 0..15, 16..31 | tangent 0..15, 16..31), so value and tangent of one (feature, point) sit
+//     in the same lane and the activation runs in registers -- one workgroup barrier per layer, no elementwise sweep;
+//   * weights never touch LDS: a tiny pack kernel rewrites W (and W^T for the reverse pass) in MFMA fragment order
+//     ([row tile][k quad][lane][4 k-steps]) once per call, a wave streams its fragments from L2 with one coalesced
+//     16-byte load per 16 MFMAs, three loads in flight;
+//   * forward writes (a_l | ad_l) of every layer to HBM in accumulator order ([tile][layer][row tile][column tile]
+//     [lane][4]: 1 KB per store instruction), the reverse kernel reads them back with the same wave assignment, one
+//     layer ahead of their use;
+//   * reverse: per layer the weight gradient contracts over the 64 columns with both operands read transposed from
+//     LDS; the 8 waves are a 4 x 2 grid of 2 x BN blocks of 16 x 16 output tiles (2 + BN fragment reads for 2 BN
+//     MFMAs), accumulated in registers over all tiles of the launch and written once as a per-workgroup partial that a
+//     fixed-order sum adds to the gradient (no atomics: same bits every run); the input gradient is the forward loop with
+//     the W^T image, its epilogue forms (zbar, zdbar) of the layer below in registers.  Two barriers per layer.
+#include "vn_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TP = 32;        // points per tile
+constexpr int LDW = 81;       // LDS row stride (floats)
+constexpr int NT = 512;       // threads per workgroup
+constexpr int WL = 6;         // most hidden layers these kernels take
+
+struct Plan {
+  int nrt[WL + 1];    // 16-row tiles of layer l's activations (l = 0: the inputs)
+  int wfo[WL + 1];    // float offset of layer l's fragment image for the forward GEMM (l = 1..L)
+  int wto[WL + 1];    // ... for the input-gradient GEMM (W^T; l = 2..L)
+  int ko[WL + 1];     // float offset of layer l's (a | ad) inside a tile's block of stored activations (l = 1..L)
+  int kept_tile;      // floats per tile
+  int rows;           // LDS rows per matrix
+  int wf_floats;      // both images
+};
+
+__device__ __forceinline__ float w_act(float z, int act) {
+  if (act == VN_ACT_TANH) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * z)) - 1.0f;
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+}
+__device__ __forceinline__ float w_d1(float a, int act) { return act == VN_ACT_TANH ? 1.f - a * a : a * (1.f - a); }
+__device__ __forceinline__ float w_d2r(float a, int act) { return act == VN_ACT_TANH ? -2.f * a : 1.f - 2.f * a; }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// ---- fragment images of the weights ---------------------------------------------------------------------------------
+// forward image of layer l:   [rt][q][lane][j] = W[k][m],  k = 16 q + 4 j + lane/16 (input),  m = 16 rt + lane%16 (output)
+// transposed image (l >= 2):  [rt][q][lane][j] = W[r][n],  r = 16 rt + lane%16 (input),      n = 16 q + 4 j + lane/16 (output)
+// zero outside the matrix, so padded rows and k-steps contribute nothing.
+__global__ __launch_bounds__(256) void vn_wide_pack_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
+                                                           float* __restrict__ wf) {
+  const int l = blockIdx.y + 1;
+  const int Hin = net.H[l - 1], Hout = net.H[l];
+  const float* W = theta + net.woff[l];
+  const int nf = pl.nrt[l] * pl.nrt[l - 1] * 256;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 2 * nf; idx += gridDim.x * 256) {
+    const bool tr = idx >= nf;
+    if (tr && l == 1) break;
+    const int e = tr ? idx - nf : idx;
+    const int j = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
+    const int nq = tr ? pl.nrt[l] : pl.nrt[l - 1];
+    const int q = blk % nq, rt = blk / nq;
+    const int kk = 16 * q + 4 * j + (lane >> 4), mm = 16 * rt + (lane & 15);
+    float v = 0.f;
+    if (!tr) { if (kk < Hin && mm < Hout) v = W[kk * Hout + mm]; }
+    else     { if (mm < Hin && kk < Hout) v = W[mm * Hout + kk]; }
+    wf[(tr ? pl.wto[l] : pl.wfo[l]) + e] = v;
+  }
+}
+
+__device__ __forceinline__ void load_tile_inputs(const VnNet& net, const VnRows& sg, long r0, int rows0, float* dst, int tid) {
+  const int d_in = net.d_in, dim = net.dim;
+  for (int i = tid; i < rows0 * 64; i += NT) {
+    const int k = i >> 6, c = i & 63;
+    const long row = r0 + (c & (TP - 1));
+    float v = 0.f;
+    if (row < sg.n && k < d_in) {
+      if (c < TP) v = sg.X[row * d_in + k];
+      else if (sg.G != nullptr && k < dim) v = sg.G[row * dim + k];
+    }
+    dst[k * LDW + c] = v;
+  }
+}
+
+// acc[ct] += sum_k Wimage[this wave's row tile][k] * B[k][16 ct + lm]: the GEMM of a layer (forward: B = activations of the
+// layer below; reverse: B = (zbar | zdbar), image = W^T).  nq = k quads of 16.
+__device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wave, int lane, int nq, const float* B, f32x4 acc[4]) {
+  const int lm = lane & 15, lk = lane >> 4;
+  const f32x4* wp = (const f32x4*)img + (long)wave * nq * 64 + lane;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 w0 = wp[0];
+  f32x4 w1 = nq > 1 ? wp[64] : zero4;
+  f32x4 w2 = nq > 2 ? wp[128] : zero4;
+  for (int q = 0; q < nq; ++q) {
+    const f32x4 wn = (q + 3 < nq) ? wp[(q + 3) * 64] : zero4;
+    const float* cb = B + (16 * q + lk) * LDW + lm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float av = w0[j];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av, cb[4 * j * LDW + 16 * ct], acc[ct]);
+    }
+    w0 = w1; w1 = w2; w2 = wn;
+  }
+}
+
+// ---- forward: rows -> (u, ud) [+ stored activations] ----------------------------------------------------------------
+__global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
+                                                         const float* __restrict__ wf, VnRows sg, long ntiles,
+                                                         float* __restrict__ kept) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lk = lane >> 4;
+  float* buf0 = lds;
+  float* buf1 = lds + pl.rows * LDW;
+  float* red = buf1 + pl.rows * LDW;         // [8][64]
+  const int L = net.L;
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long r0 = tile * TP;
+    load_tile_inputs(net, sg, r0, 16 * pl.nrt[0], buf0, tid);
+    __syncthreads();
+    float* cur = buf0;
+    float* nxt = buf1;
+    for (int l = 1; l <= L; ++l) {
+      if (wave < pl.nrt[l]) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wave_gemm(wf + pl.wfo[l], wave, lane, pl.nrt[l - 1], cur, acc);
+        const int Hout = net.H[l], act = net.actl[l];
+        const float* bias = theta + net.boff[l];
+        f32x4 av[2], adv[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * wave + 4 * lk + i;
+          const bool valid = m < Hout;
+          const float b = valid ? bias[m] : 0.f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float a = valid ? w_act(acc[h][i] + b, act) : 0.f;
+            const float ad = valid ? w_d1(a, act) * acc[2 + h][i] : 0.f;
+            av[h][i] = a; adv[h][i] = ad;
+            nxt[m * LDW + 16 * h + lm] = a;
+            nxt[m * LDW + 32 + 16 * h + lm] = ad;
+          }
+        }
+        if (kept != nullptr) {
+          f32x4* kp = (f32x4*)(kept + tile * pl.kept_tile + pl.ko[l] + wave * 1024);
+          kp[lane] = av[0]; kp[64 + lane] = av[1]; kp[128 + lane] = adv[0]; kp[192 + lane] = adv[1];
+        }
+      }
+      __syncthreads();
+      float* t = cur; cur = nxt; nxt = t;
+    }
+    // u = w_o . a_L + b_o,  ud = w_o . ad_L : eight 16-feature slices per column, added in a fixed order
+    {
+      const int HL = net.H[L];
+      const float* wo = theta + net.woff[L + 1];
+      const int c = tid & 63, k0 = 16 * (tid >> 6);
+      float p = 0.f;
+      for (int k = k0; k < k0 + 16 && k < HL; ++k) p += wo[k] * cur[k * LDW + c];
+      red[tid] = p;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float acc = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) acc += red[sl * 64 + tid];
+      const long row = r0 + (tid & (TP - 1));
+      if (row < sg.n) {
+        if (tid < TP) { if (sg.u != nullptr) sg.u[row] = acc + theta[net.boff[L + 1]]; }
+        else if (sg.ud != nullptr) sg.ud[row] = acc;
+      }
+    }
+  }
+}
+
+// ---- reverse: rows + seeds + stored activations -> per-workgroup partial parameter gradient ---------------------------
+template <int ML, int BN>
+__global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
+                                                         const float* __restrict__ wf, VnRows sg, long ntiles,
+                                                         const float* __restrict__ kept, float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lk = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* T = lds;                            // (zbar | zdbar) of the current layer
+  float* PV = lds + pl.rows * LDW;           // (a | ad) of the layer below (layer 1: the inputs)
+  float* sub = PV + pl.rows * LDW;           // [TP] ubar
+  float* sudb = sub + TP;                    // [TP] udbar
+  const int L = net.L;
+
+  f32x4 wacc[ML][2 * BN];
+  float bacc[ML];
+#pragma unroll
+  for (int l = 0; l < ML; ++l) {
+    bacc[l] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * BN; ++j) wacc[l][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float woacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float boacc = 0.f;
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long r0 = tile * TP;
+    const float* kt = kept + tile * pl.kept_tile;
+    if (tid < TP) {
+      const long row = r0 + tid;
+      sub[tid] = (row < sg.n) ? sg.ubar[row] : 0.f;
+      sudb[tid] = (row < sg.n && sg.udbar != nullptr) ? sg.udbar[row] : 0.f;
+    }
+    f32x4 ka[4], kn[4];
+    const bool ownL = wave < pl.nrt[L];
+    if (ownL) {
+      const f32x4* kp = (const f32x4*)(kt + pl.ko[L] + wave * 1024);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) ka[ct] = kp[ct * 64 + lane];
+    }
+    if (L > 1 && wave < pl.nrt[L - 1]) {
+      const f32x4* kp = (const f32x4*)(kt + pl.ko[L - 1] + wave * 1024);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) kn[ct] = kp[ct * 64 + lane];
+    }
+    __syncthreads();        // seeds visible; every wave is past the previous tile's reads of T and PV
+
+    // output layer: d w_o, d b_o and (zbar | zdbar) of the last hidden layer
+    if (ownL) {
+      const int HL = net.H[L], act = net.actl[L];
+      const float* wo = theta + net.woff[L + 1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 16 * wave + 4 * lk + i;
+        const bool valid = m < HL;
+        const float wom = valid ? wo[m] : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int c = 16 * h + lm;
+          const float ub = sub[c], udb = sudb[c];
+          const float a = ka[h][i], ad = ka[2 + h][i];
+          woacc[i] += ub * a + udb * ad;
+          const float ab = ub * wom, adb = udb * wom;
+          const float sp = w_d1(a, act);
+          T[m * LDW + c] = valid ? ab * sp + w_d2r(a, act) * ad * adb : 0.f;
+          T[m * LDW + 32 + c] = valid ? adb * sp : 0.f;
+        }
+      }
+    }
+    if (wave == 0 && lane < TP) boacc += sub[lane];
+
+#pragma unroll
+    for (int l = ML; l >= 1; --l) {
+      if (l <= L) {
+        const int Hout = net.H[l];
+        const bool own = l > 1 && wave < pl.nrt[l - 1];
+        f32x4 kb[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) kb[ct] = kn[ct];
+        if (l > 1) {
+          if (own) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int m = 16 * wave + 4 * lk + i;
+#pragma unroll
+              for (int ct = 0; ct < 4; ++ct) PV[m * LDW + 16 * ct + lm] = kb[ct][i];
+            }
+          }
+        } else {
+          load_tile_inputs(net, sg, r0, 16 * pl.nrt[0], PV, tid);
+        }
+        __syncthreads();      // #1: T and PV of this layer complete
+        if (l > 2 && wave < pl.nrt[l - 2]) {
+          const f32x4* kp = (const f32x4*)(kt + pl.ko[l - 2] + wave * 1024);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) kn[ct] = kp[ct * 64 + lane];
+        }
+        // bias gradient: row sums of the value columns
+        if (tid < Hout) {
+          float acc = 0.f;
+          for (int c = 0; c < TP; ++c) acc += T[tid * LDW + c];
+          bacc[l - 1] += acc;
+        }
+        // weight gradient: G[k][n] += sum_col PV[k][col] T[n][col]
+        {
+          const int ntm = pl.nrt[l - 1], ntn = pl.nrt[l];
+          const int tm0 = 2 * wm, tn0 = BN * wn;
+          if (tm0 < ntm && tn0 < ntn) {
+            const float* pa = PV + (16 * tm0 + lm) * LDW + lk;
+            const float* pb = T + (16 * tn0 + lm) * LDW + lk;
+            const bool a1 = tm0 + 1 < ntm;
+            for (int cs = 0; cs < 16; ++cs) {
+              const float av0 = pa[4 * cs];
+              const float av1 = a1 ? pa[16 * LDW + 4 * cs] : 0.f;
+#pragma unroll
+              for (int b = 0; b < BN; ++b) {
+                if (tn0 + b < ntn) {
+                  const float bv = pb[16 * b * LDW + 4 * cs];
+                  wacc[l - 1][b] = mfma16(av0, bv, wacc[l - 1][b]);
+                  if (a1) wacc[l - 1][BN + b] = mfma16(av1, bv, wacc[l - 1][BN + b]);
+                }
+              }
+            }
+          }
+        }
+        // input gradient of the layer: (abar | adbar)_{l-1}[k][col] = sum_n W[k][n] T[n][col]
+        f32x4 acc[4];
+        if (own) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+          wave_gemm(wf + pl.wto[l], wave, lane, pl.nrt[l], T, acc);
+        }
+        __syncthreads();      // #2: every wave is done reading T and PV
+        if (own) {
+          const int Hp = net.H[l - 1], actp = net.actl[l - 1];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = 16 * wave + 4 * lk + i;
+            const bool valid = m < Hp;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float a = kb[h][i], ad = kb[2 + h][i];
+              const float ab = acc[h][i], adb = acc[2 + h][i];
+              const float sp = w_d1(a, actp);
+              T[m * LDW + 16 * h + lm] = valid ? ab * sp + w_d2r(a, actp) * ad * adb : 0.f;
+              T[m * LDW + 32 + 16 * h + lm] = valid ? adb * sp : 0.f;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- this workgroup's partial gradient (flat parameter layout) ----
+  float* out = partial + (long)blockIdx.x * net.P;
+#pragma unroll
+  for (int l = 1; l <= ML; ++l) {
+    if (l <= L) {
+      const int Hin = net.H[l - 1], Hout = net.H[l];
+      const int ntm = pl.nrt[l - 1], ntn = pl.nrt[l];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < BN; ++b) {
+          const int tm = 2 * wm + a, tn = BN * wn + b;
+          if (tm < ntm && tn < ntn) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = 16 * tm + 4 * lk + i, col = 16 * tn + lm;
+              if (row < Hin && col < Hout) out[net.woff[l] + row * Hout + col] = wacc[l - 1][a * BN + b][i];
+            }
+          }
+        }
+      }
+      if (tid < Hout) out[net.boff[l] + tid] = bacc[l - 1];
+    }
+  }
+  {
+    const int HL = net.H[L];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = woacc[i];
+      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+      const int m = 16 * wave + 4 * lk + i;
+      if (lm == 0 && m < HL) out[net.woff[L + 1] + m] = v;
+    }
+    if (wave == 0) {
+      float v = lane < TP ? boacc : 0.f;
+      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) out[net.boff[L + 1]] = v;
+    }
+  }
+}
+
+// dst[i] += sum_b part[b][i], fixed order
+__global__ __launch_bounds__(256) void vn_wide_sum_kernel(const float* __restrict__ part, int nparts, long len, float* __restrict__ dst) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  float acc = 0.f;
+  for (int b = 0; b < nparts; ++b) acc += part[(long)b * len + i];
+  dst[i] += acc;
+}
+
+int wfail(char* err, size_t n, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (err && n) vsnprintf(err, n, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+#define WHIP(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return wfail(err, errlen, "%s: %s", #expr, hipGetErrorString(e_));    \
+  } while (0)
+
+}  // namespace
+
+struct VnWide {
+  VnNet net{};
+  Plan pl{};
+  bool deep = false;            // <6,3> instantiation (5-6 layers, widths <= 96) instead of <4,4>
+  int cus = 256;
+  size_t lds_f = 0, lds_b = 0;
+  float* wf = nullptr;
+  float* part = nullptr;
+  struct Kept { float* buf = nullptr; size_t cap = 0; const float* X = nullptr; long n = 0; bool valid = false; } kept[2];
+};
+
+bool vn_wide_supported(const VnNet& net) {
+  const char* off = getenv("VN_LAYERED_NOWIDE");
+  if (off && *off && *off != '0') return false;
+  if (net.L < 1 || net.L > WL || net.d_in > 32) return false;
+  int hmax = 0;
+  for (int l = 1; l <= net.L; ++l) {
+    if (net.H[l] > hmax) hmax = net.H[l];
+    if (net.actl[l] != VN_ACT_SIGMOID && net.actl[l] != VN_ACT_TANH) return false;
+  }
+  if (hmax > 128) return false;
+  if (net.L > 4 && hmax > 96) return false;      // weight-gradient accumulators of 5-6 layers wider than 96 exceed the registers
+  return true;
+}
+
+int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
+  *out = nullptr;
+  VnWide* w = new VnWide();
+  w->net = net;
+  Plan& pl = w->pl;
+  int rows = 0, off = 0, koff = 0;
+  for (int l = 0; l <= net.L; ++l) {
+    pl.nrt[l] = (net.H[l] + 15) / 16;
+    if (16 * pl.nrt[l] > rows) rows = 16 * pl.nrt[l];
+  }
+  for (int l = 1; l <= net.L; ++l) {
+    const int nf = pl.nrt[l] * pl.nrt[l - 1] * 256;
+    pl.wfo[l] = off; off += nf;
+    pl.wto[l] = off; if (l > 1) off += nf;
+    pl.ko[l] = koff; koff += pl.nrt[l] * 1024;
+  }
+  pl.wf_floats = off; pl.kept_tile = koff; pl.rows = rows;
+  w->deep = net.L > 4;
+  w->lds_f = ((size_t)2 * rows * LDW + 512) * sizeof(float);
+  w->lds_b = ((size_t)2 * rows * LDW + 2 * TP) * sizeof(float);
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    w->cus = prop.multiProcessorCount;
+  hipError_t e = hipFuncSetAttribute((const void*)vn_wide_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_f);
+  if (e == hipSuccess)
+    e = w->deep ? hipFuncSetAttribute((const void*)vn_wide_bwd_kernel<6, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b)
+                : hipFuncSetAttribute((const void*)vn_wide_bwd_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
+  if (e == hipSuccess) e = hipMalloc((void**)&w->wf, (size_t)pl.wf_floats * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * net.P * sizeof(float));
+  if (e != hipSuccess) {
+    vn_wide_destroy(w);
+    return wfail(err, errlen, "vn_wide_create: %s", hipGetErrorString(e));
+  }
+  *out = w;
+  return 0;
+}
+
+void vn_wide_destroy(VnWide* w) {
+  if (!w) return;
+  if (w->wf) (void)hipFree(w->wf);
+  if (w->part) (void)hipFree(w->part);
+  for (auto& k : w->kept) if (k.buf) (void)hipFree(k.buf);
+  delete w;
+}
+
+namespace {
+int pack(VnWide* w, const float* theta, hipStream_t s, char* err, size_t errlen) {
+  hipLaunchKernelGGL(vn_wide_pack_kernel, dim3(32, w->net.L), dim3(256), 0, s, w->net, w->pl, theta, w->wf);
+  WHIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int vn_wide_forward(VnWide* w, const float* theta, const VnRows& seg, int keep_slot, bool may_keep, hipStream_t s, char* err,
+                    size_t errlen) {
+  if (keep_slot >= 0) w->kept[keep_slot].valid = false;
+  if (seg.n <= 0) return 0;
+  const long ntiles = (seg.n + TP - 1) / TP;
+  float* kbuf = nullptr;
+  if (keep_slot >= 0 && may_keep) {
+    VnWide::Kept& k = w->kept[keep_slot];
+    const size_t need = (size_t)ntiles * w->pl.kept_tile;
+    bool ok = need <= k.cap;
+    if (!ok) {
+      size_t fr = 0, tot = 0;
+      if (hipMemGetInfo(&fr, &tot) == hipSuccess && (need - k.cap) * sizeof(float) <= fr / 2) {
+        if (k.buf) (void)hipFree(k.buf);
+        k.buf = nullptr; k.cap = 0;
+        if (hipMalloc((void**)&k.buf, need * sizeof(float)) == hipSuccess) { k.cap = need; ok = true; }
+        else (void)hipGetLastError();
+      }
+    }
+    if (ok) kbuf = k.buf;
+  }
+  if (int rc = pack(w, theta, s, err, errlen)) return rc;
+  const long grid = ntiles < 2l * w->cus ? ntiles : 2l * w->cus;
+  hipLaunchKernelGGL(vn_wide_fwd_kernel, dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf, seg,
+                     ntiles, kbuf);
+  WHIP(hipGetLastError());
+  if (kbuf) {
+    VnWide::Kept& k = w->kept[keep_slot];
+    k.X = seg.X; k.n = seg.n; k.valid = true;
+  }
+  return 0;
+}
+
+bool vn_wide_has_kept(const VnWide* w, int slot, const VnRows& seg) {
+  if (slot < 0) return false;
+  const VnWide::Kept& k = w->kept[slot];
+  return k.valid && k.X == seg.X && k.n == seg.n;
+}
+
+int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* grad, int keep_slot, hipStream_t s, char* err,
+                     size_t errlen) {
+  if (seg.n <= 0) return 0;
+  if (!vn_wide_has_kept(w, keep_slot, seg)) return wfail(err, errlen, "vn_wide_backward: no stored activations for these rows");
+  VnWide::Kept& k = w->kept[keep_slot];
+  k.valid = false;                                  // theta moves after this step
+  const long ntiles = (seg.n + TP - 1) / TP;
+  if (int rc = pack(w, theta, s, err, errlen)) return rc;
+  const int grid = (int)(ntiles < (long)w->cus ? ntiles : (long)w->cus);
+  if (w->deep)
+    hipLaunchKernelGGL((vn_wide_bwd_kernel<6, 3>), dim3(grid), dim3(NT), w->lds_b, s, w->net, w->pl, theta, (const float*)w->wf, seg,
+                       ntiles, (const float*)k.buf, w->part);
+  else
+    hipLaunchKernelGGL((vn_wide_bwd_kernel<4, 4>), dim3(grid), dim3(NT), w->lds_b, s, w->net, w->pl, theta, (const float*)w->wf, seg,
+                       ntiles, (const float*)k.buf, w->part);
+  WHIP(hipGetLastError());
+  hipLaunchKernelGGL(vn_wide_sum_kernel, dim3((unsigned)((w->net.P + 255) / 256)), dim3(256), 0, s, (const float*)w->part, grid,
+                     (long)w->net.P, grad);
+  WHIP(hipGetLastError());
+  return 0;
+}
