@@ -38,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int TP = 32;        // points per tile
-constexpr int LDW = 81;       // LDS row stride (floats)
+constexpr int LDW = 68;       // LDS row stride (floats): 16-byte aligned rows for the b128 accesses
 constexpr int NT = 512;       // threads per workgroup
 constexpr int WL = 6;         // most hidden layers these kernels take
 
@@ -60,6 +60,11 @@ __device__ __forceinline__ float w_d1(float a, int act) { return act == VN_ACT_T
 __device__ __forceinline__ float w_d2r(float a, int act) { return act == VN_ACT_TANH ? -2.f * a : 1.f - 2.f * a; }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// Column order of the LDS matrices: column 4 lm + ct holds point 16 (ct & 1) + lm of stream ct >> 1 (0 value, 1 tangent),
+// i.e. the four accumulator tiles of a lane side by side -- a lane reads its four B operands of a k-step with one
+// ds_read_b128 and writes a row of its results with one ds_write_b128.  The weight-gradient contraction runs over the
+// columns in storage order (both operands use the same order).
 
 // ---- fragment images of the weights ---------------------------------------------------------------------------------
 // forward image of layer l:   [rt][q][lane][j] = W[k][m],  k = 16 q + 4 j + lane/16 (input),  m = 16 rt + lane%16 (output)
@@ -86,37 +91,70 @@ __global__ __launch_bounds__(256) void vn_wide_pack_kernel(VnNet net, Plan pl, c
   }
 }
 
-__device__ __forceinline__ void load_tile_inputs(const VnNet& net, const VnRows& sg, long r0, int rows0, float* dst, int tid) {
+// inputs of a tile, through registers so that the loads of the next tile fly under the current one
+struct TileIn { float v[4]; };
+__device__ __forceinline__ TileIn tile_in_issue(const VnNet& net, const VnRows& sg, long r0, int rows0, int tid) {
+  TileIn t;
   const int d_in = net.d_in, dim = net.dim;
-  for (int i = tid; i < rows0 * 64; i += NT) {
-    const int k = i >> 6, c = i & 63;
-    const long row = r0 + (c & (TP - 1));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = tid + e * NT;
     float v = 0.f;
-    if (row < sg.n && k < d_in) {
-      if (c < TP) v = sg.X[row * d_in + k];
-      else if (sg.G != nullptr && k < dim) v = sg.G[row * dim + k];
+    if (i < rows0 * 64) {
+      const int k = i >> 6, c = i & 63;
+      const long row = r0 + 16 * (c & 1) + (c >> 2);
+      if (row < sg.n && k < d_in) {
+        if (!(c & 2)) v = sg.X[row * d_in + k];
+        else if (sg.G != nullptr && k < dim) v = sg.G[row * dim + k];
+      }
     }
-    dst[k * LDW + c] = v;
+    t.v[e] = v;
+  }
+  return t;
+}
+__device__ __forceinline__ void tile_in_write(const TileIn& t, int rows0, float* dst, int tid) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = tid + e * NT;
+    if (i < rows0 * 64) dst[(i >> 6) * LDW + (i & 63)] = t.v[e];
   }
 }
 
-// acc[ct] += sum_k Wimage[this wave's row tile][k] * B[k][16 ct + lm]: the GEMM of a layer (forward: B = activations of the
-// layer below; reverse: B = (zbar | zdbar), image = W^T).  nq = k quads of 16.
-__device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wave, int lane, int nq, const float* B, f32x4 acc[4]) {
+// the first three 16-byte fragment loads of a wave's GEMM, issued ahead of the barrier in front of it
+struct Frag { f32x4 w0, w1, w2; };
+__device__ __forceinline__ Frag frag_issue(const float* __restrict__ img, int wave, int lane, int nq) {
+  const f32x4* wp = (const f32x4*)img + (long)wave * nq * 64 + lane;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  Frag f;
+  f.w0 = wp[0];
+  f.w1 = nq > 1 ? wp[64] : zero4;
+  f.w2 = nq > 2 ? wp[128] : zero4;
+  return f;
+}
+
+// acc[ct] += sum_k image[this wave's row tile][k] * B[k][4 lm + ct]: the GEMM of a layer (forward: B = activations of the
+// layer below; reverse: B = (zbar | zdbar), image = W^T).  nq = k quads of 16; three fragment loads stay in flight.
+__device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wave, int lane, int nq, const float* B, f32x4 acc[4],
+                                          Frag f) {
   const int lm = lane & 15, lk = lane >> 4;
   const f32x4* wp = (const f32x4*)img + (long)wave * nq * 64 + lane;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 w0 = wp[0];
-  f32x4 w1 = nq > 1 ? wp[64] : zero4;
-  f32x4 w2 = nq > 2 ? wp[128] : zero4;
+  f32x4 w0 = f.w0, w1 = f.w1, w2 = f.w2;
+  // the B operand of the next k-step is read while the four MFMAs of the current one issue
+  const float* cb = B + lk * LDW + 4 * lm;
+  f32x4 bv = *(const f32x4*)cb;
+#pragma unroll 1
   for (int q = 0; q < nq; ++q) {
     const f32x4 wn = (q + 3 < nq) ? wp[(q + 3) * 64] : zero4;
-    const float* cb = B + (16 * q + lk) * LDW + lm;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      cb += 4 * LDW;
+      // one row past the last k-step is still inside the matrix or the one behind it (never used)
+      const f32x4 bn = *(const f32x4*)cb;
       const float av = w0[j];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av, cb[4 * j * LDW + 16 * ct], acc[ct]);
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av, bv[ct], acc[ct]);
+      bv = bn;
     }
     w0 = w1; w1 = w2; w2 = wn;
   }
@@ -132,35 +170,54 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
   float* buf1 = lds + pl.rows * LDW;
   float* red = buf1 + pl.rows * LDW;         // [8][64]
   const int L = net.L;
+  const int rows0 = 16 * pl.nrt[0];
+
+  TileIn tin = tile_in_issue(net, sg, (long)blockIdx.x * TP, rows0, tid);
+  Frag fr{};
+  if (wave < pl.nrt[1]) fr = frag_issue(wf + pl.wfo[1], wave, lane, pl.nrt[0]);
 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long r0 = tile * TP;
-    load_tile_inputs(net, sg, r0, 16 * pl.nrt[0], buf0, tid);
+    tile_in_write(tin, rows0, buf0, tid);
+    if (tile + gridDim.x < ntiles) tin = tile_in_issue(net, sg, (tile + gridDim.x) * TP, rows0, tid);
     __syncthreads();
     float* cur = buf0;
     float* nxt = buf1;
     for (int l = 1; l <= L; ++l) {
-      if (wave < pl.nrt[l]) {
-        f32x4 acc[4];
+      const bool active = wave < pl.nrt[l];
+      const int Hout = net.H[l], act = net.actl[l];
+      f32x4 acc[4];
+      float bs[4];
+      if (active) {
+        const float* bias = theta + net.boff[l];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * wave + 4 * lk + i;
+          bs[i] = m < Hout ? bias[m] : 0.f;
+        }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wave_gemm(wf + pl.wfo[l], wave, lane, pl.nrt[l - 1], cur, acc);
-        const int Hout = net.H[l], act = net.actl[l];
-        const float* bias = theta + net.boff[l];
+        wave_gemm(wf + pl.wfo[l], wave, lane, pl.nrt[l - 1], cur, acc, fr);
+      }
+      {   // fragments of the next GEMM this wave runs (the next layer, or layer 1 of the next tile): ahead of the barrier
+        const int ln = l < L ? l + 1 : 1;
+        if (wave < pl.nrt[ln]) fr = frag_issue(wf + pl.wfo[ln], wave, lane, pl.nrt[ln - 1]);
+      }
+      if (active) {
         f32x4 av[2], adv[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = 16 * wave + 4 * lk + i;
           const bool valid = m < Hout;
-          const float b = valid ? bias[m] : 0.f;
+          f32x4 o;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const float a = valid ? w_act(acc[h][i] + b, act) : 0.f;
+            const float a = valid ? w_act(acc[h][i] + bs[i], act) : 0.f;
             const float ad = valid ? w_d1(a, act) * acc[2 + h][i] : 0.f;
             av[h][i] = a; adv[h][i] = ad;
-            nxt[m * LDW + 16 * h + lm] = a;
-            nxt[m * LDW + 32 + 16 * h + lm] = ad;
+            o[h] = a; o[2 + h] = ad;
           }
+          *(f32x4*)(nxt + m * LDW + 4 * lm) = o;
         }
         if (kept != nullptr) {
           f32x4* kp = (f32x4*)(kept + tile * pl.kept_tile + pl.ko[l] + wave * 1024);
@@ -184,9 +241,9 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
       float acc = 0.f;
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl) acc += red[sl * 64 + tid];
-      const long row = r0 + (tid & (TP - 1));
+      const long row = r0 + 16 * (tid & 1) + (tid >> 2);
       if (row < sg.n) {
-        if (tid < TP) { if (sg.u != nullptr) sg.u[row] = acc + theta[net.boff[L + 1]]; }
+        if (!(tid & 2)) { if (sg.u != nullptr) sg.u[row] = acc + theta[net.boff[L + 1]]; }
         else if (sg.ud != nullptr) sg.ud[row] = acc;
       }
     }
@@ -206,38 +263,55 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
   float* sub = PV + pl.rows * LDW;           // [TP] ubar
   float* sudb = sub + TP;                    // [TP] udbar
   const int L = net.L;
+  const int rows0 = 16 * pl.nrt[0];
 
-  f32x4 wacc[ML][2 * BN];
+  // weight-gradient accumulators, live over the whole launch.  Hidden-to-hidden layers (l >= 2): the 2 x BN block of this
+  // wave.  Layer 1 has at most 2 x 8 tiles (d_in <= 32): column tile `wave`, both row tiles.
+  f32x4 wacc[ML > 1 ? ML - 1 : 1][2 * BN];
+  f32x4 wacc1[2];
   float bacc[ML];
+  wacc1[0] = wacc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int l = 0; l < ML; ++l) {
-    bacc[l] = 0.f;
+  for (int l = 0; l < ML; ++l) bacc[l] = 0.f;
+#pragma unroll
+  for (int l = 0; l < (ML > 1 ? ML - 1 : 1); ++l) {
 #pragma unroll
     for (int j = 0; j < 2 * BN; ++j) wacc[l][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   float woacc[4] = {0.f, 0.f, 0.f, 0.f};
   float boacc = 0.f;
 
-  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long r0 = tile * TP;
+  // stored activations of the last two layers and the seeds of a tile are fetched while the tile before it is processed
+  f32x4 ka[4], kn[4];
+  float su = 0.f, sd = 0.f;
+  const bool ownL = wave < pl.nrt[L];
+  const bool ownL1 = L > 1 && wave < pl.nrt[L > 1 ? L - 1 : 0];
+  auto fetch_head = [&](long tile) {
     const float* kt = kept + tile * pl.kept_tile;
-    if (tid < TP) {
-      const long row = r0 + tid;
-      sub[tid] = (row < sg.n) ? sg.ubar[row] : 0.f;
-      sudb[tid] = (row < sg.n && sg.udbar != nullptr) ? sg.udbar[row] : 0.f;
-    }
-    f32x4 ka[4], kn[4];
-    const bool ownL = wave < pl.nrt[L];
     if (ownL) {
       const f32x4* kp = (const f32x4*)(kt + pl.ko[L] + wave * 1024);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) ka[ct] = kp[ct * 64 + lane];
     }
-    if (L > 1 && wave < pl.nrt[L - 1]) {
+    if (ownL1) {
       const f32x4* kp = (const f32x4*)(kt + pl.ko[L - 1] + wave * 1024);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) kn[ct] = kp[ct * 64 + lane];
     }
+    if (tid < TP) {
+      const long row = tile * TP + tid;
+      su = (row < sg.n) ? sg.ubar[row] : 0.f;
+      sd = (row < sg.n && sg.udbar != nullptr) ? sg.udbar[row] : 0.f;
+    }
+  };
+  fetch_head(blockIdx.x);
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long r0 = tile * TP;
+    const float* kt = kept + tile * pl.kept_tile;
+    TileIn tin{};                                                     // inputs: consumed at layer 1, the end of the tile
+    if (L == 1) tin = tile_in_issue(net, sg, r0, rows0, tid);
+    if (tid < TP) { sub[tid] = su; sudb[tid] = sd; }
     __syncthreads();        // seeds visible; every wave is past the previous tile's reads of T and PV
 
     // output layer: d w_o, d b_o and (zbar | zdbar) of the last hidden layer
@@ -249,17 +323,19 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
         const int m = 16 * wave + 4 * lk + i;
         const bool valid = m < HL;
         const float wom = valid ? wo[m] : 0.f;
+        f32x4 o;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int c = 16 * h + lm;
-          const float ub = sub[c], udb = sudb[c];
+          const int p = 16 * h + lm;
+          const float ub = sub[p], udb = sudb[p];
           const float a = ka[h][i], ad = ka[2 + h][i];
           woacc[i] += ub * a + udb * ad;
           const float ab = ub * wom, adb = udb * wom;
           const float sp = w_d1(a, act);
-          T[m * LDW + c] = valid ? ab * sp + w_d2r(a, act) * ad * adb : 0.f;
-          T[m * LDW + 32 + c] = valid ? adb * sp : 0.f;
+          o[h] = valid ? ab * sp + w_d2r(a, act) * ad * adb : 0.f;
+          o[2 + h] = valid ? adb * sp : 0.f;
         }
+        *(f32x4*)(T + m * LDW + 4 * lm) = o;
       }
     }
     if (wave == 0 && lane < TP) boacc += sub[lane];
@@ -269,52 +345,94 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
       if (l <= L) {
         const int Hout = net.H[l];
         const bool own = l > 1 && wave < pl.nrt[l - 1];
-        f32x4 kb[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) kb[ct] = kn[ct];
         if (l > 1) {
           if (own) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int m = 16 * wave + 4 * lk + i;
-#pragma unroll
-              for (int ct = 0; ct < 4; ++ct) PV[m * LDW + 16 * ct + lm] = kb[ct][i];
+              *(f32x4*)(PV + m * LDW + 4 * lm) = f32x4{kn[0][i], kn[1][i], kn[2][i], kn[3][i]};
             }
           }
         } else {
-          load_tile_inputs(net, sg, r0, 16 * pl.nrt[0], PV, tid);
+          // the input rows are written by all threads, and rows 0..31 of PV belong to waves 0/1, which may still be in
+          // their layer-2 epilogue (it re-reads PV): one extra barrier per tile
+          if (L > 1) __syncthreads();
+          tile_in_write(tin, rows0, PV, tid);
         }
         __syncthreads();      // #1: T and PV of this layer complete
-        if (l > 2 && wave < pl.nrt[l - 2]) {
-          const f32x4* kp = (const f32x4*)(kt + pl.ko[l - 2] + wave * 1024);
+        // loads that fly under this layer's work: the W^T fragments of its input-gradient GEMM, the stored activations
+        // two layers down (layer 1: the head of the next tile)
+        Frag fr{};
+        if (own) fr = frag_issue(wf + pl.wto[l], wave, lane, pl.nrt[l]);
+        if (l > 2) {
+          if (wave < pl.nrt[l - 2]) {
+            const f32x4* kp = (const f32x4*)(kt + pl.ko[l - 2] + wave * 1024);
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) kn[ct] = kp[ct * 64 + lane];
+            for (int ct = 0; ct < 4; ++ct) kn[ct] = kp[ct * 64 + lane];
+          }
+        } else if (l == 1) {
+          if (tile + gridDim.x < ntiles) fetch_head(tile + gridDim.x);
         }
-        // bias gradient: row sums of the value columns
-        if (tid < Hout) {
-          float acc = 0.f;
-          for (int c = 0; c < TP; ++c) acc += T[tid * LDW + c];
-          bacc[l - 1] += acc;
+        if (l == 2) tin = tile_in_issue(net, sg, r0, rows0, tid);
+        // bias gradient: row sums of the value columns; thread t takes 8 of the 32 value columns of row t / 4 (four 8-byte
+        // reads), the four partial sums of a row meet at the flush
+        {
+          const int row = tid >> 2;
+          if (row < Hout) {
+            const float* tr = T + row * LDW + 16 * (tid & 3);
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float2 v = *(const float2*)(tr + 4 * e);
+              acc += v.x + v.y;
+            }
+            bacc[l - 1] += acc;
+          }
         }
         // weight gradient: G[k][n] += sum_col PV[k][col] T[n][col]
-        {
+        if (l == 1) {
+          if (wave < pl.nrt[1]) {
+            const float* pa = PV + lm * LDW + lk;
+            const float* pb = T + (16 * wave + lm) * LDW + lk;
+            const bool a1 = pl.nrt[0] > 1;
+#pragma unroll 4
+            for (int cs = 0; cs < 16; ++cs) {
+              const float bv = pb[4 * cs];
+              wacc1[0] = mfma16(pa[4 * cs], bv, wacc1[0]);
+              if (a1) wacc1[1] = mfma16(pa[16 * LDW + 4 * cs], bv, wacc1[1]);
+            }
+          }
+        } else {
+          const int li = l > 1 ? l - 2 : 0;
           const int ntm = pl.nrt[l - 1], ntn = pl.nrt[l];
           const int tm0 = 2 * wm, tn0 = BN * wn;
           if (tm0 < ntm && tn0 < ntn) {
             const float* pa = PV + (16 * tm0 + lm) * LDW + lk;
             const float* pb = T + (16 * tn0 + lm) * LDW + lk;
             const bool a1 = tm0 + 1 < ntm;
+            // operands of the next 4 columns are read while the MFMAs of the current ones issue (rows of absent tiles are
+            // not read: their products are skipped)
+            float av0 = pa[0], av1 = a1 ? pa[16 * LDW] : 0.f, bv[BN];
+#pragma unroll
+            for (int b = 0; b < BN; ++b) bv[b] = (tn0 + b < ntn) ? pb[16 * b * LDW] : 0.f;
+#pragma unroll 2
             for (int cs = 0; cs < 16; ++cs) {
-              const float av0 = pa[4 * cs];
-              const float av1 = a1 ? pa[16 * LDW + 4 * cs] : 0.f;
+              const int cn = cs < 15 ? 4 * (cs + 1) : 0;
+              const float nav0 = pa[cn];
+              const float nav1 = a1 ? pa[16 * LDW + cn] : 0.f;
+              float nbv[BN];
+#pragma unroll
+              for (int b = 0; b < BN; ++b) nbv[b] = (tn0 + b < ntn) ? pb[16 * b * LDW + cn] : 0.f;
 #pragma unroll
               for (int b = 0; b < BN; ++b) {
                 if (tn0 + b < ntn) {
-                  const float bv = pb[16 * b * LDW + 4 * cs];
-                  wacc[l - 1][b] = mfma16(av0, bv, wacc[l - 1][b]);
-                  if (a1) wacc[l - 1][BN + b] = mfma16(av1, bv, wacc[l - 1][BN + b]);
+                  wacc[li][b] = mfma16(av0, bv[b], wacc[li][b]);
+                  if (a1) wacc[li][BN + b] = mfma16(av1, bv[b], wacc[li][BN + b]);
                 }
               }
+              av0 = nav0; av1 = nav1;
+#pragma unroll
+              for (int b = 0; b < BN; ++b) bv[b] = nbv[b];
             }
           }
         }
@@ -323,7 +441,7 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
         if (own) {
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-          wave_gemm(wf + pl.wto[l], wave, lane, pl.nrt[l], T, acc);
+          wave_gemm(wf + pl.wto[l], wave, lane, pl.nrt[l], T, acc, fr);
         }
         __syncthreads();      // #2: every wave is done reading T and PV
         if (own) {
@@ -332,14 +450,17 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
           for (int i = 0; i < 4; ++i) {
             const int m = 16 * wave + 4 * lk + i;
             const bool valid = m < Hp;
+            const f32x4 pv = *(const f32x4*)(PV + m * LDW + 4 * lm);      // (a | ad) of this lane's positions: rows this wave wrote
+            f32x4 o;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const float a = kb[h][i], ad = kb[2 + h][i];
+              const float a = pv[h], ad = pv[2 + h];
               const float ab = acc[h][i], adb = acc[2 + h][i];
               const float sp = w_d1(a, actp);
-              T[m * LDW + 16 * h + lm] = valid ? ab * sp + w_d2r(a, actp) * ad * adb : 0.f;
-              T[m * LDW + 32 + 16 * h + lm] = valid ? adb * sp : 0.f;
+              o[h] = valid ? ab * sp + w_d2r(a, actp) * ad * adb : 0.f;
+              o[2 + h] = valid ? adb * sp : 0.f;
             }
+            *(f32x4*)(T + m * LDW + 4 * lm) = o;
           }
         }
       }
@@ -353,21 +474,39 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
     if (l <= L) {
       const int Hin = net.H[l - 1], Hout = net.H[l];
       const int ntm = pl.nrt[l - 1], ntn = pl.nrt[l];
+      if (l == 1) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int b = 0; b < BN; ++b) {
-          const int tm = 2 * wm + a, tn = BN * wn + b;
-          if (tm < ntm && tn < ntn) {
+        for (int a = 0; a < 2; ++a) {
+          if (a < ntm && wave < ntn) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int row = 16 * tm + 4 * lk + i, col = 16 * tn + lm;
-              if (row < Hin && col < Hout) out[net.woff[l] + row * Hout + col] = wacc[l - 1][a * BN + b][i];
+              const int row = 16 * a + 4 * lk + i, col = 16 * wave + lm;
+              if (row < Hin && col < Hout) out[net.woff[1] + row * Hout + col] = wacc1[a][i];
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int b = 0; b < BN; ++b) {
+            const int tm = 2 * wm + a, tn = BN * wn + b;
+            if (tm < ntm && tn < ntn) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int row = 16 * tm + 4 * lk + i, col = 16 * tn + lm;
+                if (row < Hin && col < Hout) out[net.woff[l] + row * Hout + col] = wacc[l > 1 ? l - 2 : 0][a * BN + b][i];
+              }
             }
           }
         }
       }
-      if (tid < Hout) out[net.boff[l] + tid] = bacc[l - 1];
+      {
+        float v = bacc[l - 1];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        if ((tid & 3) == 0 && (tid >> 2) < Hout) out[net.boff[l] + (tid >> 2)] = v;
+      }
     }
   }
   {
