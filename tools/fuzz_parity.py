@@ -1,9 +1,9 @@
 """Randomised cross-check of the independent GPU routes on the same inputs: the AUTO kernel choice (fused16 / fused32 /
-two-pass / generic / layer-by-layer), the generic kernels and the layer-by-layer route (vn_layered.hip), whichever can
-run a case: random depth, widths (uniform and ragged; one case in five beyond the kernels' range: up to 9 layers,
+two-pass / generic / layer-by-layer), the generic kernels and both forms of the layer-by-layer route (the tile kernels of
+vn_wide.hip for nets up to 128 wide, route id 4; the GEMM form of vn_layered.hip, shown as 40), whichever can run a case: random depth, widths (uniform and ragged; one case in five beyond the kernels' range: up to 9 layers,
 150 wide), d_in, dim, integNum, source / integW / detJvec / per-row tables, sizes from one tile to several tiles per
 workgroup.   python tools/fuzz_parity.py [cases] [seed]"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from varnet_amd.engine import VNEngine
 
@@ -24,6 +24,12 @@ def synth(seed, d_in, dim, widths, integNum, n_k, nB, bDof, source=False, integW
 
 
 def make_engine(d_in, dim, widths, integNum, source, integW, kernel=0, act='sigmoid'):
+    if kernel == 40:                            # the layer-by-layer route on its GEMMs (read when the engine is created)
+        os.environ['VN_LAYERED_NOWIDE'] = '1'
+        try:
+            return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=4, activationFun=act)
+        finally:
+            del os.environ['VN_LAYERED_NOWIDE']
     return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel, activationFun=act)
 
 
@@ -49,7 +55,7 @@ for case in range(ncases):
     rows = bool(rng.random() < 0.2)
     grads, routes = [], []
     in_range = L <= 6 and max(widths) <= 64 and d_in <= 8       # the generic kernels' range (AUTO also runs 7-8 x <= 32 fused)
-    kernels = [4, 0]                            # the layer-by-layer route is the reference: it runs every case
+    kernels = [40, 4, 0]                        # the layer-by-layer route on its GEMMs is the reference: it runs every case
     if in_range:
         try:
             make_engine(d_in, dim, widths, q, src, iw, 1, act).close()
@@ -71,7 +77,7 @@ for case in range(ncases):
         eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
         eng.set_weights(d['w'])
         gb = eng.bind_grad_buffer(); eng.grad(0); torch.cuda.synchronize()
-        grads.append(gb.cpu().numpy().astype(np.float64)); routes.append(eng.kernel_path()[0]); eng.close()
+        grads.append(gb.cpu().numpy().astype(np.float64)); routes.append(40 if kernel == 40 else eng.kernel_path()[0]); eng.close()
     P = grads[0].size - 4
     err = lerr = 0.0
     for g1 in grads[1:]:

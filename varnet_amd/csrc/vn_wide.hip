@@ -40,7 +40,7 @@ namespace {
 constexpr int TP = 32;        // points per tile
 constexpr int LDW = 68;       // LDS row stride (floats): 16-byte aligned rows for the b128 accesses
 constexpr int NT = 512;       // threads per workgroup
-constexpr int WL = 6;         // most hidden layers these kernels take
+constexpr int WL = VN_MAX_LAYERS;   // most hidden layers these kernels take (the ABI's limit)
 
 struct Plan {
   int nrt[WL + 1];    // 16-row tiles of layer l's activations (l = 0: the inputs)
@@ -251,13 +251,12 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
 }
 
 // ---- reverse: rows + seeds + stored activations -> per-workgroup partial parameter gradient ---------------------------
-template <int ML, int BN>
+template <int ML, int BM, int BN>
 __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
                                                          const float* __restrict__ wf, VnRows sg, long ntiles,
                                                          const float* __restrict__ kept, float* __restrict__ partial) {
   extern __shared__ float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lk = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave0 = tid >> 6, lm0 = lane & 15, lk0 = lane >> 4;
   float* T = lds;                            // (zbar | zdbar) of the current layer
   float* PV = lds + pl.rows * LDW;           // (a | ad) of the layer below (layer 1: the inputs)
   float* sub = PV + pl.rows * LDW;           // [TP] ubar
@@ -265,9 +264,9 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
   const int L = net.L;
   const int rows0 = 16 * pl.nrt[0];
 
-  // weight-gradient accumulators, live over the whole launch.  Hidden-to-hidden layers (l >= 2): the 2 x BN block of this
+  // weight-gradient accumulators, live over the whole launch.  Hidden-to-hidden layers (l >= 2): the BM x BN block of this
   // wave.  Layer 1 has at most 2 x 8 tiles (d_in <= 32): column tile `wave`, both row tiles.
-  f32x4 wacc[ML > 1 ? ML - 1 : 1][2 * BN];
+  f32x4 wacc[ML > 1 ? ML - 1 : 1][BM * BN];
   f32x4 wacc1[2];
   float bacc[ML];
   wacc1[0] = wacc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
 #pragma unroll
   for (int l = 0; l < (ML > 1 ? ML - 1 : 1); ++l) {
 #pragma unroll
-    for (int j = 0; j < 2 * BN; ++j) wacc[l][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < BM * BN; ++j) wacc[l][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   float woacc[4] = {0.f, 0.f, 0.f, 0.f};
   float boacc = 0.f;
@@ -284,17 +283,17 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
   // stored activations of the last two layers and the seeds of a tile are fetched while the tile before it is processed
   f32x4 ka[4], kn[4];
   float su = 0.f, sd = 0.f;
-  const bool ownL = wave < pl.nrt[L];
-  const bool ownL1 = L > 1 && wave < pl.nrt[L > 1 ? L - 1 : 0];
+  const bool ownL = wave0 < pl.nrt[L];
+  const bool ownL1 = L > 1 && wave0 < pl.nrt[L > 1 ? L - 1 : 0];
   auto fetch_head = [&](long tile) {
     const float* kt = kept + tile * pl.kept_tile;
     if (ownL) {
-      const f32x4* kp = (const f32x4*)(kt + pl.ko[L] + wave * 1024);
+      const f32x4* kp = (const f32x4*)(kt + pl.ko[L] + wave0 * 1024);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) ka[ct] = kp[ct * 64 + lane];
     }
     if (ownL1) {
-      const f32x4* kp = (const f32x4*)(kt + pl.ko[L - 1] + wave * 1024);
+      const f32x4* kp = (const f32x4*)(kt + pl.ko[L - 1] + wave0 * 1024);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) kn[ct] = kp[ct * 64 + lane];
     }
@@ -307,6 +306,13 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
   fetch_head(blockIdx.x);
 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // The layer loop below is unrolled (the accumulators are registers), and the compiler would hoist every layer's LDS and
+    // global addresses out of this loop into registers that stay live for the whole launch (126 spilled VGPRs in the
+    // 16-layer instantiation).  An opaque zero makes the lane coordinates a value of this iteration, so addresses are
+    // formed where they are used.
+    int oz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    const int lm = lm0 + oz, lk = lk0 + oz, wave = wave0 + oz, wm = wave >> 1, wn = wave & 1;
     const long r0 = tile * TP;
     const float* kt = kept + tile * pl.kept_tile;
     TileIn tin{};                                                     // inputs: consumed at layer 1, the end of the tile
@@ -405,32 +411,35 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
         } else {
           const int li = l > 1 ? l - 2 : 0;
           const int ntm = pl.nrt[l - 1], ntn = pl.nrt[l];
-          const int tm0 = 2 * wm, tn0 = BN * wn;
+          const int tm0 = BM * wm, tn0 = BN * wn;
           if (tm0 < ntm && tn0 < ntn) {
             const float* pa = PV + (16 * tm0 + lm) * LDW + lk;
             const float* pb = T + (16 * tn0 + lm) * LDW + lk;
-            const bool a1 = tm0 + 1 < ntm;
             // operands of the next 4 columns are read while the MFMAs of the current ones issue (rows of absent tiles are
             // not read: their products are skipped)
-            float av0 = pa[0], av1 = a1 ? pa[16 * LDW] : 0.f, bv[BN];
+            float av[BM], bv[BN];
+#pragma unroll
+            for (int a = 0; a < BM; ++a) av[a] = (tm0 + a < ntm) ? pa[16 * a * LDW] : 0.f;
 #pragma unroll
             for (int b = 0; b < BN; ++b) bv[b] = (tn0 + b < ntn) ? pb[16 * b * LDW] : 0.f;
 #pragma unroll 2
             for (int cs = 0; cs < 16; ++cs) {
               const int cn = cs < 15 ? 4 * (cs + 1) : 0;
-              const float nav0 = pa[cn];
-              const float nav1 = a1 ? pa[16 * LDW + cn] : 0.f;
-              float nbv[BN];
+              float nav[BM], nbv[BN];
+#pragma unroll
+              for (int a = 0; a < BM; ++a) nav[a] = (tm0 + a < ntm) ? pa[16 * a * LDW + cn] : 0.f;
 #pragma unroll
               for (int b = 0; b < BN; ++b) nbv[b] = (tn0 + b < ntn) ? pb[16 * b * LDW + cn] : 0.f;
 #pragma unroll
               for (int b = 0; b < BN; ++b) {
                 if (tn0 + b < ntn) {
-                  wacc[li][b] = mfma16(av0, bv[b], wacc[li][b]);
-                  if (a1) wacc[li][BN + b] = mfma16(av1, bv[b], wacc[li][BN + b]);
+#pragma unroll
+                  for (int a = 0; a < BM; ++a)
+                    if (a == 0 || tm0 + a < ntm) wacc[li][a * BN + b] = mfma16(av[a], bv[b], wacc[li][a * BN + b]);
                 }
               }
-              av0 = nav0; av1 = nav1;
+#pragma unroll
+              for (int a = 0; a < BM; ++a) av[a] = nav[a];
 #pragma unroll
               for (int b = 0; b < BN; ++b) bv[b] = nbv[b];
             }
@@ -468,6 +477,7 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
   }
 
   // ---- this workgroup's partial gradient (flat parameter layout) ----
+  const int lm = lm0, lk = lk0, wave = wave0, wm = wave >> 1, wn = wave & 1;
   float* out = partial + (long)blockIdx.x * net.P;
 #pragma unroll
   for (int l = 1; l <= ML; ++l) {
@@ -487,10 +497,10 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
         }
       } else {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < BM; ++a) {
 #pragma unroll
           for (int b = 0; b < BN; ++b) {
-            const int tm = 2 * wm + a, tn = BN * wn + b;
+            const int tm = BM * wm + a, tn = BN * wn + b;
             if (tm < ntm && tn < ntn) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -553,7 +563,7 @@ int wfail(char* err, size_t n, const char* fmt, ...) {
 struct VnWide {
   VnNet net{};
   Plan pl{};
-  bool deep = false;            // <6,3> instantiation (5-6 layers, widths <= 96) instead of <4,4>
+  int variant = 0;              // reverse-kernel instantiation: 0 <4,2,4> (<= 128 wide)  1 <6,2,3> (<= 96)  2 <16,1,2> (<= 64)
   int cus = 256;
   size_t lds_f = 0, lds_b = 0;
   float* wf = nullptr;
@@ -570,8 +580,8 @@ bool vn_wide_supported(const VnNet& net) {
     if (net.H[l] > hmax) hmax = net.H[l];
     if (net.actl[l] != VN_ACT_SIGMOID && net.actl[l] != VN_ACT_TANH) return false;
   }
-  if (hmax > 128) return false;
-  if (net.L > 4 && hmax > 96) return false;      // weight-gradient accumulators of 5-6 layers wider than 96 exceed the registers
+  // the weight-gradient accumulators of all layers live in registers: depth trades against width
+  if (!(net.L <= 4 && hmax <= 128) && !(net.L <= 6 && hmax <= 96) && hmax > 64) return false;
   return true;
 }
 
@@ -592,7 +602,11 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
     pl.ko[l] = koff; koff += pl.nrt[l] * 1024;
   }
   pl.wf_floats = off; pl.kept_tile = koff; pl.rows = rows;
-  w->deep = net.L > 4;
+  {
+    int hm = 0;
+    for (int l = 1; l <= net.L; ++l) if (net.H[l] > hm) hm = net.H[l];
+    w->variant = (net.L <= 4) ? 0 : (net.L <= 6 && hm <= 96) ? 1 : 2;
+  }
   w->lds_f = ((size_t)2 * rows * LDW + 512) * sizeof(float);
   w->lds_b = ((size_t)2 * rows * LDW + 2 * TP) * sizeof(float);
   int dev = 0;
@@ -601,8 +615,9 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
     w->cus = prop.multiProcessorCount;
   hipError_t e = hipFuncSetAttribute((const void*)vn_wide_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_f);
   if (e == hipSuccess)
-    e = w->deep ? hipFuncSetAttribute((const void*)vn_wide_bwd_kernel<6, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b)
-                : hipFuncSetAttribute((const void*)vn_wide_bwd_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
+    e = hipFuncSetAttribute(w->variant == 0 ? (const void*)vn_wide_bwd_kernel<4, 2, 4>
+                            : w->variant == 1 ? (const void*)vn_wide_bwd_kernel<6, 2, 3> : (const void*)vn_wide_bwd_kernel<16, 1, 2>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
   if (e == hipSuccess) e = hipMalloc((void**)&w->wf, (size_t)pl.wf_floats * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * net.P * sizeof(float));
   if (e != hipSuccess) {
@@ -677,12 +692,13 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
   const long ntiles = (seg.n + TP - 1) / TP;
   if (int rc = pack(w, theta, s, err, errlen)) return rc;
   const int grid = (int)(ntiles < (long)w->cus ? ntiles : (long)w->cus);
-  if (w->deep)
-    hipLaunchKernelGGL((vn_wide_bwd_kernel<6, 3>), dim3(grid), dim3(NT), w->lds_b, s, w->net, w->pl, theta, (const float*)w->wf, seg,
-                       ntiles, (const float*)k.buf, w->part);
-  else
-    hipLaunchKernelGGL((vn_wide_bwd_kernel<4, 4>), dim3(grid), dim3(NT), w->lds_b, s, w->net, w->pl, theta, (const float*)w->wf, seg,
-                       ntiles, (const float*)k.buf, w->part);
+#define VN_WIDE_BWD(ML_, BM_, BN_)                                                                                     \
+  hipLaunchKernelGGL((vn_wide_bwd_kernel<ML_, BM_, BN_>), dim3(grid), dim3(NT), w->lds_b, s, w->net, w->pl, theta,         \
+                     (const float*)w->wf, seg, ntiles, (const float*)k.buf, w->part)
+  if (w->variant == 0) VN_WIDE_BWD(4, 2, 4);
+  else if (w->variant == 1) VN_WIDE_BWD(6, 2, 3);
+  else VN_WIDE_BWD(16, 1, 2);
+#undef VN_WIDE_BWD
   WHIP(hipGetLastError());
   hipLaunchKernelGGL(vn_wide_sum_kernel, dim3((unsigned)((w->net.P + 255) / 256)), dim3(256), 0, s, (const float*)w->part, grid,
                      (long)w->net.P, grad);
