@@ -34,6 +34,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef VN_WIDE_ABL
+#define VN_WIDE_ABL 0      // diagnostic builds: 1 no activation stores, 2 no transcendentals, 3 no MFMAs in the layer GEMMs
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -134,30 +138,46 @@ __device__ __forceinline__ Frag frag_issue(const float* __restrict__ img, int wa
 }
 
 // acc[ct] += sum_k image[this wave's row tile][k] * B[k][4 lm + ct]: the GEMM of a layer (forward: B = activations of the
-// layer below; reverse: B = (zbar | zdbar), image = W^T).  nq = k quads of 16; three fragment loads stay in flight.
+// layer below; reverse: B = (zbar | zdbar), image = W^T).  nq = k quads of 16.
+//  * Three 16-byte fragment loads stay in flight.  The quad loop is unrolled by four over a register ring with static
+//    indices: rotating the ring with moves makes the move of the newest fragment wait for its own load (vmcnt(0) in every
+//    iteration -- the prefetch was void).
+//  * The B operand of the next k-step is read while the four MFMAs of the current one issue; the scheduler otherwise
+//    sinks every ds_read to its use to save registers (read, wait, 4 MFMAs, read, ...), hence the group barriers.
 __device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wave, int lane, int nq, const float* B, f32x4 acc[4],
                                           Frag f) {
   const int lm = lane & 15, lk = lane >> 4;
   const f32x4* wp = (const f32x4*)img + (long)wave * nq * 64 + lane;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 w0 = f.w0, w1 = f.w1, w2 = f.w2;
-  // the B operand of the next k-step is read while the four MFMAs of the current one issue
+  f32x4 ring[4] = {f.w0, f.w1, f.w2, zero4};
   const float* cb = B + lk * LDW + 4 * lm;
   f32x4 bv = *(const f32x4*)cb;
 #pragma unroll 1
-  for (int q = 0; q < nq; ++q) {
-    const f32x4 wn = (q + 3 < nq) ? wp[(q + 3) * 64] : zero4;
+  for (int q0 = 0; q0 < nq; q0 += 4) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      cb += 4 * LDW;
-      // one row past the last k-step is still inside the matrix or the one behind it (never used)
-      const f32x4 bn = *(const f32x4*)cb;
-      const float av = w0[j];
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u;
+      if (q < nq) {
+        // unconditional (clamped): a conditional load makes the wait-count bookkeeping fall back to vmcnt(0) at the join
+        ring[(u + 3) & 3] = wp[(q + 3 < nq ? q + 3 : nq - 1) * 64];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av, bv[ct], acc[ct]);
-      bv = bn;
+        for (int j = 0; j < 4; ++j) {
+          cb += 4 * LDW;
+          // one row past the last k-step is still inside the matrix or the one behind it (never used)
+          const f32x4 bn = *(const f32x4*)cb;
+          const float av = ring[u][j];
+#if VN_WIDE_ABL == 3
+          acc[j] += av * bv;
+#else
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av, bv[ct], acc[ct]);
+#endif
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // the next step's ds_read first ...
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // ... then this step's four MFMAs
+          bv = bn;
+        }
+      }
     }
-    w0 = w1; w1 = w2; w2 = wn;
   }
 }
 
@@ -213,17 +233,23 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
           f32x4 o;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
+#if VN_WIDE_ABL == 2
+            const float a = valid ? 0.5f + 0.25f * (acc[h][i] + bs[i]) : 0.f;
+#else
             const float a = valid ? w_act(acc[h][i] + bs[i], act) : 0.f;
+#endif
             const float ad = valid ? w_d1(a, act) * acc[2 + h][i] : 0.f;
             av[h][i] = a; adv[h][i] = ad;
             o[h] = a; o[2 + h] = ad;
           }
           *(f32x4*)(nxt + m * LDW + 4 * lm) = o;
         }
+#if VN_WIDE_ABL != 1
         if (kept != nullptr) {
           f32x4* kp = (f32x4*)(kept + tile * pl.kept_tile + pl.ko[l] + wave * 1024);
           kp[lane] = av[0]; kp[64 + lane] = av[1]; kp[128 + lane] = adv[0]; kp[192 + lane] = adv[1];
         }
+#endif
       }
       __syncthreads();
       float* t = cur; cur = nxt; nxt = t;
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
     // formed where they are used.
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-    const int lm = lm0 + oz, lk = lk0 + oz, wave = wave0 + oz, wm = wave >> 1, wn = wave & 1;
+    const int lm = lm0 + oz, lk = lk0 + oz, wave = __builtin_amdgcn_readfirstlane(wave0) + oz, wm = wave >> 1, wn = wave & 1;
     const long r0 = tile * TP;
     const float* kt = kept + tile * pl.kept_tile;
     TileIn tin{};                                                     // inputs: consumed at layer 1, the end of the tile
