@@ -45,6 +45,7 @@ namespace {
 constexpr int TP = 32;        // points per tile
 constexpr int LDW = 68;       // LDS row stride (floats): 16-byte aligned rows for the b128 accesses
 constexpr int NT = 512;       // threads per workgroup
+constexpr int BROWS = 128;    // rows of the reverse kernel's two LDS matrices (always the widest net: see its weight-gradient loop)
 constexpr int WL = VN_MAX_LAYERS;   // most hidden layers these kernels take (the ABI's limit)
 
 struct Plan {
@@ -285,8 +286,8 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave0 = tid >> 6, lm0 = lane & 15, lk0 = lane >> 4;
   float* T = lds;                            // (zbar | zdbar) of the current layer
-  float* PV = lds + pl.rows * LDW;           // (a | ad) of the layer below (layer 1: the inputs)
-  float* sub = PV + pl.rows * LDW;           // [TP] ubar
+  float* PV = lds + BROWS * LDW;             // (a | ad) of the layer below (layer 1: the inputs)
+  float* sub = PV + BROWS * LDW;             // [TP] ubar
   float* sudb = sub + TP;                    // [TP] udbar
   const int L = net.L;
   const int rows0 = 16 * pl.nrt[0];
@@ -440,31 +441,33 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
           const int ntm = pl.nrt[l - 1], ntn = pl.nrt[l];
           const int tm0 = BM * wm, tn0 = BN * wn;
           if (tm0 < ntm && tn0 < ntn) {
+            // Straight-line body: a block at the ragged edge of the tile grid (widths that are not a multiple of the block)
+            // also multiplies its absent tiles -- rows of LDS that exist (both matrices are allocated 128 rows) but hold
+            // whatever an earlier layer left there; those accumulators are never written out.  Per-tile conditions cost a
+            // scalar branch around every MFMA and a conservative wait count after every read.
             const float* pa = PV + (16 * tm0 + lm) * LDW + lk;
             const float* pb = T + (16 * tn0 + lm) * LDW + lk;
-            // operands of the next 4 columns are read while the MFMAs of the current ones issue (rows of absent tiles are
-            // not read: their products are skipped)
             float av[BM], bv[BN];
 #pragma unroll
-            for (int a = 0; a < BM; ++a) av[a] = (tm0 + a < ntm) ? pa[16 * a * LDW] : 0.f;
+            for (int a = 0; a < BM; ++a) av[a] = pa[16 * a * LDW];
 #pragma unroll
-            for (int b = 0; b < BN; ++b) bv[b] = (tn0 + b < ntn) ? pb[16 * b * LDW] : 0.f;
+            for (int b = 0; b < BN; ++b) bv[b] = pb[16 * b * LDW];
 #pragma unroll 2
             for (int cs = 0; cs < 16; ++cs) {
+              // operands of the next 4 columns are read while the MFMAs of the current ones issue
               const int cn = cs < 15 ? 4 * (cs + 1) : 0;
               float nav[BM], nbv[BN];
 #pragma unroll
-              for (int a = 0; a < BM; ++a) nav[a] = (tm0 + a < ntm) ? pa[16 * a * LDW + cn] : 0.f;
+              for (int a = 0; a < BM; ++a) nav[a] = pa[16 * a * LDW + cn];
 #pragma unroll
-              for (int b = 0; b < BN; ++b) nbv[b] = (tn0 + b < ntn) ? pb[16 * b * LDW + cn] : 0.f;
+              for (int b = 0; b < BN; ++b) nbv[b] = pb[16 * b * LDW + cn];
 #pragma unroll
               for (int b = 0; b < BN; ++b) {
-                if (tn0 + b < ntn) {
 #pragma unroll
-                  for (int a = 0; a < BM; ++a)
-                    if (a == 0 || tm0 + a < ntm) wacc[li][a * BN + b] = mfma16(av[a], bv[b], wacc[li][a * BN + b]);
-                }
+                for (int a = 0; a < BM; ++a) wacc[li][a * BN + b] = mfma16(av[a], bv[b], wacc[li][a * BN + b]);
               }
+              __builtin_amdgcn_sched_group_barrier(0x100, BM + BN, 0);     // the next step's reads first ...
+              __builtin_amdgcn_sched_group_barrier(0x008, BM * BN, 0);     // ... then this step's MFMAs
 #pragma unroll
               for (int a = 0; a < BM; ++a) av[a] = nav[a];
 #pragma unroll
@@ -635,7 +638,7 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
     w->variant = (net.L <= 4) ? 0 : (net.L <= 6 && hm <= 96) ? 1 : 2;
   }
   w->lds_f = ((size_t)2 * rows * LDW + 512) * sizeof(float);
-  w->lds_b = ((size_t)2 * rows * LDW + 2 * TP) * sizeof(float);
+  w->lds_b = ((size_t)2 * BROWS * LDW + 2 * TP) * sizeof(float);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
