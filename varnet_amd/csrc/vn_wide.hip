@@ -27,7 +27,7 @@
 //     MFMAs), accumulated in registers over all tiles of the launch and written once as a per-workgroup partial that a
 //     fixed-order sum adds to the gradient (no atomics: same bits every run); the input gradient is the forward loop with
 //     the W^T image, its epilogue forms (zbar, zdbar) of the layer below in registers.  Two barriers per layer.
-// Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 29.5 ms = 0.55 of peak (GEMM form 90.5 ms).
+// Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 27.0 ms = 0.60 of peak (GEMM form 90.8 ms), 4 x 128 0.63.
 #include "vn_internal.h"
 
 #include <cstdarg>
