@@ -58,10 +58,25 @@ struct Plan {
   int wf_floats;      // both images
 };
 
-__device__ __forceinline__ float w_act(float z, int act) {
-  if (act == VN_ACT_TANH) return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * z)) - 1.0f;
-  return __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+// Both activations in one branch-free form (the choice is per layer and wave-uniform, but a branch or a select per element
+// costs vector issue slots, which the f32 MFMAs share):  a = sA rcp(1 + 2^(c z)) - sB  with (sA, sB) = (1, 0) for the
+// sigmoid and (2, 1) for tanh = 2 sigmoid(2z) - 1, c = -sA log2(e);  act' = (1 - a)(a + sB);  act''/act' = (1 - sB) - 2a.
+struct ActK { float sA, sB, c; };
+__device__ __forceinline__ ActK act_consts(int act) {
+  ActK k;
+  // selects between literals, not arithmetic: the condition is wave-uniform, so these stay scalar registers
+  k.sA = act == VN_ACT_TANH ? 2.f : 1.f;
+  k.sB = act == VN_ACT_TANH ? 1.f : 0.f;
+  k.c = act == VN_ACT_TANH ? -2.8853900817779268f : -1.4426950408889634f;
+  return k;
 }
+__device__ __forceinline__ float w_act(float z, const ActK& k) {
+  return fmaf(k.sA, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(k.c * z)), -k.sB);
+}
+__device__ __forceinline__ float w_d1(float a, const ActK& k) { return (1.f - a) * (a + k.sB); }
+__device__ __forceinline__ float w_d2r(float a, const ActK& k) { return fmaf(-2.f, a, 2.f - k.sA); }
+
+// runtime-selected forms (the reverse kernel: its register budget does not like the straight-line variant, measured)
 __device__ __forceinline__ float w_d1(float a, int act) { return act == VN_ACT_TANH ? 1.f - a * a : a * (1.f - a); }
 __device__ __forceinline__ float w_d2r(float a, int act) { return act == VN_ACT_TANH ? -2.f * a : 1.f - 2.f * a; }
 
@@ -187,7 +202,9 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
                                                          const float* __restrict__ wf, VnRows sg, long ntiles,
                                                          float* __restrict__ kept) {
   extern __shared__ float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lk = lane >> 4;
+  // the wave index as a scalar: everything addressed by it (row tile, fragment image, stored-activation block) is then
+  // formed on the scalar unit -- the vector unit shares its datapath with the f32 MFMAs
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lm = lane & 15, lk = lane >> 4;
   float* buf0 = lds;
   float* buf1 = lds + pl.rows * LDW;
   float* red = buf1 + pl.rows * LDW;         // [8][64]
@@ -227,19 +244,23 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
       }
       if (active) {
         f32x4 av[2], adv[2];
+        const ActK ak = act_consts(act);
+        // rows past the layer's width (only in its last row tile) must hold zeros, not act(0)
+        const bool ragged = 16 * wave + 16 > Hout;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = 16 * wave + 4 * lk + i;
-          const bool valid = m < Hout;
+          const float vm = (!ragged || m < Hout) ? 1.f : 0.f;
           f32x4 o;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
 #if VN_WIDE_ABL == 2
-            const float a = valid ? 0.5f + 0.25f * (acc[h][i] + bs[i]) : 0.f;
+            float a = 0.5f + 0.25f * (acc[h][i] + bs[i]);
 #else
-            const float a = valid ? w_act(acc[h][i] + bs[i], act) : 0.f;
+            float a = w_act(acc[h][i] + bs[i], ak);
 #endif
-            const float ad = valid ? w_d1(a, act) * acc[2 + h][i] : 0.f;
+            if (ragged) a *= vm;                       // wave-uniform branch; acc[2 + h] is zero there (zero weights)
+            const float ad = w_d1(a, ak) * acc[2 + h][i];
             av[h][i] = a; adv[h][i] = ad;
             o[h] = a; o[2 + h] = ad;
           }
