@@ -19,6 +19,9 @@ CASES = [
     # d_in dim widths                 integNum n_k  nB  bDof source integW detJvec
     (3, 2, [100, 80],                 64,      9,   77, 40,  False, False, False),   # wider than 64
     (3, 2, [128, 128, 128],           64,      30,  50, 20,  True,  False, True),
+    (3, 2, [96, 80, 96, 72, 96],      16,      21,  40, 15,  False, True,  False),   # tile kernels: <6,2,3> instantiation
+    (3, 2, [128, 112, 128, 100, 128, 120], 16, 9,   30, 12,  True,  False, False),   # ... <6,2,4>
+    (2, 1, [64, 50, 64, 33, 64, 64, 40, 64, 64], 16, 15, 30, 10, False, False, True),   # ... <16,1,2>
     (2, 1, [20] * 8,                  16,      40,  50, 30,  False, False, False),   # more than 6 hidden layers
     (3, 2, [30, 70, 12, 65, 9, 40, 33], 36,    17,  12, 5,   True,  True,  True),    # ragged, 7 layers
     (10, 2, [40, 40],                 64,      12,  30, 10,  False, True,  False),   # more than 8 inputs (many MOR parameters)
@@ -48,9 +51,9 @@ def _setup(case, kernel, act='sigmoid'):
 
 
 def _tile_kernels_take(widths, d_in):
-    """vn_wide_supported (vn_wide.hip): up to 4 hidden layers of width <= 128, 5-6 of width <= 96, any depth of width <= 64;
+    """vn_wide_supported (vn_wide.hip): up to 6 hidden layers of width <= 128, any depth of width <= 64;
     at most 32 inputs"""
-    return d_in <= 32 and ((max(widths) <= 128 and len(widths) <= 4) or (len(widths) <= 6 and max(widths) <= 96) or max(widths) <= 64)
+    return d_in <= 32 and ((max(widths) <= 128 and len(widths) <= 6) or max(widths) <= 64)
 
 
 @pytest.mark.parametrize('impl', ['tile-kernels', 'gemms'])

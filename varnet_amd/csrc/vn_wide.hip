@@ -614,7 +614,7 @@ int wfail(char* err, size_t n, const char* fmt, ...) {
 struct VnWide {
   VnNet net{};
   Plan pl{};
-  int variant = 0;              // reverse-kernel instantiation: 0 <4,2,4> (<= 128 wide)  1 <6,2,3> (<= 96)  2 <16,1,2> (<= 64)
+  int variant = 0;              // reverse-kernel instantiation: 0 <4,2,4> (<= 128 wide)  1 <6,2,3> (<= 96)  2 <16,1,2> (<= 64)  3 <6,2,4>
   int cus = 256;
   size_t lds_f = 0, lds_b = 0;
   float* wf = nullptr;
@@ -632,7 +632,7 @@ bool vn_wide_supported(const VnNet& net) {
     if (net.actl[l] != VN_ACT_SIGMOID && net.actl[l] != VN_ACT_TANH) return false;
   }
   // the weight-gradient accumulators of all layers live in registers: depth trades against width
-  if (!(net.L <= 4 && hmax <= 128) && !(net.L <= 6 && hmax <= 96) && hmax > 64) return false;
+  if (!(net.L <= 6 && hmax <= 128) && hmax > 64) return false;
   return true;
 }
 
@@ -656,7 +656,7 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   {
     int hm = 0;
     for (int l = 1; l <= net.L; ++l) if (net.H[l] > hm) hm = net.H[l];
-    w->variant = (net.L <= 4) ? 0 : (net.L <= 6 && hm <= 96) ? 1 : 2;
+    w->variant = (net.L <= 4) ? 0 : (net.L <= 6 && hm <= 96) ? 1 : (net.L <= 6 && hm > 64) ? 3 : 2;
   }
   w->lds_f = ((size_t)2 * rows * LDW + 512) * sizeof(float);
   w->lds_b = ((size_t)2 * BROWS * LDW + 2 * TP) * sizeof(float);
@@ -667,7 +667,8 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   hipError_t e = hipFuncSetAttribute((const void*)vn_wide_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_f);
   if (e == hipSuccess)
     e = hipFuncSetAttribute(w->variant == 0 ? (const void*)vn_wide_bwd_kernel<4, 2, 4>
-                            : w->variant == 1 ? (const void*)vn_wide_bwd_kernel<6, 2, 3> : (const void*)vn_wide_bwd_kernel<16, 1, 2>,
+                            : w->variant == 1 ? (const void*)vn_wide_bwd_kernel<6, 2, 3>
+                            : w->variant == 3 ? (const void*)vn_wide_bwd_kernel<6, 2, 4> : (const void*)vn_wide_bwd_kernel<16, 1, 2>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
   if (e == hipSuccess) e = hipMalloc((void**)&w->wf, (size_t)pl.wf_floats * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * net.P * sizeof(float));
@@ -748,6 +749,7 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
                      (const float*)w->wf, seg, ntiles, (const float*)k.buf, w->part)
   if (w->variant == 0) VN_WIDE_BWD(4, 2, 4);
   else if (w->variant == 1) VN_WIDE_BWD(6, 2, 3);
+  else if (w->variant == 3) VN_WIDE_BWD(6, 2, 4);
   else VN_WIDE_BWD(16, 1, 2);
 #undef VN_WIDE_BWD
   WHIP(hipGetLastError());
