@@ -18,7 +18,7 @@ for spec in sys.argv[1:]:
     widths = [int(v) for v in spec.split(',')]
     Fpt = 2 * sum(a * b for a, b in zip([d_in] + widths, widths + [1]))
     in_range = len(widths) <= 6 and max(widths) <= 64
-    tiles = (max(widths) <= 128 and len(widths) <= 6) or max(widths) <= 64
+    tiles = max(widths) <= 256
     for kernel in ((0, 4) if in_range else (0,)) + ((40,) if tiles else ()):
         if kernel == 40:
             os.environ['VN_LAYERED_NOWIDE'] = '1'

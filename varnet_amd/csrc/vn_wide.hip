@@ -198,6 +198,8 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wav
 }
 
 // ---- forward: rows -> (u, ud) [+ stored activations] ----------------------------------------------------------------
+// RP = row-tile passes per layer: wave w owns row tiles w, w + 8, ... (RP = 1: widths <= 128; RP = 2: <= 256)
+template <int RP>
 __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
                                                          const float* __restrict__ wf, VnRows sg, long ntiles,
                                                          float* __restrict__ kept) {
@@ -223,66 +225,73 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
     float* cur = buf0;
     float* nxt = buf1;
     for (int l = 1; l <= L; ++l) {
-      const bool active = wave < pl.nrt[l];
       const int Hout = net.H[l], act = net.actl[l];
-      f32x4 acc[4];
-      float bs[4];
-      if (active) {
-        const float* bias = theta + net.boff[l];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = 16 * wave + 4 * lk + i;
-          bs[i] = m < Hout ? bias[m] : 0.f;
-        }
+      for (int rp = 0; rp < RP; ++rp) {
+        const int rt = wave + 8 * rp;
+        const bool active = rt < pl.nrt[l];
+        f32x4 acc[4];
+        float bs[4];
+        if (active) {
+          const float* bias = theta + net.boff[l];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wave_gemm(wf + pl.wfo[l], wave, lane, pl.nrt[l - 1], cur, acc, fr);
-      }
-      {   // fragments of the next GEMM this wave runs (the next layer, or layer 1 of the next tile): ahead of the barrier
-        const int ln = l < L ? l + 1 : 1;
-        if (wave < pl.nrt[ln]) fr = frag_issue(wf + pl.wfo[ln], wave, lane, pl.nrt[ln - 1]);
-      }
-      if (active) {
-        f32x4 av[2], adv[2];
-        const ActK ak = act_consts(act);
-        // rows past the layer's width (only in its last row tile) must hold zeros, not act(0)
-        const bool ragged = 16 * wave + 16 > Hout;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = 16 * wave + 4 * lk + i;
-          const float vm = (!ragged || m < Hout) ? 1.f : 0.f;
-          f32x4 o;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-#if VN_WIDE_ABL == 2
-            float a = 0.5f + 0.25f * (acc[h][i] + bs[i]);
-#else
-            float a = w_act(acc[h][i] + bs[i], ak);
-#endif
-            if (ragged) a *= vm;                       // wave-uniform branch; acc[2 + h] is zero there (zero weights)
-            const float ad = w_d1(a, ak) * acc[2 + h][i];
-            av[h][i] = a; adv[h][i] = ad;
-            o[h] = a; o[2 + h] = ad;
+          for (int i = 0; i < 4; ++i) {
+            const int m = 16 * rt + 4 * lk + i;
+            bs[i] = m < Hout ? bias[m] : 0.f;
           }
-          *(f32x4*)(nxt + m * LDW + 4 * lm) = o;
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+          wave_gemm(wf + pl.wfo[l], rt, lane, pl.nrt[l - 1], cur, acc, fr);
         }
-#if VN_WIDE_ABL != 1
-        if (kept != nullptr) {
-          f32x4* kp = (f32x4*)(kept + tile * pl.kept_tile + pl.ko[l] + wave * 1024);
-          kp[lane] = av[0]; kp[64 + lane] = av[1]; kp[128 + lane] = adv[0]; kp[192 + lane] = adv[1];
+        {   // fragments of the next GEMM this wave runs (its next row tile, the next layer, or layer 1 of the next tile):
+            // ahead of the epilogue and the barrier
+          const bool same = rp + 1 < RP && rt + 8 < pl.nrt[l];
+          const int ln = same ? l : (l < L ? l + 1 : 1);
+          const int rn = same ? rt + 8 : wave;
+          if (rn < pl.nrt[ln]) fr = frag_issue(wf + pl.wfo[ln], rn, lane, pl.nrt[ln - 1]);
         }
+        if (active) {
+          f32x4 av[2], adv[2];
+          const ActK ak = act_consts(act);
+          // rows past the layer's width (only in its last row tile) must hold zeros, not act(0)
+          const bool ragged = 16 * rt + 16 > Hout;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = 16 * rt + 4 * lk + i;
+            const float vm = (!ragged || m < Hout) ? 1.f : 0.f;
+            f32x4 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#if VN_WIDE_ABL == 2
+              float a = 0.5f + 0.25f * (acc[h][i] + bs[i]);
+#else
+              float a = w_act(acc[h][i] + bs[i], ak);
 #endif
+              if (ragged) a *= vm;                       // wave-uniform branch; acc[2 + h] is zero there (zero weights)
+              const float ad = w_d1(a, ak) * acc[2 + h][i];
+              av[h][i] = a; adv[h][i] = ad;
+              o[h] = a; o[2 + h] = ad;
+            }
+            *(f32x4*)(nxt + m * LDW + 4 * lm) = o;
+          }
+#if VN_WIDE_ABL != 1
+          if (kept != nullptr) {
+            f32x4* kp = (f32x4*)(kept + tile * pl.kept_tile + pl.ko[l] + rt * 1024);
+            kp[lane] = av[0]; kp[64 + lane] = av[1]; kp[128 + lane] = adv[0]; kp[192 + lane] = adv[1];
+          }
+#endif
+        }
       }
       __syncthreads();
       float* t = cur; cur = nxt; nxt = t;
     }
-    // u = w_o . a_L + b_o,  ud = w_o . ad_L : eight 16-feature slices per column, added in a fixed order
+    // u = w_o . a_L + b_o,  ud = w_o . ad_L : eight feature slices per column, added in a fixed order
     {
       const int HL = net.H[L];
       const float* wo = theta + net.woff[L + 1];
-      const int c = tid & 63, k0 = 16 * (tid >> 6);
+      const int c = tid & 63, k0 = 16 * RP * (tid >> 6);
       float p = 0.f;
-      for (int k = k0; k < k0 + 16 && k < HL; ++k) p += wo[k] * cur[k * LDW + c];
+      for (int k = k0; k < k0 + 16 * RP && k < HL; ++k) p += wo[k] * cur[k * LDW + c];
       red[tid] = p;
     }
     __syncthreads();
@@ -587,6 +596,277 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
   }
 }
 
+// ---- reverse, ONE LAYER PER LAUNCH ---------------------------------------------------------------------------------
+// For nets whose weight-gradient accumulators do not fit the registers all at once (7+ layers wider than 64; widths 129..256:
+// a 256 x 256 layer alone is 128 registers per lane).  Launch l = L..1 reads (zbar | zdbar)_l of a tile from HBM (layer L:
+// forms it from the seeds), the stored (a | ad)_{l-1}, accumulates dW_l, db_l over all tiles in registers and writes
+// (zbar | zdbar)_{l-1} back in the same block layout -- 2 x 2 H floats more HBM traffic per point and layer than the
+// register-resident kernel above, still far from the HBM roofline at these widths.
+// partial: [workgroup][W_l, b_l (, w_o, b_o when l = L)] -- the flat parameter order, so one fixed-order sum adds it to grad.
+template <int RP, int BM, int BN>
+__global__ __launch_bounds__(NT) void vn_wide_lbwd_kernel(VnNet net, Plan pl, int l, const float* __restrict__ theta,
+                                                          const float* __restrict__ wf, VnRows sg, long ntiles,
+                                                          const float* __restrict__ kept, const float* __restrict__ zin,
+                                                          float* __restrict__ zout, int zstride, float* __restrict__ partial,
+                                                          int plen) {
+  extern __shared__ float lds[];
+  constexpr int R = 128 * RP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lm = lane & 15, lk = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* T = lds;
+  float* PV = lds + R * LDW;
+  float* sub = PV + R * LDW;
+  float* sudb = sub + TP;
+  const int L = net.L;
+  const bool top = l == L;
+  const int Hin = net.H[l - 1], Hout = net.H[l];
+  const int ntm = pl.nrt[l - 1], ntn = pl.nrt[l];
+  const int rows0 = 16 * pl.nrt[0];
+
+  f32x4 wacc[BM * BN];      // layer 1 (at most 2 x 16 tiles): wacc[2 rp + a] = tile (a, wave + 8 rp)
+  float bacc[RP], woacc[RP][4], boacc = 0.f;
+#pragma unroll
+  for (int j = 0; j < BM * BN; ++j) wacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rp = 0; rp < RP; ++rp) {
+    bacc[rp] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) woacc[rp][i] = 0.f;
+  }
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long r0 = tile * TP;
+    const float* kt = kept + tile * pl.kept_tile;
+    // ---- stage T = (zbar | zdbar)_l and PV = (a | ad)_{l-1} (layer 1: the inputs) ----
+    TileIn tin{};
+    if (l == 1) tin = tile_in_issue(net, sg, r0, rows0, tid);
+    f32x4 t4[RP][4];
+#pragma unroll
+    for (int rp = 0; rp < RP; ++rp) {
+      const int rt = wave + 8 * rp;
+      if (rt < ntn) {
+        const f32x4* kp = top ? (const f32x4*)(kt + pl.ko[L] + rt * 1024) : (const f32x4*)(zin + tile * zstride + rt * 1024);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) t4[rp][ct] = kp[ct * 64 + lane];
+      }
+      if (l > 1 && rt < ntm) {
+        // (a | ad)_{l-1}: HBM -> registers -> LDS; the epilogue of the input gradient reads it back from there
+        const f32x4* kp = (const f32x4*)(kt + pl.ko[l - 1] + rt * 1024);
+        f32x4 kb[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) kb[ct] = kp[ct * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * rt + 4 * lk + i;
+          *(f32x4*)(PV + m * LDW + 4 * lm) = f32x4{kb[0][i], kb[1][i], kb[2][i], kb[3][i]};
+        }
+      }
+    }
+    if (top) {
+      if (tid < TP) {
+        const long row = r0 + tid;
+        sub[tid] = (row < sg.n) ? sg.ubar[row] : 0.f;
+        sudb[tid] = (row < sg.n && sg.udbar != nullptr) ? sg.udbar[row] : 0.f;
+      }
+      __syncthreads();
+      if (wave == 0 && lane < TP) boacc += sub[lane];
+    }
+#pragma unroll
+    for (int rp = 0; rp < RP; ++rp) {
+      const int rt = wave + 8 * rp;
+      if (rt < ntn) {
+        const int act = net.actl[L];
+        const float* wo = theta + net.woff[L + 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * rt + 4 * lk + i;
+          f32x4 o;
+          if (top) {
+            // output layer: d w_o and (zbar | zdbar)_L from the seeds and the stored (a | ad)_L
+            const bool valid = m < Hout;
+            const float wom = valid ? wo[m] : 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int p = 16 * h + lm;
+              const float ub = sub[p], udb = sudb[p];
+              const float a = t4[rp][h][i], ad = t4[rp][2 + h][i];
+              woacc[rp][i] += ub * a + udb * ad;
+              const float ab = ub * wom, adb = udb * wom;
+              const float sp = w_d1(a, act);
+              o[h] = valid ? ab * sp + w_d2r(a, act) * ad * adb : 0.f;
+              o[2 + h] = valid ? adb * sp : 0.f;
+            }
+          } else {
+            o = f32x4{t4[rp][0][i], t4[rp][1][i], t4[rp][2][i], t4[rp][3][i]};
+          }
+          *(f32x4*)(T + m * LDW + 4 * lm) = o;
+        }
+      }
+    }
+    if (l == 1) tile_in_write(tin, rows0, PV, tid);
+    __syncthreads();      // #1: T and PV complete
+
+    // bias gradient: row sums of the value columns (thread t: 8 of the 32 value columns of row t / 4 [+ 128])
+#pragma unroll
+    for (int rp = 0; rp < RP; ++rp) {
+      const int row = (tid >> 2) + 128 * rp;
+      if (row < Hout) {
+        const float* tr = T + row * LDW + 16 * (tid & 3);
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float2 v = *(const float2*)(tr + 4 * e);
+          acc += v.x + v.y;
+        }
+        bacc[rp] += acc;
+      }
+    }
+    // weight gradient: G[k][n] += sum_col PV[k][col] T[n][col]
+    if (l == 1) {
+#pragma unroll
+      for (int rp = 0; rp < RP; ++rp) {
+        const int tn = wave + 8 * rp;
+        if (tn < ntn) {
+          const float* pa = PV + lm * LDW + lk;
+          const float* pb = T + (16 * tn + lm) * LDW + lk;
+          const bool a1 = ntm > 1;
+#pragma unroll 4
+          for (int cs = 0; cs < 16; ++cs) {
+            const float bv = pb[4 * cs];
+            wacc[2 * rp] = mfma16(pa[4 * cs], bv, wacc[2 * rp]);
+            if (a1) wacc[2 * rp + 1] = mfma16(pa[16 * LDW + 4 * cs], bv, wacc[2 * rp + 1]);
+          }
+        }
+      }
+    } else {
+      const int tm0 = BM * wm, tn0 = BN * wn;
+      if (tm0 < ntm && tn0 < ntn) {
+        // straight-line block (see the register-resident kernel): absent tiles at the ragged edge are multiplied too, their
+        // rows exist in LDS, their accumulators are never written out
+        const float* pa = PV + (16 * tm0 + lm) * LDW + lk;
+        const float* pb = T + (16 * tn0 + lm) * LDW + lk;
+        float av[BM], bv[BN];
+#pragma unroll
+        for (int a = 0; a < BM; ++a) av[a] = pa[16 * a * LDW];
+#pragma unroll
+        for (int b = 0; b < BN; ++b) bv[b] = pb[16 * b * LDW];
+#pragma unroll 2
+        for (int cs = 0; cs < 16; ++cs) {
+          const int cn = cs < 15 ? 4 * (cs + 1) : 0;
+          float nav[BM], nbv[BN];
+#pragma unroll
+          for (int a = 0; a < BM; ++a) nav[a] = pa[16 * a * LDW + cn];
+#pragma unroll
+          for (int b = 0; b < BN; ++b) nbv[b] = pb[16 * b * LDW + cn];
+#pragma unroll
+          for (int b = 0; b < BN; ++b) {
+#pragma unroll
+            for (int a = 0; a < BM; ++a) wacc[a * BN + b] = mfma16(av[a], bv[b], wacc[a * BN + b]);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, BM + BN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, BM * BN, 0);
+#pragma unroll
+          for (int a = 0; a < BM; ++a) av[a] = nav[a];
+#pragma unroll
+          for (int b = 0; b < BN; ++b) bv[b] = nbv[b];
+        }
+      }
+    }
+    // input gradient + adjoint of the activation below: (zbar | zdbar)_{l-1} straight from registers to HBM
+    if (l > 1) {
+      const int actp = net.actl[l - 1];
+#pragma unroll
+      for (int rp = 0; rp < RP; ++rp) {
+        const int rt = wave + 8 * rp;
+        if (rt < ntm) {
+          f32x4 acc[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+          wave_gemm(wf + pl.wto[l], rt, lane, ntn, T, acc, frag_issue(wf + pl.wto[l], rt, lane, ntn));
+          f32x4 zo[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = 16 * rt + 4 * lk + i;
+            const bool valid = m < Hin;
+            const f32x4 pv = *(const f32x4*)(PV + m * LDW + 4 * lm);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float a = pv[h], ad = pv[2 + h];
+              const float ab = acc[h][i], adb = acc[2 + h][i];
+              const float sp = w_d1(a, actp);
+              zo[h][i] = valid ? ab * sp + w_d2r(a, actp) * ad * adb : 0.f;
+              zo[2 + h][i] = valid ? adb * sp : 0.f;
+            }
+          }
+          f32x4* zp = (f32x4*)(zout + tile * zstride + rt * 1024);
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) zp[ct * 64 + lane] = zo[ct];
+        }
+      }
+    }
+    __syncthreads();      // #2: every wave is done with T and PV before the next tile overwrites them
+  }
+
+  // ---- this workgroup's partial of layer l ----
+  float* out = partial + (long)blockIdx.x * plen;
+  if (l == 1) {
+#pragma unroll
+    for (int rp = 0; rp < RP; ++rp) {
+      const int tn = wave + 8 * rp;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (a < ntm && tn < ntn) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 16 * a + 4 * lk + i, col = 16 * tn + lm;
+            if (row < Hin && col < Hout) out[row * Hout + col] = wacc[2 * rp + a][i];
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < BM; ++a) {
+#pragma unroll
+      for (int b = 0; b < BN; ++b) {
+        const int tm = BM * wm + a, tn = BN * wn + b;
+        if (tm < ntm && tn < ntn) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 16 * tm + 4 * lk + i, col = 16 * tn + lm;
+            if (row < Hin && col < Hout) out[row * Hout + col] = wacc[a * BN + b][i];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rp = 0; rp < RP; ++rp) {
+    float v = bacc[rp];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    const int row = (tid >> 2) + 128 * rp;
+    if ((tid & 3) == 0 && row < Hout) out[Hin * Hout + row] = v;
+  }
+  if (top) {
+#pragma unroll
+    for (int rp = 0; rp < RP; ++rp) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = woacc[rp][i];
+        for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+        const int m = 16 * (wave + 8 * rp) + 4 * lk + i;
+        if (lm == 0 && m < Hout) out[Hin * Hout + Hout + m] = v;
+      }
+    }
+    if (wave == 0) {
+      float v = lane < TP ? boacc : 0.f;
+      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) out[Hin * Hout + 2 * Hout] = v;
+    }
+  }
+}
+
 // dst[i] += sum_b part[b][i], fixed order
 __global__ __launch_bounds__(256) void vn_wide_sum_kernel(const float* __restrict__ part, int nparts, long len, float* __restrict__ dst) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -614,11 +894,17 @@ int wfail(char* err, size_t n, const char* fmt, ...) {
 struct VnWide {
   VnNet net{};
   Plan pl{};
-  int variant = 0;              // reverse-kernel instantiation: 0 <4,2,4> (<= 128 wide)  1 <6,2,3> (<= 96)  2 <16,1,2> (<= 64)  3 <6,2,4>
+  // reverse pass: 0 <4,2,4> (<= 4 layers <= 128 wide)  1 <6,2,3> (5-6 layers <= 96)  3 <6,2,4> (5-6 layers <= 128)  2 <16,1,2> (<= 64 wide)
+  // -- all layers in one launch, accumulators in registers --  4 / 5: one launch per layer (7+ layers <= 128 wide / widths 129..256)
+  int variant = 0;
+  int rp = 1;                   // row-tile passes per layer (2: widths 129..256)
   int cus = 256;
   size_t lds_f = 0, lds_b = 0;
   float* wf = nullptr;
   float* part = nullptr;
+  int zstride = 0;              // floats per tile of a (zbar | zdbar) buffer of the layer-serial reverse pass
+  float* zbuf[2] = {nullptr, nullptr};
+  size_t zcap = 0;
   struct Kept { float* buf = nullptr; size_t cap = 0; const float* X = nullptr; long n = 0; bool valid = false; } kept[2];
 };
 
@@ -631,9 +917,7 @@ bool vn_wide_supported(const VnNet& net) {
     if (net.H[l] > hmax) hmax = net.H[l];
     if (net.actl[l] != VN_ACT_SIGMOID && net.actl[l] != VN_ACT_TANH) return false;
   }
-  // the weight-gradient accumulators of all layers live in registers: depth trades against width
-  if (!(net.L <= 6 && hmax <= 128) && hmax > 64) return false;
-  return true;
+  return hmax <= 256;           // two LDS matrices of 256 rows x 64 columns are what a workgroup can hold
 }
 
 int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
@@ -641,10 +925,12 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   VnWide* w = new VnWide();
   w->net = net;
   Plan& pl = w->pl;
-  int rows = 0, off = 0, koff = 0;
+  int rows = 0, off = 0, koff = 0, hm = 0, maxnrt = 0, maxplen = net.P;
   for (int l = 0; l <= net.L; ++l) {
     pl.nrt[l] = (net.H[l] + 15) / 16;
     if (16 * pl.nrt[l] > rows) rows = 16 * pl.nrt[l];
+    if (l >= 1 && net.H[l] > hm) hm = net.H[l];
+    if (l >= 1 && pl.nrt[l] > maxnrt) maxnrt = pl.nrt[l];
   }
   for (int l = 1; l <= net.L; ++l) {
     const int nf = pl.nrt[l] * pl.nrt[l - 1] * 256;
@@ -653,25 +939,27 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
     pl.ko[l] = koff; koff += pl.nrt[l] * 1024;
   }
   pl.wf_floats = off; pl.kept_tile = koff; pl.rows = rows;
-  {
-    int hm = 0;
-    for (int l = 1; l <= net.L; ++l) if (net.H[l] > hm) hm = net.H[l];
-    w->variant = (net.L <= 4) ? 0 : (net.L <= 6 && hm <= 96) ? 1 : (net.L <= 6 && hm > 64) ? 3 : 2;
-  }
+  w->rp = hm > 128 ? 2 : 1;
+  if (hm > 128) w->variant = 5;
+  else if (hm <= 64) w->variant = net.L <= 4 ? 0 : 2;
+  else w->variant = net.L <= 4 ? 0 : net.L > 6 ? 4 : hm <= 96 ? 1 : 3;
+  w->zstride = maxnrt * 1024;
   w->lds_f = ((size_t)2 * rows * LDW + 512) * sizeof(float);
-  w->lds_b = ((size_t)2 * BROWS * LDW + 2 * TP) * sizeof(float);
+  w->lds_b = ((size_t)2 * BROWS * w->rp * LDW + 2 * TP) * sizeof(float);
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     w->cus = prop.multiProcessorCount;
-  hipError_t e = hipFuncSetAttribute((const void*)vn_wide_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_f);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(w->variant == 0 ? (const void*)vn_wide_bwd_kernel<4, 2, 4>
-                            : w->variant == 1 ? (const void*)vn_wide_bwd_kernel<6, 2, 3>
-                            : w->variant == 3 ? (const void*)vn_wide_bwd_kernel<6, 2, 4> : (const void*)vn_wide_bwd_kernel<16, 1, 2>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
+  const void* fk = w->rp == 2 ? (const void*)vn_wide_fwd_kernel<2> : (const void*)vn_wide_fwd_kernel<1>;
+  const void* bk = w->variant == 0 ? (const void*)vn_wide_bwd_kernel<4, 2, 4>
+                   : w->variant == 1 ? (const void*)vn_wide_bwd_kernel<6, 2, 3>
+                   : w->variant == 2 ? (const void*)vn_wide_bwd_kernel<16, 1, 2>
+                   : w->variant == 3 ? (const void*)vn_wide_bwd_kernel<6, 2, 4>
+                   : w->variant == 4 ? (const void*)vn_wide_lbwd_kernel<1, 2, 4> : (const void*)vn_wide_lbwd_kernel<2, 4, 8>;
+  hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_f);
+  if (e == hipSuccess) e = hipFuncSetAttribute(bk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
   if (e == hipSuccess) e = hipMalloc((void**)&w->wf, (size_t)pl.wf_floats * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * net.P * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * maxplen * sizeof(float));
   if (e != hipSuccess) {
     vn_wide_destroy(w);
     return wfail(err, errlen, "vn_wide_create: %s", hipGetErrorString(e));
@@ -684,6 +972,7 @@ void vn_wide_destroy(VnWide* w) {
   if (!w) return;
   if (w->wf) (void)hipFree(w->wf);
   if (w->part) (void)hipFree(w->part);
+  for (float* z : w->zbuf) if (z) (void)hipFree(z);
   for (auto& k : w->kept) if (k.buf) (void)hipFree(k.buf);
   delete w;
 }
@@ -693,6 +982,17 @@ int pack(VnWide* w, const float* theta, hipStream_t s, char* err, size_t errlen)
   hipLaunchKernelGGL(vn_wide_pack_kernel, dim3(32, w->net.L), dim3(256), 0, s, w->net, w->pl, theta, w->wf);
   WHIP(hipGetLastError());
   return 0;
+}
+// grow a device buffer if half of the free memory allows it
+bool reserve(float** buf, size_t* cap, size_t need) {
+  if (need <= *cap) return true;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess || (need - *cap) * sizeof(float) > fr / 2) return false;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr; *cap = 0;
+  if (hipMalloc((void**)buf, need * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  *cap = need;
+  return true;
 }
 }  // namespace
 
@@ -704,23 +1004,27 @@ int vn_wide_forward(VnWide* w, const float* theta, const VnRows& seg, int keep_s
   float* kbuf = nullptr;
   if (keep_slot >= 0 && may_keep) {
     VnWide::Kept& k = w->kept[keep_slot];
-    const size_t need = (size_t)ntiles * w->pl.kept_tile;
-    bool ok = need <= k.cap;
-    if (!ok) {
-      size_t fr = 0, tot = 0;
-      if (hipMemGetInfo(&fr, &tot) == hipSuccess && (need - k.cap) * sizeof(float) <= fr / 2) {
-        if (k.buf) (void)hipFree(k.buf);
-        k.buf = nullptr; k.cap = 0;
-        if (hipMalloc((void**)&k.buf, need * sizeof(float)) == hipSuccess) { k.cap = need; ok = true; }
-        else (void)hipGetLastError();
+    bool ok = reserve(&k.buf, &k.cap, (size_t)ntiles * w->pl.kept_tile);
+    if (ok && w->variant >= 4) {
+      // the layer-serial reverse pass also needs its two (zbar | zdbar) buffers
+      const size_t zneed = (size_t)ntiles * w->zstride;
+      if (zneed > w->zcap) {
+        size_t c0 = w->zcap, c1 = w->zcap;
+        ok = reserve(&w->zbuf[0], &c0, zneed) && reserve(&w->zbuf[1], &c1, zneed);
+        w->zcap = ok ? zneed : 0;
+        if (!ok) { for (float*& z : w->zbuf) { if (z) (void)hipFree(z); z = nullptr; } }
       }
     }
     if (ok) kbuf = k.buf;
   }
   if (int rc = pack(w, theta, s, err, errlen)) return rc;
   const long grid = ntiles < 2l * w->cus ? ntiles : 2l * w->cus;
-  hipLaunchKernelGGL(vn_wide_fwd_kernel, dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf, seg,
-                     ntiles, kbuf);
+  if (w->rp == 2)
+    hipLaunchKernelGGL(vn_wide_fwd_kernel<2>, dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf,
+                       seg, ntiles, kbuf);
+  else
+    hipLaunchKernelGGL(vn_wide_fwd_kernel<1>, dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf,
+                       seg, ntiles, kbuf);
   WHIP(hipGetLastError());
   if (kbuf) {
     VnWide::Kept& k = w->kept[keep_slot];
@@ -744,6 +1048,27 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
   const long ntiles = (seg.n + TP - 1) / TP;
   if (int rc = pack(w, theta, s, err, errlen)) return rc;
   const int grid = (int)(ntiles < (long)w->cus ? ntiles : (long)w->cus);
+  const VnNet& net = w->net;
+  if (w->variant >= 4) {
+    // one launch per layer, last to first; (zbar | zdbar) travels through the two buffers
+    if ((size_t)ntiles * w->zstride > w->zcap) return wfail(err, errlen, "vn_wide_backward: adjoint buffers missing");
+    for (int l = net.L; l >= 1; --l) {
+      const int plen = net.H[l - 1] * net.H[l] + net.H[l] + (l == net.L ? net.H[l] + 1 : 0);
+      const float* zin = w->zbuf[(net.L - l + 1) & 1];
+      float* zout = w->zbuf[(net.L - l) & 1];
+      if (w->variant == 4)
+        hipLaunchKernelGGL((vn_wide_lbwd_kernel<1, 2, 4>), dim3(grid), dim3(NT), w->lds_b, s, net, w->pl, l, theta, (const float*)w->wf,
+                           seg, ntiles, (const float*)k.buf, zin, zout, w->zstride, w->part, plen);
+      else
+        hipLaunchKernelGGL((vn_wide_lbwd_kernel<2, 4, 8>), dim3(grid), dim3(NT), w->lds_b, s, net, w->pl, l, theta, (const float*)w->wf,
+                           seg, ntiles, (const float*)k.buf, zin, zout, w->zstride, w->part, plen);
+      WHIP(hipGetLastError());
+      hipLaunchKernelGGL(vn_wide_sum_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, s, (const float*)w->part, grid,
+                         (long)plen, grad + net.woff[l]);
+      WHIP(hipGetLastError());
+    }
+    return 0;
+  }
 #define VN_WIDE_BWD(ML_, BM_, BN_)                                                                                     \
   hipLaunchKernelGGL((vn_wide_bwd_kernel<ML_, BM_, BN_>), dim3(grid), dim3(NT), w->lds_b, s, w->net, w->pl, theta,         \
                      (const float*)w->wf, seg, ntiles, (const float*)k.buf, w->part)
