@@ -61,7 +61,7 @@ enum { VN_OPT_ADAM = 0, VN_OPT_RMSPROP = 1 };   /* tf.train.AdamOptimizer / RMSP
 enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 /* 4 waves, 32x32x2 */,
        VN_KERNEL_FUSED16 = 3 /* 8 waves, 16x16x4 */,
        /* Layer-by-layer route for networks outside the kernels' range (more than 6 hidden layers, widths above 64,
-        * more than 8 inputs).  Hidden widths <= 128 (<= 6 layers; <= 64 at any depth): tile
+        * more than 8 inputs).  Hidden widths <= 256: tile
         * kernels that carry 32 points through all layers with the activations in LDS and keep (a, ad) of every layer
         * in HBM for the reverse kernel (6 F_pt per point).  Otherwise: activations of a chunk of rows live in HBM,
         * every layer is one GEMM over the stacked (value, tangent) rows -- rocBLAS, loaded with dlopen at first use --

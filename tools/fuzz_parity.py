@@ -1,7 +1,7 @@
 """Randomised cross-check of the independent GPU routes on the same inputs: the AUTO kernel choice (fused16 / fused32 /
 two-pass / generic / layer-by-layer), the generic kernels and both forms of the layer-by-layer route (the tile kernels of
-vn_wide.hip for nets up to 128 wide, route id 4; the GEMM form of vn_layered.hip, shown as 40), whichever can run a case: random depth, widths (uniform and ragged; one case in five beyond the kernels' range: up to 9 layers,
-150 wide), d_in, dim, integNum, source / integW / detJvec / per-row tables, sizes from one tile to several tiles per
+vn_wide.hip for nets up to 256 wide, route id 4; the GEMM form of vn_layered.hip, shown as 40), whichever can run a case: random depth, widths (uniform and ragged; one case in five beyond the kernels' range: up to 9 layers,
+300 wide), d_in, dim, integNum, source / integW / detJvec / per-row tables, sizes from one tile to several tiles per
 workgroup.   python tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
@@ -41,9 +41,9 @@ for case in range(ncases):
     L = int(rng.integers(1, 10 if beyond else 7))
     act = 'tanh' if rng.random() < 0.3 else 'sigmoid'
     if rng.random() < 0.5:
-        widths = [int(rng.choice([7, 10, 20, 30, 32, 33, 40, 48, 49, 50, 51, 56, 60, 63, 64] + ([65, 96, 100, 128, 150] if beyond else [])))] * L
+        widths = [int(rng.choice([7, 10, 20, 30, 32, 33, 40, 48, 49, 50, 51, 56, 60, 63, 64] + ([65, 96, 100, 128, 150, 200, 256, 300] if beyond else [])))] * L
     else:
-        widths = [int(rng.integers(1, 151 if beyond else 65)) for _ in range(L)]
+        widths = [int(rng.integers(1, 301 if beyond else 65)) for _ in range(L)]
     dim = int(rng.integers(1, 4)); td = True
     d_in = dim + 1 + int(rng.integers(0, 2))
     q = int(rng.choice([4, 8, 16, 27, 32, 36, 64, 128, 216, 256, 1296]))     # 256: 3D+t 2-point, 1296: 3D+t 3-point Gauss

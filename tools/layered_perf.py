@@ -1,6 +1,6 @@
 """Step time of the layer-by-layer route (vn_layered.hip, vn_wide.hip) on config-3 sized inputs (100 000 test functions x 64
 points):   python tools/layered_perf.py "128,128,128" ["50,50,50,50,50" ...]
-A net the fused kernels cover is run on both routes; a net the tile kernels of vn_wide.hip take (up to 128 wide) is also run on
+A net the fused kernels cover is run on both routes; a net the tile kernels of vn_wide.hip take (up to 256 wide) is also run on
 the GEMM form of the route (VN_LAYERED_NOWIDE=1), shown as route 4/gemms."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')

@@ -161,7 +161,7 @@ int vn_layered_residual_f64(VnLayered* w, const double* theta, const double* X, 
                             const double* src, const double* ddx, int td, long n, double* u, double* res, hipStream_t s,
                             char* err, size_t errlen);
 
-// ---- tile kernels of the layer-by-layer route for hidden widths <= 128: vn_wide.hip -------------------------------
+// ---- tile kernels of the layer-by-layer route for hidden widths <= 256: vn_wide.hip -------------------------------
 // A workgroup carries 32 points through all layers with the activations in LDS; the forward stores (a, ad) of every layer
 // in HBM for the reverse kernel.  vn_layered.hip hands qualifying networks over (VN_LAYERED_NOWIDE=1 keeps them on the GEMMs).
 struct VnWide;

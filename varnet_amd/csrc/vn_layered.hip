@@ -18,7 +18,7 @@
 // evaluation is forward (all rows) -> seed kernel -> reverse (all rows): the forward KEEPS the activations of all rows in
 // HBM when they fit half of the free memory (6.4 M rows of a 3 x 256 net: 39 GB of the 288) and the reverse pass reads
 // them -- 6 F_pt per interior point; otherwise the reverse pass recomputes them per chunk (8 F_pt).
-// Networks up to 128 wide do not run their training passes here: vn_wide.hip carries tiles of 32 points through all layers
+// Networks up to 256 wide do not run their training passes here: vn_wide.hip carries tiles of 32 points through all layers
 // with the activations in LDS (3x faster; VN_LAYERED_NOWIDE=1 keeps them on the GEMMs, which also remain the fallback
 // when the stored activations do not fit, and serve the residual and fp64 entry points).
 #include "vn_internal.h"
@@ -356,7 +356,7 @@ struct VnLayered {
     const float* X = nullptr; long n = 0, c = 0; int S = 0; bool valid = false;
   } kept[2];
   bool never_keep = false;                      // VN_LAYERED_NOKEEP=1: always recompute (tests run both ways)
-  VnWide* wide = nullptr;                       // tile kernels for the training passes of nets up to 128 wide (vn_wide.hip)
+  VnWide* wide = nullptr;                       // tile kernels for the training passes of nets up to 256 wide (vn_wide.hip)
 };
 
 namespace {

@@ -1,4 +1,4 @@
-// Tile kernels of the layer-by-layer route for hidden widths up to 128 (vn_layered.hip hands such networks over).
+// Tile kernels of the layer-by-layer route for hidden widths up to 256 (vn_layered.hip hands such networks over).
 //
 // Why: with one GEMM per layer a 128-wide layer moves 16 B of HBM per 2*128 FLOP in each direction -- the GEMM route is
 // HBM-bound there (3 x 128 at 6.4 M points: 91 ms = 0.18 of the fp32 MFMA peak).  Here a workgroup carries a tile of 32
@@ -27,7 +27,11 @@
 //     MFMAs), accumulated in registers over all tiles of the launch and written once as a per-workgroup partial that a
 //     fixed-order sum adds to the gradient (no atomics: same bits every run); the input gradient is the forward loop with
 //     the W^T image, its epilogue forms (zbar, zdbar) of the layer below in registers.  Two barriers per layer.
-// Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 27.0 ms = 0.60 of peak (GEMM form 90.8 ms), 4 x 128 0.63.
+//   * widths 129..256: two row-tile passes per wave and layer (LDS matrices of 256 rows); nets whose accumulators do not fit
+//     the registers all at once (7+ layers wider than 64, widths above 128) run the reverse pass one layer per launch
+//     (vn_wide_lbwd_kernel: accumulators of one layer in registers, the adjoints travel through HBM).
+// Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 27.0 ms = 0.60 of peak (GEMM form 90.8 ms), 4 x 128 0.63,
+// 8 x 128 0.60, 3 x 256 120.6 ms = 0.54 (GEMM form 176 ms).
 #include "vn_internal.h"
 
 #include <cstdarg>
