@@ -947,6 +947,11 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   if (hm > 128) w->variant = 5;
   else if (hm <= 64) w->variant = net.L <= 4 ? 0 : 2;
   else w->variant = net.L <= 4 ? 0 : net.L > 6 ? 4 : hm <= 96 ? 1 : 3;
+  {
+    // diagnostic: VN_WIDE_SERIAL=1 runs every net up to 128 wide on the layer-serial reverse pass (what it costs, measured)
+    const char* sv = getenv("VN_WIDE_SERIAL");
+    if (sv && *sv && *sv != '0' && hm <= 128) w->variant = 4;
+  }
   w->zstride = maxnrt * 1024;
   w->lds_f = ((size_t)2 * rows * LDW + 512) * sizeof(float);
   w->lds_b = ((size_t)2 * BROWS * w->rp * LDW + 2 * TP) * sizeof(float);
