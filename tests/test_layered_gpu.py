@@ -22,6 +22,8 @@ CASES = [
     (3, 2, [96, 80, 96, 72, 96],      16,      21,  40, 15,  False, True,  False),   # tile kernels: <6,2,3> instantiation
     (3, 2, [128, 112, 128, 100, 128, 120], 16, 9,   30, 12,  True,  False, False),   # ... <6,2,4>
     (2, 1, [64, 50, 64, 33, 64, 64, 40, 64, 64], 16, 15, 30, 10, False, False, True),   # ... <16,1,2>
+    (3, 2, [200, 256, 130, 180],      16,      7,   20, 9,   True,  True,  False),   # ... two row-tile passes, layer-serial reverse
+    (4, 3, [128] * 8,                 8,       9,   20, 9,   False, False, False),   # ... layer-serial reverse at 128
     (2, 1, [20] * 8,                  16,      40,  50, 30,  False, False, False),   # more than 6 hidden layers
     (3, 2, [30, 70, 12, 65, 9, 40, 33], 36,    17,  12, 5,   True,  True,  True),    # ragged, 7 layers
     (10, 2, [40, 40],                 64,      12,  30, 10,  False, True,  False),   # more than 8 inputs (many MOR parameters)
