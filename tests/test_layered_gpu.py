@@ -20,7 +20,7 @@ CASES = [
     (3, 2, [100, 80],                 64,      9,   77, 40,  False, False, False),   # wider than 64
     (3, 2, [128, 128, 128],           64,      30,  50, 20,  True,  False, True),
     (3, 2, [96, 80, 96, 72, 96],      16,      21,  40, 15,  False, True,  False),   # tile kernels: <6,2,3> instantiation
-    (3, 2, [128, 112, 128, 100, 128, 120], 16, 9,   30, 12,  True,  False, False),   # ... <6,2,4>
+    (3, 2, [128, 112, 128, 100, 128, 120], 16, 9,   30, 12,  True,  False, False),   # ... layer-serial reverse (5+ layers wider than 96)
     (2, 1, [64, 50, 64, 33, 64, 64, 40, 64, 64], 16, 15, 30, 10, False, False, True),   # ... <16,1,2>
     (3, 2, [200, 256, 130, 180],      16,      7,   20, 9,   True,  True,  False),   # ... two row-tile passes, layer-serial reverse
     (4, 3, [128] * 8,                 8,       9,   20, 9,   False, False, False),   # ... layer-serial reverse at 128

@@ -31,7 +31,7 @@
 //     the registers all at once (7+ layers wider than 64, widths above 128) run the reverse pass one layer per launch
 //     (vn_wide_lbwd_kernel: accumulators of one layer in registers, the adjoints travel through HBM).
 // Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 27.0 ms = 0.60 of peak (GEMM form 90.8 ms), 4 x 128 0.63,
-// 8 x 128 0.60, 3 x 256 120.6 ms = 0.54 (GEMM form 176 ms).
+// 8 x 128 0.64, 3 x 256 120.3 ms = 0.54 (GEMM form 176 ms).
 #include "vn_internal.h"
 
 #include <cstdarg>
@@ -601,14 +601,15 @@ __global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, con
 }
 
 // ---- reverse, ONE LAYER PER LAUNCH ---------------------------------------------------------------------------------
-// For nets whose weight-gradient accumulators do not fit the registers all at once (7+ layers wider than 64; widths 129..256:
-// a 256 x 256 layer alone is 128 registers per lane).  Launch l = L..1 reads (zbar | zdbar)_l of a tile from HBM (layer L:
+// For nets whose weight-gradient accumulators do not fit the registers all at once (5+ layers wider than 96, 7+ wider than 64;
+// widths 129..256: a 256 x 256 layer alone is 128 registers per lane).  Launch l = L..1 reads (zbar | zdbar)_l of a tile from HBM (layer L:
 // forms it from the seeds), the stored (a | ad)_{l-1}, accumulates dW_l, db_l over all tiles in registers and writes
 // (zbar | zdbar)_{l-1} back in the same block layout -- 2 x 2 H floats more HBM traffic per point and layer than the
 // register-resident kernel above, still far from the HBM roofline at these widths.
 // partial: [workgroup][W_l, b_l (, w_o, b_o when l = L)] -- the flat parameter order, so one fixed-order sum adds it to grad.
+// (one row-tile pass: capped at 128 registers so that two workgroups share a CU -- one layer's accumulators are only 32)
 template <int RP, int BM, int BN>
-__global__ __launch_bounds__(NT) void vn_wide_lbwd_kernel(VnNet net, Plan pl, int l, const float* __restrict__ theta,
+__global__ __launch_bounds__(NT, RP == 1 ? 4 : 2) void vn_wide_lbwd_kernel(VnNet net, Plan pl, int l, const float* __restrict__ theta,
                                                           const float* __restrict__ wf, VnRows sg, long ntiles,
                                                           const float* __restrict__ kept, const float* __restrict__ zin,
                                                           float* __restrict__ zout, int zstride, float* __restrict__ partial,
@@ -898,8 +899,8 @@ int wfail(char* err, size_t n, const char* fmt, ...) {
 struct VnWide {
   VnNet net{};
   Plan pl{};
-  // reverse pass: 0 <4,2,4> (<= 4 layers <= 128 wide)  1 <6,2,3> (5-6 layers <= 96)  3 <6,2,4> (5-6 layers <= 128)  2 <16,1,2> (<= 64 wide)
-  // -- all layers in one launch, accumulators in registers --  4 / 5: one launch per layer (7+ layers <= 128 wide / widths 129..256)
+  // reverse pass: 0 <4,2,4> (<= 4 layers <= 128 wide)  1 <6,2,3> (5-6 layers <= 96)  2 <16,1,2> (<= 64 wide) -- all layers in one
+  // launch, accumulators in registers --  4 / 5: one launch per layer (5+ layers wider than 96, 7+ wider than 64 / widths 129..256)
   int variant = 0;
   int rp = 1;                   // row-tile passes per layer (2: widths 129..256)
   int cus = 256;
@@ -946,7 +947,7 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   w->rp = hm > 128 ? 2 : 1;
   if (hm > 128) w->variant = 5;
   else if (hm <= 64) w->variant = net.L <= 4 ? 0 : 2;
-  else w->variant = net.L <= 4 ? 0 : net.L > 6 ? 4 : hm <= 96 ? 1 : 3;
+  else w->variant = net.L <= 4 ? 0 : (net.L <= 6 && hm <= 96) ? 1 : 4;
   {
     // diagnostic: VN_WIDE_SERIAL=1 runs every net up to 128 wide on the layer-serial reverse pass (what it costs, measured)
     const char* sv = getenv("VN_WIDE_SERIAL");
@@ -963,12 +964,11 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   const void* bk = w->variant == 0 ? (const void*)vn_wide_bwd_kernel<4, 2, 4>
                    : w->variant == 1 ? (const void*)vn_wide_bwd_kernel<6, 2, 3>
                    : w->variant == 2 ? (const void*)vn_wide_bwd_kernel<16, 1, 2>
-                   : w->variant == 3 ? (const void*)vn_wide_bwd_kernel<6, 2, 4>
                    : w->variant == 4 ? (const void*)vn_wide_lbwd_kernel<1, 2, 4> : (const void*)vn_wide_lbwd_kernel<2, 4, 8>;
   hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_f);
   if (e == hipSuccess) e = hipFuncSetAttribute(bk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
   if (e == hipSuccess) e = hipMalloc((void**)&w->wf, (size_t)pl.wf_floats * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * maxplen * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * (w->variant == 4 ? 2 : 1) * maxplen * sizeof(float));
   if (e != hipSuccess) {
     vn_wide_destroy(w);
     return wfail(err, errlen, "vn_wide_create: %s", hipGetErrorString(e));
@@ -1056,7 +1056,8 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
   k.valid = false;                                  // theta moves after this step
   const long ntiles = (seg.n + TP - 1) / TP;
   if (int rc = pack(w, theta, s, err, errlen)) return rc;
-  const int grid = (int)(ntiles < (long)w->cus ? ntiles : (long)w->cus);
+  const long wgs = (long)w->cus * (w->variant == 4 ? 2 : 1);        // layer-serial, one pass: two workgroups per CU
+  const int grid = (int)(ntiles < wgs ? ntiles : wgs);
   const VnNet& net = w->net;
   if (w->variant >= 4) {
     // one launch per layer, last to first; (zbar | zdbar) travels through the two buffers
@@ -1083,7 +1084,6 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
                      (const float*)w->wf, seg, ntiles, (const float*)k.buf, w->part)
   if (w->variant == 0) VN_WIDE_BWD(4, 2, 4);
   else if (w->variant == 1) VN_WIDE_BWD(6, 2, 3);
-  else if (w->variant == 3) VN_WIDE_BWD(6, 2, 4);
   else VN_WIDE_BWD(16, 1, 2);
 #undef VN_WIDE_BWD
   WHIP(hipGetLastError());
