@@ -30,8 +30,8 @@
 //   * widths 129..256: two row-tile passes per wave and layer (LDS matrices of 256 rows); nets whose accumulators do not fit
 //     the registers all at once (7+ layers wider than 64, widths above 128) run the reverse pass one layer per launch
 //     (vn_wide_lbwd_kernel: accumulators of one layer in registers, the adjoints travel through HBM).
-// Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 27.0 ms = 0.60 of peak (GEMM form 90.8 ms), 4 x 128 0.63,
-// 8 x 128 0.64, 3 x 256 120.3 ms = 0.54 (GEMM form 176 ms).
+// Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 26.7 ms = 0.61 of peak (GEMM form 90.8 ms), 4 x 128 0.63,
+// 8 x 128 0.66, 3 x 256 120.3 ms = 0.54 (GEMM form 176 ms).
 #include "vn_internal.h"
 
 #include <cstdarg>
@@ -872,13 +872,31 @@ __global__ __launch_bounds__(NT, RP == 1 ? 4 : 2) void vn_wide_lbwd_kernel(VnNet
   }
 }
 
-// dst[i] += sum_b part[b][i], fixed order
-__global__ __launch_bounds__(256) void vn_wide_sum_kernel(const float* __restrict__ part, int nparts, long len, float* __restrict__ dst) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= len) return;
+// dst[i] += sum_b part[b][i], fixed order: 64 elements x 8 groups of partials per workgroup; group g adds the contiguous run
+// of partials [g n/8, (g+1) n/8), the eight group sums meet in LDS in a fixed order
+constexpr int SUMG = 8;
+__global__ __launch_bounds__(64 * SUMG) void vn_wide_sum_kernel(const float* __restrict__ part, int nparts, long len, float* __restrict__ dst) {
+  __shared__ float red[SUMG][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + tx;
   float acc = 0.f;
-  for (int b = 0; b < nparts; ++b) acc += part[(long)b * len + i];
-  dst[i] += acc;
+  if (i < len) {
+    const int per = (nparts + SUMG - 1) / SUMG;
+    const int b0 = g * per, b1 = b0 + per < nparts ? b0 + per : nparts;
+    const float* p = part + i;
+    int bb = b0;
+    for (; bb + 4 <= b1; bb += 4)
+      acc += (p[(long)bb * len] + p[(long)(bb + 1) * len]) + (p[(long)(bb + 2) * len] + p[(long)(bb + 3) * len]);
+    for (; bb < b1; ++bb) acc += p[(long)bb * len];
+  }
+  red[g][tx] = acc;
+  __syncthreads();
+  if (g == 0 && i < len) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < SUMG; ++k) v += red[k][tx];
+    dst[i] += v;
+  }
 }
 
 int wfail(char* err, size_t n, const char* fmt, ...) {
@@ -1073,7 +1091,7 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
         hipLaunchKernelGGL((vn_wide_lbwd_kernel<2, 4, 8>), dim3(grid), dim3(NT), w->lds_b, s, net, w->pl, l, theta, (const float*)w->wf,
                            seg, ntiles, (const float*)k.buf, zin, zout, w->zstride, w->part, plen);
       WHIP(hipGetLastError());
-      hipLaunchKernelGGL(vn_wide_sum_kernel, dim3((unsigned)((plen + 255) / 256)), dim3(256), 0, s, (const float*)w->part, grid,
+      hipLaunchKernelGGL(vn_wide_sum_kernel, dim3((unsigned)((plen + 63) / 64)), dim3(64 * SUMG), 0, s, (const float*)w->part, grid,
                          (long)plen, grad + net.woff[l]);
       WHIP(hipGetLastError());
     }
@@ -1087,7 +1105,7 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
   else VN_WIDE_BWD(16, 1, 2);
 #undef VN_WIDE_BWD
   WHIP(hipGetLastError());
-  hipLaunchKernelGGL(vn_wide_sum_kernel, dim3((unsigned)((w->net.P + 255) / 256)), dim3(256), 0, s, (const float*)w->part, grid,
+  hipLaunchKernelGGL(vn_wide_sum_kernel, dim3((unsigned)((w->net.P + 63) / 64)), dim3(64 * SUMG), 0, s, (const float*)w->part, grid,
                      (long)w->net.P, grad);
   WHIP(hipGetLastError());
   return 0;
