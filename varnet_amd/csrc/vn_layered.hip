@@ -324,13 +324,32 @@ __global__ __launch_bounds__(EB) void k_colsum_part_narrow(const float* __restri
     __syncthreads();
   }
 }
-// dst[i] += sum_b part[b][i], fixed order
-__global__ __launch_bounds__(EB) void k_sum_parts(const float* __restrict__ part, int nparts, long len, float* __restrict__ dst) {
-  const long i = (long)blockIdx.x * EB + threadIdx.x;
-  if (i >= len) return;
+// dst[i] += sum_b part[b][i], fixed order: 64 elements x 8 groups of partials per workgroup; group g adds the contiguous run
+// of partials [g n/8, (g+1) n/8), the eight group sums meet in LDS in a fixed order (one thread per element walking all
+// partials left a few workgroups with a chain of thousands of dependent adds)
+constexpr int SUMG = 8;
+__global__ __launch_bounds__(64 * SUMG) void k_sum_parts(const float* __restrict__ part, int nparts, long len, float* __restrict__ dst) {
+  __shared__ float red[SUMG][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + tx;
   float acc = 0.f;
-  for (int b = 0; b < nparts; ++b) acc += part[(long)b * len + i];
-  dst[i] += acc;
+  if (i < len) {
+    const int per = (nparts + SUMG - 1) / SUMG;
+    const int b0 = g * per, b1 = b0 + per < nparts ? b0 + per : nparts;
+    const float* p = part + i;
+    int bb = b0;
+    for (; bb + 4 <= b1; bb += 4)
+      acc += (p[(long)bb * len] + p[(long)(bb + 1) * len]) + (p[(long)(bb + 2) * len] + p[(long)(bb + 3) * len]);
+    for (; bb < b1; ++bb) acc += p[(long)bb * len];
+  }
+  red[g][tx] = acc;
+  __syncthreads();
+  if (g == 0 && i < len) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < SUMG; ++k) v += red[k][tx];
+    dst[i] += v;
+  }
 }
 
 inline unsigned blocks(long n) { return (unsigned)((n + EB - 1) / EB); }
@@ -390,7 +409,7 @@ int colsum_add(VnLayered* w, const float* A, const float* x, long n, int H, floa
   else hipLaunchKernelGGL(k_colsum_part_narrow, dim3(nb), dim3(EB), 0, s, A, x, n, H, w->part);
   LHIP(hipGetLastError());
   LTRACE(s, "colsum partial kernel done");
-  hipLaunchKernelGGL(k_sum_parts, dim3(blocks(H)), dim3(EB), 0, s, w->part, nb, (long)H, dst);
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((H + 63) / 64)), dim3(64 * SUMG), 0, s, w->part, nb, (long)H, dst);
   LHIP(hipGetLastError());
   return 0;
 }
@@ -416,7 +435,7 @@ int wgrad_add(VnLayered* w, const float* A, const float* Zbar, long M, int Hin, 
   if (rest > 0)
     LBLAS(g_blas.sgemm(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rest, &one,
                        Zbar + (long)G * rows * Hout, Hout, A + (long)G * rows * Hin, Hin, &zero, w->part + (long)G * len, Hout));
-  hipLaunchKernelGGL(k_sum_parts, dim3(blocks(len)), dim3(EB), 0, s, w->part, np, len, dW);
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((len + 63) / 64)), dim3(64 * SUMG), 0, s, w->part, np, len, dW);
   LHIP(hipGetLastError());
   return 0;
 }
