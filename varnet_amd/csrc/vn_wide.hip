@@ -28,10 +28,11 @@
 //     fixed-order sum adds to the gradient (no atomics: same bits every run); the input gradient is the forward loop with
 //     the W^T image, its epilogue forms (zbar, zdbar) of the layer below in registers.  Two barriers per layer.
 //   * widths 129..256: two row-tile passes per wave and layer (LDS matrices of 256 rows); nets whose accumulators do not fit
-//     the registers all at once (7+ layers wider than 64, widths above 128) run the reverse pass one layer per launch
-//     (vn_wide_lbwd_kernel: accumulators of one layer in registers, the adjoints travel through HBM).
-// Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 26.7 ms = 0.61 of peak (GEMM form 90.8 ms), 4 x 128 0.63,
-// 8 x 128 0.66, 3 x 256 120.3 ms = 0.54 (GEMM form 176 ms).
+//     the registers all at once (5+ layers wider than 96, 7+ wider than 64, widths above 128) run the reverse pass one layer per
+//     launch (vn_wide_lbwd_kernel: accumulators of one layer in registers, the adjoints travel through HBM; up to 128 wide it
+//     is cut to 128 registers and two workgroups share a CU).
+// Measured at 6.4 M points (profiles/r2_layered_perf.txt): 3 x 128 26.7 ms = 0.61 of peak (GEMM form 86 ms), 4 x 128 0.63,
+// 8 x 128 0.66, 3 x 256 120.8 ms = 0.53 (GEMM form 172 ms).
 #include "vn_internal.h"
 
 #include <cstdarg>
