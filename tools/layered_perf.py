@@ -19,7 +19,8 @@ for spec in sys.argv[1:]:
     Fpt = 2 * sum(a * b for a, b in zip([d_in] + widths, widths + [1]))
     in_range = len(widths) <= 6 and max(widths) <= 64
     tiles = max(widths) <= 256
-    for kernel in ((0, 4) if in_range else (0,)) + ((40,) if tiles else ()):
+    gemm_leg = tiles and not os.environ.get('VN_PERF_TILES_ONLY')      # counter passes skip the GEMM leg (hundreds of launches, each serialised)
+    for kernel in ((0, 4) if in_range else (0,)) + ((40,) if gemm_leg else ()):
         if kernel == 40:
             os.environ['VN_LAYERED_NOWIDE'] = '1'
         e = VNEngine(dim, d_in, widths, True, q, kernel=4 if kernel == 40 else kernel)

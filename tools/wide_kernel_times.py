@@ -6,7 +6,7 @@ f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     n = r['Kernel_Name']
-    if 'vn_wide_fwd' in n or 'vn_wide_bwd' in n:
+    if 'vn_wide_fwd' in n or 'bwd_kernel' in n:
         agg['fwd' if 'fwd' in n else 'bwd'].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
 lab = sys.argv[2] if len(sys.argv) > 2 else ''
 print('%-28s' % lab + '  '.join('%s %.2f ms (median of the %d interior launches)' % (k, sorted(x for x in v if x > 1.0)[len([x for x in v if x > 1.0]) // 2], len([x for x in v if x > 1.0])) for k, v in sorted(agg.items())))

@@ -5,6 +5,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd $root
 out=gpurun_out/wide_pmc
+export VN_PERF_TILES_ONLY=1      # the GEMM leg of layered_perf.py under counters takes many minutes
 rm -rf $out; mkdir -p $out
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $grp | cut -d' ' -f1)
@@ -16,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/wide_pmc/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if 'vn_wide_fwd' in n or 'vn_wide_bwd' in n:
+        if 'vn_wide_fwd' in n or 'bwd_kernel' in n:
             agg['fwd' if 'fwd' in n else 'bwd'][r['Counter_Name']].append(float(r['Counter_Value']))
 with open('gpurun_out/wide_pmc/summary.txt', 'w') as o:
     for k in sorted(agg):
