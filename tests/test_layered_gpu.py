@@ -212,6 +212,37 @@ def test_adam_trajectory_parity_layered():
     eng.close()
 
 
+@pytest.mark.parametrize('widths', [[128, 96, 128], [128] * 7, [200, 256]], ids=['one-launch', 'layer-serial', 'two-passes'])
+def test_long_trajectory_tile_kernels_against_the_gemm_form(widths, monkeypatch):
+    """600 TF-1 Adam steps from the same start on both implementations of the route (tile kernels of vn_wide.hip, GEMM form): two
+    fp32 programs with different summation orders stay within 1e-3 in relative loss, and end at the same parameters to 1e-3."""
+    d_in, dim, integNum, n_k, nB, bDof = 3, 2, 64, 37, 90, 50
+    d = synth(11, d_in, dim, widths, integNum, n_k, nB, bDof)
+    runs = []
+    for gemms in (False, True):
+        if gemms:
+            monkeypatch.setenv('VN_LAYERED_NOWIDE', '1')
+        eng = make_engine(d_in, dim, widths, integNum, False, False, 0)
+        monkeypatch.delenv('VN_LAYERED_NOWIDE', raising=False)
+        assert eng.kernel_path()[0] == LAYERED
+        eng.init_params(seed=4)
+        eng.set_fe_table(d['N1'], d['dNt1'], None)
+        eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=n_k, detJ=d['detJ'])
+        eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+        eng.set_weights(d['w'])
+        steps = 600
+        losses = torch.zeros(steps, device='cuda')
+        for i in range(steps):
+            eng.train_step(0, losses[i:i + 1])
+        torch.cuda.synchronize()
+        runs.append((losses.cpu().numpy().astype(np.float64), eng.get_params().astype(np.float64)))
+        eng.close()
+    (la, ta), (lb, tb) = runs
+    assert la[-1] < la[0]
+    assert np.max(np.abs(la - lb) / np.abs(lb)) <= 1e-3
+    assert np.max(np.abs(ta - tb)) <= 1e-3 * np.max(np.abs(tb))
+
+
 def test_varnet_constructor_accepts_a_wide_deep_net(tmp_path):
     """The kept constructor with a layerWidth the kernels do not cover trains end to end (Operator_1Dt problem)."""
     from tests.test_varnet_host import op1dt
