@@ -85,13 +85,19 @@ typedef struct vn_config {
   int32_t device;                   /* HIP device ordinal                                  */
   int32_t optimizer;                /* VN_OPT_ADAM | VN_OPT_RMSPROP (TFModel.py:183-186)   */
   int32_t kernel;                   /* VN_KERNEL_*                                         */
-  double  lr, beta1, beta2, eps;    /* TF-1 Adam defaults 1e-3, .9, .999, 1e-8             */
+  double  lr, beta1, beta2, eps;    /* taken literally, NO defaulting (TF-1's own defaults are 1e-3, .9, .999, 1e-8).  lr >= 0
+                                     * (lr = 0 is legal TF: TFModel.py:130).  With VN_OPT_ADAM: 0 <= beta1, beta2 < 1 and
+                                     * eps > 0, else vn_create returns VN_EINVAL -- a zero-initialised struct (eps = 0 turns a
+                                     * zero gradient into 0/0 = NaN in the update) is rejected, not trained.  RMSProp ignores
+                                     * beta1, beta2, eps (TF-1 constants: decay 0.9, momentum 0, epsilon 1e-10).           */
   int32_t layer_act[VN_MAX_LAYERS]; /* with VN_ACT_PER_LAYER: VN_ACT_SIGMOID | VN_ACT_TANH of hidden layer i */
 } vn_config;
 
 const char* vn_last_error(void);
 int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_kernel_path, vn_profile_comm;
-                                * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, layer_act, VN_KERNEL_LAYERED */
+                                * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, layer_act, VN_KERNEL_LAYERED;
+                                * 4: vn_comm_available, Adam hyper-parameters validated (no silent NaN from a zeroed config) */
+#define VN_ABI_VERSION 4     /* what this header describes: a binding must refuse a library that reports another number */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
 int vn_create(const vn_config* cfg, vn_engine** out);
@@ -202,6 +208,9 @@ int vn_residual_f64(vn_engine* h, const double* X_dev, const double* diff_dev,
  * three calls.  RCCL is loaded at run time (librccl.so.1 by SONAME, or $VN_RCCL_LIB); without it these four
  * entry points return VN_EUNSUPPORTED and everything else works. */
 #define VN_COMM_ID_BYTES 128
+/* VN_OK if RCCL can be loaded in this process (no collective, no GPU work): lets every rank probe locally BEFORE any
+ * rank enters the collective bootstrap, so that all ranks take the same route. */
+int vn_comm_available(void);
 int vn_comm_unique_id(void* id_out_host);
 int vn_comm_init(vn_engine* h, int32_t rank, int32_t world, const void* unique_id_host);
 /* Ranks RCCL reports for the attached communicator (1 if none); rank_out may be NULL. */

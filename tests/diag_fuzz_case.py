@@ -1,4 +1,4 @@
-"""Which route is off?  Loads gpurun_out/fuzz_mismatch.npz (written by tools/fuzz_parity.py when two GPU routes disagree)
+"""Which route is off?  Loads gpurun_out/fuzz_mismatch.npz (written by tests/fuzz_routes.py when two GPU routes disagree)
 and compares every route's gradient with the fp64 oracle and with the oracle run in fp32.
     python tests/diag_fuzz_case.py"""
 import os, sys

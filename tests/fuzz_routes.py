@@ -1,0 +1,202 @@
+"""
+Randomised cross-check of the independent GPU routes on the same inputs, WITH the oracle in the loop (test
+infrastructure: lives under tests/ because it uses oracle/).
+
+Routes: the AUTO kernel choice (8-wave fused / two-pass / layer-by-layer), the generic kernels, and both forms of the
+layer-by-layer route (tile kernels of vn_wide.hip = route 4, GEMM form = 40), whichever can run a case.  Cases: random
+depth, widths (uniform and ragged; one in five beyond the fused kernels' range: up to 9 layers, 300 wide), sigmoid /
+tanh, d_in, dim, integNum 4..1296, source / integW / detJvec / per-row tables, one tile to several tiles per workgroup.
+
+Bars:
+  * every route against the fp64 oracle: loss LOSS_BAR, gradient GRAD_BAR (|g - g_ref|_inf / |g_ref|_inf) -- checked on
+    every case of the pytest subsample and on every `oracle_every`-th case of a soak;
+  * routes pairwise: PAIR_BAR = 3e-4.
+  An ill-conditioned draw (the gradient is a small remainder of large cancelling per-row terms) moves EVERY fp32
+  evaluation, the oracle's own fp32 run included.  Its condition estimate is  cond = dev32 / 2^-24,  dev32 = deviation of
+  the oracle run in fp32 from the oracle run in fp64 (same norm).  Only when cond > COND_WHITELIST (dev32 > 1e-4) are the
+  gradient bars widened, to 2 x dev32 -- per case, by its measured conditioning, never globally.
+
+    python -m tests.fuzz_routes [cases] [seed] [oracle_every]      (soak; on the GPU box)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import tf1_graph as og  # noqa: E402
+
+LOSS_BAR = 4e-5              # random nets: loss = sum of squares of cancelling sums (engine parity cases: 1e-5)
+GRAD_BAR = 1e-4
+PAIR_BAR = 3e-4
+U32 = 2.0 ** -24
+COND_WHITELIST = 1e-4 / U32
+
+
+def synth(seed, d_in, dim, widths, integNum, n_k, nB, bDof, source=False, integW=False, detJvec=False):
+    rng = np.random.default_rng(seed)
+    n = n_k * integNum
+    d = dict(Input=rng.uniform(-1, 1, (n, d_in)).astype(np.float32), gcoef=rng.standard_normal((n, dim)).astype(np.float32),
+             source=rng.standard_normal((n, 1)).astype(np.float32) if source else None,
+             N1=rng.uniform(0, 1, integNum).astype(np.float32), dNt1=rng.standard_normal(integNum).astype(np.float32),
+             integW=rng.uniform(0.5, 1.0, (1, integNum)).astype(np.float32) if integW else None,
+             detJ=(rng.uniform(0.1, 0.2, (n_k, 1)).astype(np.float32) if detJvec else np.float32(0.137)),
+             biInput=rng.uniform(-1, 1, (nB, d_in)).astype(np.float32), biLabel=rng.standard_normal((nB, 1)).astype(np.float32),
+             w=np.array([3.0, 2.0, 5.0]))
+    d['N'] = np.tile(d['N1'], n_k).reshape(n, 1)
+    d['dNt'] = np.tile(d['dNt1'], n_k).reshape(n, 1)
+    return d
+
+
+def make_engine(d_in, dim, widths, integNum, source, integW, kernel=0, act='sigmoid'):
+    from varnet_amd.engine import VNEngine
+    if kernel == 40:                            # the layer-by-layer route on its GEMMs (read when the engine is created)
+        os.environ['VN_LAYERED_NOWIDE'] = '1'
+        try:
+            return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=4, activationFun=act)
+        finally:
+            del os.environ['VN_LAYERED_NOWIDE']
+    return VNEngine(dim, d_in, widths, True, integNum, isSource=source, integWflag=integW, kernel=kernel, activationFun=act)
+
+
+def draw_case(rng, case):
+    """One random case; `rng` is advanced exactly as the round-2 tool advanced it (same seeds = same cases)."""
+    beyond = rng.random() < 0.2
+    L = int(rng.integers(1, 10 if beyond else 7))
+    act = 'tanh' if rng.random() < 0.3 else 'sigmoid'
+    if rng.random() < 0.5:
+        widths = [int(rng.choice([7, 10, 20, 30, 32, 33, 40, 48, 49, 50, 51, 56, 60, 63, 64] + ([65, 96, 100, 128, 150, 200, 256, 300] if beyond else [])))] * L
+    else:
+        widths = [int(rng.integers(1, 301 if beyond else 65)) for _ in range(L)]
+    dim = int(rng.integers(1, 4))
+    d_in = dim + 1 + int(rng.integers(0, 2))
+    q = int(rng.choice([4, 8, 16, 27, 32, 36, 64, 128, 216, 256, 1296]))     # 256: 3D+t 2-point, 1296: 3D+t 3-point Gauss
+    big = rng.random() < 0.25
+    n_k = int(rng.integers(1, 40)) if not big else int(rng.integers(300, 2500) * 128 // q + 1)
+    nB = int(rng.integers(2, 300))
+    bDof = int(rng.integers(1, nB))
+    src, iw, djv = bool(rng.random() < 0.5), bool(rng.random() < 0.5), bool(rng.random() < 0.3)
+    rows = bool(rng.random() < 0.2)
+    return dict(case=case, L=L, act=act, widths=widths, dim=dim, d_in=d_in, q=q, big=big, n_k=n_k, nB=nB, bDof=bDof,
+                src=src, iw=iw, djv=djv, rows=rows)
+
+
+def oracle(c, d, flat, dtype):
+    f = np.float64 if dtype == torch.float64 else np.float32
+    cv = lambda a: None if a is None else np.asarray(a).astype(f)
+    ref, g = og.loss_and_grad(
+        flat.astype(f), c['d_in'], c['widths'], dtype, Input=cv(d['Input']), gcoef=cv(d['gcoef']), source=cv(d['source']),
+        N=cv(d['N']), dNt=cv(d['dNt']), integW=cv(d['integW']), intShape=[c['n_k'], c['q']],
+        detJ=(cv(d['detJ']) if c['djv'] else float(d['detJ'])), detJvec=c['djv'], biInput=cv(d['biInput']),
+        biLabel=cv(d['biLabel']), bDof=c['bDof'], biDimVal=2.0, w=d['w'], dim=c['dim'], time_dependent=True,
+        is_source=c['src'], integWflag=c['iw'], activation=c['act'])
+    return float(ref['loss']), np.asarray(g, dtype=np.float64)
+
+
+def run_case(c, with_oracle=True):
+    """All routes that can run the case.  Returns a result dict; result['ok'] is the verdict, result['msg'] a line."""
+    L, widths, d_in, dim, q = c['L'], c['widths'], c['d_in'], c['dim'], c['q']
+    src, iw, djv, act, case = c['src'], c['iw'], c['djv'], c['act'], c['case']
+    in_range = L <= 6 and max(widths) <= 64 and d_in <= 8       # the generic kernels' range
+    kernels = [40, 4, 0]
+    if in_range:
+        try:
+            make_engine(d_in, dim, widths, q, src, iw, 1, act).close()
+            kernels.append(1)
+        except Exception:                       # deep + wide: too big for the generic kernels' LDS
+            pass
+    n_k = c['n_k'] if (c['big'] and in_range) else min(c['n_k'], 40)     # keep the HBM route's cases small
+    c = dict(c, n_k=n_k)
+    d = synth(1000 + case, d_in, dim, widths, q, n_k, c['nB'], c['bDof'], src, iw, djv)
+    grads, routes, flat = [], [], None
+    for kernel in kernels:
+        eng = make_engine(d_in, dim, widths, q, src, iw, kernel, act)
+        eng.init_params(seed=case)
+        flat = eng.get_params() + 0.05 * np.random.default_rng(case).standard_normal(eng.P).astype(np.float32)
+        eng.set_params(flat)
+        eng.set_fe_table(d['N1'], d['dNt1'], d['integW'])
+        kw = dict(N_rows=d['N'], dNt_rows=d['dNt']) if c['rows'] else {}
+        eng.set_interior(0, d['Input'], d['gcoef'], d['source'], n_k=n_k, detJ=d['detJ'], **kw)
+        eng.set_bic(d['biInput'], d['biLabel'], c['bDof'], 2.0)
+        eng.set_weights(d['w'])
+        gb = eng.bind_grad_buffer()
+        eng.grad(0)
+        torch.cuda.synchronize()
+        grads.append(gb.cpu().numpy().astype(np.float64))
+        routes.append(40 if kernel == 40 else eng.kernel_path()[0])
+        eng.close()
+    P = grads[0].size - 4
+    pair = lpair = 0.0
+    for i in range(len(grads)):
+        for j in range(i):
+            sc = max(np.max(np.abs(grads[j][:P])), 1e-30)
+            pair = max(pair, np.max(np.abs(grads[i][:P] - grads[j][:P])) / sc)
+            lpair = max(lpair, abs(grads[i][P] - grads[j][P]) / max(abs(grads[j][P]), 1e-30))
+    need32 = pair > PAIR_BAR
+    with_oracle = with_oracle or need32           # a pairwise miss is always taken to the oracle
+    res = dict(case=case, routes=routes, pair=pair, lpair=lpair, oracle=with_oracle, gerr=None, lerr=None, cond=None,
+               n_k=n_k, P=P)
+    gbar, pbar = GRAD_BAR, PAIR_BAR
+    if with_oracle:
+        l64, g64 = oracle(c, d, flat, torch.float64)
+        sc = max(np.max(np.abs(g64)), 1e-30)
+        res['gerr'] = max(np.max(np.abs(g[:P] - g64)) / sc for g in grads)
+        res['lerr'] = max(abs(g[P] - l64) / max(abs(l64), 1e-30) for g in grads)
+        need32 = need32 or res['gerr'] > GRAD_BAR
+        if need32:
+            _, g32 = oracle(c, d, flat, torch.float32)
+            dev32 = np.max(np.abs(g32 - g64)) / sc
+            res['cond'] = dev32 / U32
+            if res['cond'] > COND_WHITELIST:            # ill-conditioned draw: bars follow its measured conditioning
+                gbar, pbar = max(GRAD_BAR, 2 * dev32), max(PAIR_BAR, 2 * dev32)
+    ok = pair <= pbar and lpair <= 5e-5
+    if with_oracle:
+        ok = ok and res['gerr'] <= gbar and res['lerr'] <= LOSS_BAR
+    res['ok'] = bool(ok)
+    res['msg'] = ('case %3d %s L=%d widths=%s d_in=%d dim=%d q=%d n_k=%d nB=%d src=%d iw=%d djv=%d rows=%d routes=%s: '
+                  'pair %.1e/%.1e' % (case, act, L, widths, d_in, dim, q, n_k, c['nB'], src, iw, djv, c['rows'], routes, pair, lpair))
+    if with_oracle:
+        res['msg'] += '  oracle %.1e/%.1e' % (res['gerr'], res['lerr'])
+    if res['cond'] is not None:
+        res['msg'] += '  cond %.1e%s' % (res['cond'], ' (whitelisted)' if res['cond'] > COND_WHITELIST else '')
+    if not ok:
+        res['msg'] += '   <<<<<<<< MISMATCH'
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        np.savez(os.path.join(ROOT, 'gpurun_out', 'fuzz_mismatch.npz'), widths=np.array(widths), d_in=d_in, dim=dim, q=q,
+                 n_k=n_k, nB=c['nB'], bDof=c['bDof'], src=src, iw=iw, djv=djv, rows=c['rows'], act=act, flat=flat,
+                 routes=np.array(routes), grads=np.array(grads),
+                 **{'d_' + k: (np.zeros(0) if v is None else np.asarray(v)) for k, v in d.items()})
+    return res
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    every = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    rng = np.random.default_rng(seed)
+    worst_pair = worst_or = 0.0
+    n_or = n_wl = 0
+    for case in range(ncases):
+        c = draw_case(rng, case)
+        r = run_case(c, with_oracle=(case % every == 0))
+        print(r['msg'], flush=True)
+        if not r['ok']:
+            sys.exit(1)
+        wl = r['cond'] is not None and r['cond'] > COND_WHITELIST
+        n_wl += wl
+        if not wl:
+            worst_pair = max(worst_pair, r['pair'])
+        if r['oracle']:
+            n_or += 1
+            if not wl:
+                worst_or = max(worst_or, r['gerr'])
+    print('all %d cases agree (seed %d): worst pairwise deviation %.2e; %d cases against the fp64 oracle, worst %.2e; '
+          '%d ill-conditioned draws whitelisted by their condition estimate' % (ncases, seed, worst_pair, n_or, worst_or, n_wl))
+
+
+if __name__ == '__main__':
+    main()

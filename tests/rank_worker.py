@@ -8,10 +8,13 @@ import os
 import numpy as np
 
 
-def run_rank(rank, world, port, outdir, backend, engine, problem, train_kw, tag):
+def run_rank(rank, world, port, outdir, backend, engine, problem, train_kw, tag, env=None):
+    os.environ.update(env or {})          # (fork-server children do not see later changes of the parent's environment)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     os.environ['RANK'], os.environ['WORLD_SIZE'] = str(rank), str(world)
+    if os.environ.get('VN_TEST_BREAK_RCCL_ON_RANK') == str(rank):       # this rank alone cannot load RCCL
+        os.environ['VN_RCCL_LIB'] = '/nonexistent/librccl.so'
     import torch
     import torch.distributed as dist
     from tests.test_varnet_host import op1dt, op2dt
@@ -65,10 +68,10 @@ def free_port():
     return p
 
 
-def launch(ctx, world, outdir, backend, engine, problem, train_kw, tag, timeout=600):
+def launch(ctx, world, outdir, backend, engine, problem, train_kw, tag, timeout=600, env=None):
     """Start `world` ranks from the multiprocessing context `ctx`, wait, assert they all succeeded."""
     port = free_port()
-    procs = [ctx.Process(target=run_rank, args=(r, world, port, outdir, backend, engine, problem, train_kw, tag))
+    procs = [ctx.Process(target=run_rank, args=(r, world, port, outdir, backend, engine, problem, train_kw, tag, env))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -124,3 +127,29 @@ def run_c_host(root, outdir, q):
     r = subprocess.run([exe, os.path.join(root, 'varnet_amd', 'libvarnet_hip.so')], capture_output=True, text=True,
                        env=env, timeout=300)
     q.put((r.returncode, r.stdout + '\n' + r.stderr))
+
+
+class FailingTower:
+    """Stand-in for VarNet inside a forked tower (tests/test_distributed_gloo.py): rank 1 raises in `train` while rank 0
+    sits in a collective that can then never complete."""
+
+    def __init__(self):
+        self.rank = int(os.environ['RANK'])
+
+    def train(self):
+        import torch
+        import torch.distributed as dist
+        if self.rank == 1:
+            raise RuntimeError('boom in tower 1')
+        dist.all_reduce(torch.zeros(1))               # the peer never joins
+        return 'unreachable'
+
+    def ok(self):
+        return 'pong %d' % self.rank
+
+    def die(self):
+        if self.rank == 1:
+            os._exit(7)
+        import torch
+        import torch.distributed as dist
+        dist.all_reduce(torch.zeros(1))

@@ -29,7 +29,9 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), 'missing export ' + n
     assert set(names) == set(engine.ABI_SYMBOLS), set(names) ^ set(engine.ABI_SYMBOLS)
-    assert lib.vn_abi_version() == 3
+    assert lib.vn_abi_version() == engine.VN_ABI_VERSION == 4
+    hdr = open(os.path.join(ROOT, 'include', 'varnet_hip.h')).read()
+    assert re.search(r'#define\s+VN_ABI_VERSION\s+4\b', hdr)
 
 
 def test_no_silent_cpu_fallback():
@@ -40,6 +42,7 @@ def test_no_silent_cpu_fallback():
     cfg = engine.VnConfig()
     cfg.dim, cfg.d_in, cfg.n_layers, cfg.integ_num = 1, 2, 1, 16
     cfg.widths[0] = 5
+    cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = 1e-3, 0.9, 0.999, 1e-8
     h = C.c_void_p()
     rc = lib.vn_create(C.byref(cfg), C.byref(h))
     assert rc != 0 and b'no CPU fallback' in lib.vn_last_error()
@@ -61,12 +64,53 @@ def test_argument_validation_without_gpu():
     # nets beyond the kernels' range (9 layers, 500 wide) are legal configs now: they pass validation and fail
     # only for want of a GPU here (VN_EHIP = 2), not as bad arguments
     cfg.d_in, cfg.n_layers = 2, 9
+    cfg.lr, cfg.beta1, cfg.beta2, cfg.eps = 1e-3, 0.9, 0.999, 1e-8
     for i in range(9):
         cfg.widths[i] = 500
     assert lib.vn_create(C.byref(cfg), C.byref(h)) in (0, 2)
     if h.value:
         lib.vn_destroy(h)
     assert lib.vn_create(None, C.byref(h)) == 1
+
+
+def test_zero_initialised_config_is_rejected_not_trained():
+    """the Adam hyper-parameters are taken literally (no defaulting), so a memset-zero vn_config -- which a
+    round-1 C host could pass -- must be refused (eps = 0 gives 0/0 = NaN for a zero-gradient parameter), with a message
+    that names the field; beta outside [0, 1) likewise; RMSProp ignores the three fields; lr = 0 stays legal."""
+    engine, lib = _lib()
+    h = C.c_void_p()
+    cfg = engine.VnConfig()                                            # ctypes zero-initialises: lr = beta = eps = 0
+    cfg.dim, cfg.d_in, cfg.n_layers, cfg.integ_num = 1, 2, 1, 16
+    cfg.widths[0] = 5
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) == 1 and b'epsilon' in lib.vn_last_error()
+    cfg.eps = 1e-8
+    cfg.beta1 = 1.0
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) == 1 and b'beta1' in lib.vn_last_error()
+    cfg.beta1, cfg.beta2 = 0.9, -0.1
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) == 1 and b'beta2' in lib.vn_last_error()
+    cfg.beta2 = 0.999                                                  # lr = 0: legal (TFModel.py:130 only rejects negatives)
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) in (0, 2)           # 2 = no GPU here
+    if h.value:
+        lib.vn_destroy(h)
+        h = C.c_void_p()
+    cfg.beta1 = cfg.beta2 = cfg.eps = 0.0
+    cfg.optimizer = 1                                                  # VN_OPT_RMSPROP: TF-1 constants, fields unused
+    assert lib.vn_create(C.byref(cfg), C.byref(h)) in (0, 2)
+    if h.value:
+        lib.vn_destroy(h)
+
+
+def test_stale_library_is_refused(tmp_path):
+    """load_library checks vn_abi_version before binding: a side build with another vn_config layout must not
+    be driven through this binding.  (A stub that reports ABI 3 stands in for a stale build.)"""
+    import subprocess
+    engine, _ = _lib()
+    src = tmp_path / 'stale.c'
+    src.write_text('int vn_abi_version(void) { return 3; }\n')
+    so = tmp_path / 'libvarnet_hip_stale.so'
+    subprocess.run(['gcc', '-shared', '-fPIC', str(src), '-o', str(so)], check=True)
+    with pytest.raises(engine.VNError, match='ABI version 3'):
+        engine.load_library(str(so))
 
 
 def test_product_package_never_imports_oracle():

@@ -122,3 +122,49 @@ def test_world2_optimal_sampling_draws_one_training_set(tmp_path):
     np.testing.assert_array_equal(b0['Input'], b1['Input'])
     np.testing.assert_allclose(b1['theta'], b0['theta'], rtol=0, atol=0)
     np.testing.assert_allclose(b1['w'], b0['w'], rtol=1e-12)
+
+
+def _tower_controller(q, method):
+    """Runs in a fresh process (the controller forks its towers)."""
+    import time
+    os.environ['VN_DIST_BACKEND'] = 'gloo'
+    from varnet_amd.towers import TowerGroup
+    try:
+        grp = TowerGroup(rw.FailingTower, (), {}, ['GPU:0', 'GPU:1'])
+        assert grp.call('ok') == 'pong 0'
+        pids = [p.pid for p in grp.procs]
+        t0 = time.time()
+        try:
+            grp.call(method)
+            q.put((1, 'no error raised'))
+            return
+        except RuntimeError as e:
+            msg = str(e)
+        dt = time.time() - t0
+        time.sleep(0.5)
+        alive = []
+        for pid in pids:
+            try:
+                os.kill(pid, 0)
+                alive.append(pid)
+            except OSError:
+                pass
+        q.put((0, (msg, dt, alive)))
+    except Exception:
+        import traceback
+        q.put((1, traceback.format_exc()))
+
+
+@pytest.mark.parametrize('method,needle', [('train', 'boom in tower 1'), ('die', 'tower 1 exited')])
+def test_failed_tower_does_not_wedge_the_controller(method, needle):
+    """a tower that raises (or dies) while its peer is inside a collective must surface as an error in the
+    controller within seconds, and the surviving tower must be terminated -- not block on the healthy tower's pipe."""
+    ctx = _spawn_ctx()
+    q = ctx.Queue()
+    p = ctx.Process(target=_tower_controller, args=(q, method))
+    p.start()
+    rc, val = q.get(timeout=120)
+    p.join(30)
+    assert rc == 0, val
+    msg, dt, alive = val
+    assert needle in msg and dt < 30 and alive == [], (msg, dt, alive)

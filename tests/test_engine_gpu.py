@@ -631,3 +631,56 @@ def test_six_wide_layers(kernel, path):
         assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
         assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
         eng.close()
+
+
+# ---- row a10: vn_params_init == the oracle's glorot_init (TFModel.py:213,219,242; global_variables_initializer) ------
+@pytest.mark.parametrize('d_in,dim,widths,seed', [
+    (2, 1, [20], 0),                         # Operator_1Dt.py:156
+    (3, 2, [50, 50, 50, 50, 50], 1),         # BASELINE config 3
+    (3, 1, [10, 20, 30], 12345678901234567), # Operator_1DtMOR.py:189 (a seed beyond 2**53: the stream is 64-bit)
+    (2, 1, [7, 128, 3], 7),                  # ragged, layer-by-layer route
+])
+def test_params_init_equals_oracle_glorot(d_in, dim, widths, seed):
+    """Same splitmix64 stream bit for bit, limits sqrt(6/(fan_in+fan_out)) (keras glorot_uniform, also the default of
+    the Dense(1) output layer), zero biases, zero Adam slots, step 0 -- also after training steps have moved all of it."""
+    eng = make_engine(d_in, dim, widths, 16, False, False)
+    P = eng.P
+    assert P == og.param_count(d_in, widths)
+
+    def check():
+        ref = og.glorot_init(d_in, widths, seed)
+        got = eng.get_params()
+        assert got.dtype == np.float32 and ref.dtype == np.float32
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))          # bit for bit
+        off = 0
+        for fi, fo in og.layer_dims(d_in, widths):
+            W, b = got[off:off + fi * fo], got[off + fi * fo:off + fi * fo + fo]
+            lim = np.sqrt(6.0 / (fi + fo))
+            assert np.all(np.abs(W) <= np.float32(lim)) and np.all(b == 0)
+            if fi * fo >= 400:
+                assert np.max(np.abs(W)) > 0.9 * lim and abs(W.mean()) < 0.15 * lim   # uniform on (-lim, lim)
+            off += fi * fo + fo
+        assert off == P
+        st = np.asarray(eng.export_state(), dtype=np.uint8)
+        assert int(st[:8].view(np.int64)[0]) == 0 and eng.step == 0              # step 0
+        slots = st[8:].view(np.float32)
+        assert slots.size == 3 * P and np.array_equal(slots[:P].view(np.uint32), ref.view(np.uint32))
+        assert np.all(slots[P:] == 0)                                              # Adam m, v = 0
+
+    eng.init_params(seed=seed)
+    check()
+    # move parameters, slots and the step counter, then re-initialise (VarNet.py:1412)
+    d = synth(3, d_in, dim, widths, 16, 24, 20, 12)
+    eng.set_fe_table(d['N1'], d['dNt1'])
+    eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=24, detJ=float(d['detJ']))
+    eng.set_bic(d['biInput'], d['biLabel'], 12, 2.0)
+    eng.set_weights(d['w'])
+    for _ in range(3):
+        eng.train_step(0)
+    torch.cuda.synchronize()
+    assert eng.step == 3 and not np.array_equal(eng.get_params(), og.glorot_init(d_in, widths, seed))
+    eng.init_params(seed=seed)
+    check()
+    eng.init_params(seed=seed + 1)
+    assert not np.array_equal(eng.get_params(), og.glorot_init(d_in, widths, seed))
+    eng.close()

@@ -36,5 +36,5 @@ def test_random_shape_matches_oracle(seed):
     g = gb.cpu().numpy()
     eng.close()
     info = (L, widths, d_in, dim, q, n_k, nB, src, iw, djv)
-    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * 4 * abs(ref['loss']), info
+    assert abs(g[eng.P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss']), (info, abs(g[eng.P] - ref['loss']) / abs(ref['loss']))
     assert np.max(np.abs(g[:eng.P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref)), info

@@ -99,6 +99,21 @@ def test_two_ranks_share_one_gpu_gloo(tmp_path, batchNum):
     assert str(b0['comm']) == 'torch' and list(b0['block']) == [0, 300] and list(b1['block']) == [300, 600]
 
 
+def test_rccl_missing_on_one_rank_falls_back_on_all_ranks(tmp_path):
+    """VN_COMM=try attempts the in-engine RCCL communicator; rank 1 alone cannot load RCCL
+    (VN_RCCL_LIB names a missing file).  The bootstrap must not hang or mismatch collectives: BOTH ranks skip the
+    communicator, keep the gradient SUM in torch.distributed and reproduce the one-rank run."""
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    out = str(tmp_path)
+    kw = dict(weight=[10., 10., 1.], epochNum=10, saveFreq=1000, verbose=False)
+    rw.launch(conftest.FORKSERVER, 1, out, 'gloo', 'hip', _problem(), kw, 'f')
+    rw.launch(conftest.FORKSERVER, 2, out, 'gloo', 'hip', _problem(), kw, 'f', timeout=240,
+              env={'VN_COMM': 'try', 'VN_TEST_BREAK_RCCL_ON_RANK': '1'})
+    a, b0, b1 = _compare(out, 'f', 2e-4, 2e-4)
+    assert str(b0['comm']) == 'torch' and str(b1['comm']) == 'torch'
+
+
 def test_two_ranks_with_an_empty_shard_gloo(tmp_path):
     """HIP engine with n_k == 0 on rank 1 (nt < batchLen * world): the BC/IC tiles still run there and the
     rank joins the collective."""
@@ -125,11 +140,7 @@ def test_two_ranks_two_gpus_rccl(tmp_path):
     rw.launch(conftest.FORKSERVER, 2, out, 'nccl', 'hip', _problem(), kw, 'n')
     a, b0, b1 = _compare(out, 'n', 2e-4, 2e-4)
     assert str(b0['comm']) == 'rccl'
-    os.environ['VN_COMM'] = 'torch'
-    try:
-        rw.launch(conftest.FORKSERVER, 2, out, 'nccl', 'hip', _problem(), kw, 't')
-    finally:
-        del os.environ['VN_COMM']
+    rw.launch(conftest.FORKSERVER, 2, out, 'nccl', 'hip', _problem(), kw, 't', env={'VN_COMM': 'torch'})
     t0 = np.load(os.path.join(out, 't_w2_r0.npz'))
     assert str(t0['comm']) == 'torch'
     np.testing.assert_allclose(t0['theta'], b0['theta'], rtol=0, atol=1e-6)

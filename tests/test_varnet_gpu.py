@@ -148,13 +148,17 @@ def test_fullsize_sampled_oracle_check(cfg3):
     ref, gref = og.loss_and_grad(
         flat, 3, [50] * 5, torch.float64, Input=d['Input'][:rows].cpu().numpy().astype(np.float64),
         gcoef=d['gcoef'][:rows].cpu().numpy().astype(np.float64), source=None,
-        N=np.tile(fd.N, n_s).reshape(rows, 1), dNt=np.tile(fd.dNt, n_s).reshape(rows, 1), integW=None,
-        intShape=[n_s, q], detJ=float(fd.detJ), detJvec=False,
+        N=np.tile(fd.N, n_s).reshape(rows, 1).astype(np.float32).astype(np.float64),      # the fp32 feed (TFModel.py:606-607)
+        dNt=np.tile(fd.dNt, n_s).reshape(rows, 1).astype(np.float32).astype(np.float64), integW=None,
+        intShape=[n_s, q], detJ=float(np.float32(fd.detJ)), detJvec=False,
         biInput=d['biInput'].cpu().numpy().astype(np.float64),
         biLabel=d['biLabel'].cpu().numpy().astype(np.float64).reshape(-1, 1), bDof=fd.bDofsum,
         biDimVal=float(fd.biDimVal), w=w, dim=2, time_dependent=True, is_source=False, integWflag=False)
     P = eng.P
-    assert abs(g[P] - ref['loss']) <= 4e-5 * abs(ref['loss'])
+    # the stated bar.  Round 2 ran this at 4e-5 because the oracle was handed the fp64 FE tables and detJ while
+    # the engine -- like the reference's placeholders -- sees them rounded to fp32: a difference of the INPUTS, amplified
+    # by the cancellation inside R_k, not of the arithmetic.
+    assert abs(g[P] - ref['loss']) <= 1e-5 * abs(ref['loss'])
     assert np.max(np.abs(g[:P] - gref)) <= 1e-4 * np.max(np.abs(gref))
 
 

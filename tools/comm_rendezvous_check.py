@@ -14,11 +14,11 @@ rank = int(os.environ['RANK'])
 torch.cuda.set_device(0)
 dist.init_process_group('gloo', rank=rank, world_size=2)
 eng = VNEngine(1, 2, [20, 20], True, 16)
-try:
-    eng.comm_init_from_torch(dist)
+ok, why = eng.comm_init_from_torch(dist)            # collective-safe: (False, reason) on EVERY rank if any rank failed
+if ok:
     print('rank %d: communicator of %s ranks created (two GPUs visible?)' % (rank, eng.comm_size()), flush=True)
     eng.comm_destroy()
-except VNError as e:
-    print('rank %d: vn_comm_init -> %s' % (rank, e), flush=True)
+else:
+    print('rank %d: vn_comm_init -> %s' % (rank, why), flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -139,6 +139,15 @@ int build_net(const vn_config& c, VnNet& net) {
     return fail(VN_EUNSUPPORTED, "activation must be sigmoid or tanh (VarNet.py:97)");
   if (c.optimizer != VN_OPT_ADAM && c.optimizer != VN_OPT_RMSPROP) return fail(VN_EINVAL, "unknown optimizer requested!");
   if (c.lr < 0.0) return fail(VN_EINVAL, "learning rate must be positive!");  // TFModel.py:130
+  if (c.optimizer == VN_OPT_ADAM) {
+    // taken literally, never defaulted: a zero-initialised config (eps = 0: 0/0 in the update of a zero-gradient
+    // parameter) is an error, not a NaN three steps later
+    if (!(c.beta1 >= 0.0 && c.beta1 < 1.0) || !(c.beta2 >= 0.0 && c.beta2 < 1.0))
+      return fail(VN_EINVAL, "Adam beta1 = %g, beta2 = %g must lie in [0, 1) (TF-1 defaults 0.9, 0.999; the struct is not defaulted)",
+                  c.beta1, c.beta2);
+    if (!(c.eps > 0.0))
+      return fail(VN_EINVAL, "Adam epsilon = %g must be positive (TF-1 default 1e-8; the struct is not defaulted)", c.eps);
+  }
   memset(&net, 0, sizeof net);
   net.d_in = c.d_in;
   net.dim = c.dim;
@@ -395,12 +404,19 @@ Rccl g_rccl;
 
 int load_rccl() {
   if (g_rccl.dl) return VN_OK;
-  const char* names[] = {getenv("VN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // $VN_RCCL_LIB names THE library to use (no fall-through to another copy: a host that points at a specific build
+  // must not silently get a different one); otherwise the SONAME a PyTorch-ROCm process already carries, then /opt/rocm
+  const char* user = getenv("VN_RCCL_LIB");
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* dl = nullptr;
-  for (const char* n : names) {
-    if (!n || !*n) continue;
-    dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (dl) break;
+  if (user && *user) {
+    dl = dlopen(user, RTLD_NOW | RTLD_LOCAL);
+    if (!dl) return fail(VN_EUNSUPPORTED, "RCCL: VN_RCCL_LIB=%s cannot be loaded (%s)", user, dlerror());
+  } else {
+    for (const char* n : names) {
+      dl = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (dl) break;
+    }
   }
   if (!dl) return fail(VN_EUNSUPPORTED, "RCCL not found (%s): set VN_RCCL_LIB", dlerror());
   Rccl r;
@@ -434,7 +450,7 @@ int load_rccl() {
 extern "C" {
 
 const char* vn_last_error(void) { return g_err.c_str(); }
-int vn_abi_version(void) { return 3; }   // 3: vn_config.widths[16], VN_KERNEL_LAYERED (2: vn_comm_*, vn_kernel_path, tanh, empty feeds)
+int vn_abi_version(void) { return VN_ABI_VERSION; }   // 4: vn_comm_available, validated Adam hyper-parameters (3: vn_config.widths[16], VN_KERNEL_LAYERED)
 
 int vn_create(const vn_config* cfg, vn_engine** out) {
   if (!cfg || !out) return fail(VN_EINVAL, "null argument");
@@ -996,6 +1012,8 @@ int vn_residual_f64(vn_engine* h, const double* X, const double* diff, const dou
 
 
 // ---- tower gradient SUM over RCCL (TFModel.py:342-377) ------------------------------------
+int vn_comm_available(void) { return load_rccl(); }
+
 int vn_comm_unique_id(void* id_out) {
   if (!id_out) return fail(VN_EINVAL, "null argument");
   if (int rc = load_rccl()) return rc;

@@ -21,6 +21,7 @@ VN_MAX_DIN = 32
 VN_KMAX_LAYERS, VN_KMAX_WIDTH, VN_KMAX_DIN = 6, 64, 8
 VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED, VN_KERNEL_FUSED16, VN_KERNEL_LAYERED = 0, 1, 2, 3, 4
 VN_COMM_ID_BYTES = 128
+VN_ABI_VERSION = 4          # include/varnet_hip.h: load_library refuses a library that reports another number
 
 
 class VnConfig(C.Structure):
@@ -65,6 +66,7 @@ _SIGS = {
     'vn_forward_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'vn_residual': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_residual_f64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
+    'vn_comm_available': (C.c_int, []),
     'vn_comm_unique_id': (C.c_int, [C.c_void_p]),
     'vn_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'vn_comm_size': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -82,6 +84,10 @@ _SIGS = {
 ABI_SYMBOLS = tuple(_SIGS.keys())
 
 
+class VNError(RuntimeError):
+    pass
+
+
 def load_library(path=None):
     """dlopen libvarnet_hip.so and attach the prototypes.  Raises if it is missing."""
     global _lib
@@ -92,6 +98,12 @@ def load_library(path=None):
         raise RuntimeError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                            '(there is no CPU fallback for the VarNet engine)' % p)
     lib = C.CDLL(p)
+    # a stale side build (VARNET_HIP_LIB / tools/build_variant.sh) would misread vn_config: check before binding anything else
+    lib.vn_abi_version.restype = C.c_int
+    lib.vn_abi_version.argtypes = []
+    got = lib.vn_abi_version()
+    if got != VN_ABI_VERSION:
+        raise VNError('%s reports ABI version %d, this binding is written for %d: rebuild it from this tree' % (p, got, VN_ABI_VERSION))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -99,10 +111,6 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
-
-
-class VNError(RuntimeError):
-    pass
 
 
 def _ptr(t):
@@ -379,6 +387,11 @@ class VNEngine:
 
     # -- towers: RCCL communicator inside the engine (TFModel.py:253-289, 342-377) ---------------
     @staticmethod
+    def comm_available():
+        """True if RCCL loads in this process (local probe: no collective, no GPU work)."""
+        return load_library().vn_comm_available() == 0
+
+    @staticmethod
     def comm_unique_id():
         """128 opaque bytes (ncclUniqueId) made on ONE rank; ship them to every rank, then `comm_init`."""
         lib = load_library()
@@ -396,12 +409,51 @@ class VNEngine:
         self._ck(self.lib.vn_comm_init(self.h, int(rank), int(world), buf))
 
     def comm_init_from_torch(self, dist):
-        """Bootstrap through an initialised torch.distributed group: rank 0 makes the id, everyone
-        receives it as an ordinary object broadcast."""
+        """Bootstrap through an initialised torch.distributed group.  Collective-safe: every rank walks through the SAME
+        sequence of collectives whatever fails where, so a rank without RCCL makes all ranks fall back instead of
+        leaving its peers in a broadcast or inside ncclCommInitRank.
+          1. every rank probes RCCL locally (no collective), MIN all-reduce of the flag;
+          2. only if all can load it: rank 0 makes the id inside try/except and ALWAYS broadcasts an (ok, id) pair;
+          3. all ranks call comm_init together, then agree (MIN) that it came up everywhere; else all destroy.
+        Returns (True, '') when the communicator is up on every rank, (False, reason) when all ranks skipped it."""
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [self.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        self.comm_init(rank, world, box[0])
+        t = self.torch
+        dev = self.device if dist.get_backend() == 'nccl' else 'cpu'
+
+        def all_ok(ok):
+            flag = t.tensor([1 if ok else 0], dtype=t.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        why = ''
+        try:
+            mine = self.comm_available()
+            if not mine:
+                why = self.lib.vn_last_error().decode()
+        except Exception as e:                       # noqa: BLE001  (a probe must not raise past the collective)
+            mine, why = False, str(e)
+        if not all_ok(mine):
+            return False, why or 'RCCL is not loadable on another rank'
+        box = [None]
+        if rank == 0:
+            try:
+                box = [(1, self.comm_unique_id())]
+            except Exception as e:                   # noqa: BLE001
+                box = [(0, str(e))]
+        dist.broadcast_object_list(box, src=0)       # always, also on failure
+        ok0, payload = box[0]
+        if not ok0:
+            return False, 'rank 0 could not create the RCCL id: %s' % payload
+        up, why = True, ''
+        try:
+            self.comm_init(rank, world, payload)
+        except Exception as e:                       # noqa: BLE001
+            up, why = False, str(e)
+        if all_ok(up):
+            return True, ''
+        if up:
+            self.comm_destroy()
+        return False, why or 'ncclCommInitRank failed on another rank'
 
     def comm_size(self):
         w, r = C.c_int32(), C.c_int32()

@@ -12,6 +12,7 @@ pickled but are inherited by a fork.  `controller` is accepted and unused: the g
 all-reduce and the optimizer step is repeated on every rank, there is no controller device.
 """
 import multiprocessing
+import multiprocessing.connection
 import os
 import socket
 import traceback
@@ -32,7 +33,12 @@ def _tower_main(rank, world, port, conn, cls, args, kwargs, device, backend):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(device)
+        # the GPU index is validated HERE, in the tower: the controller must not ask the runtime for a device count
+        # (on ROCm that call can initialise HIP/HSA without torch noticing, and a fork must not inherit that)
+        if backend == 'nccl' or torch.cuda.is_available():        # (CPU-only rehearsals over gloo have no device to pick)
+            if device >= torch.cuda.device_count():
+                raise ValueError('requested processor GPU:%d is unavailable!' % device)      # TFModel.py:121-123
+            torch.cuda.set_device(device)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device))
         else:
@@ -78,9 +84,7 @@ class TowerGroup:
         backend = os.environ.get('VN_DIST_BACKEND', 'nccl')
         if backend == 'nccl' and len(set(devices)) != len(devices):
             raise ValueError('processors %s name a GPU twice' % (processors,))
-        ndev = torch.cuda.device_count()
-        if any(d >= ndev for d in devices):
-            raise ValueError('requested processor GPU:%d is unavailable!' % max(devices))
+        # (no device count here: each tower checks its own index and reports through the 'err' message)
         ctx = multiprocessing.get_context('fork')
         port = _free_port()
         self.world = len(devices)
@@ -96,18 +100,35 @@ class TowerGroup:
         self._gather()
 
     def _gather(self):
+        """One reply per tower.  All pipes and all process sentinels are watched together: a tower that raises or dies
+        while its peers sit inside a collective (the training all-reduce, the RCCL bootstrap) would otherwise leave the
+        controller blocked on a healthy tower's pipe forever.  On the first error or death the remaining towers are
+        terminated (exact PIDs) and the error is raised."""
+        pending = dict(enumerate(self.conns))
+        sentinel = {p.sentinel: r for r, p in enumerate(self.procs)}
         out, err = None, None
-        for r, c in enumerate(self.conns):
-            try:
-                tag, val = c.recv()
-            except EOFError:
-                tag, val = 'err', 'tower %d exited' % r
-            if tag == 'err' and err is None:
-                err = 'tower %d failed:\n%s' % (r, val)
-            if r == 0:
-                out = val
+        while pending and err is None:
+            ready = multiprocessing.connection.wait(list(pending.values()) + [s for s, r in sentinel.items() if r in pending])
+            for obj in ready:
+                if obj in sentinel:
+                    r = sentinel[obj]
+                    if r in pending and not pending[r].poll():            # died without a reply
+                        err = 'tower %d exited (exit code %s)' % (r, self.procs[r].exitcode)
+                        break
+                    continue
+                r = next(k for k, c in pending.items() if c is obj)
+                try:
+                    tag, val = obj.recv()
+                except EOFError:
+                    tag, val = 'err', 'tower %d exited' % r
+                del pending[r]
+                if tag == 'err':
+                    err = 'tower %d failed:\n%s' % (r, val)
+                    break
+                if r == 0:
+                    out = val
         if err is not None:
-            self.close()
+            self.close(kill=True)
             raise RuntimeError(err)
         return out
 
@@ -116,16 +137,22 @@ class TowerGroup:
             c.send((name, a, k))
         return self._gather()
 
-    def close(self):
+    def close(self, kill=False):
+        """kill=True: a tower failed -- its peers may be blocked inside a collective and would never read the
+        shutdown message, so they are terminated at once (the exact processes this group started)."""
         for c in self.conns:
             try:
                 c.send(None)
             except Exception:
                 pass
         for p in self.procs:
-            p.join(20)
+            if not kill:
+                p.join(20)
             if p.is_alive():
                 p.terminate()
+                p.join(5)
+                if p.is_alive():
+                    p.kill()
         self.conns, self.procs = [], []
 
     def __del__(self):

@@ -735,25 +735,17 @@ class VarNet:
         self.comm = 'none'
         if self.world > 1:
             self.comm = 'torch'
-            mode = os.environ.get('VN_COMM', 'auto')      # auto: in-engine RCCL whenever the ranks own distinct GPUs
+            # auto: in-engine RCCL whenever the ranks own distinct GPUs (nccl backend); rccl: required; try: attempted
+            # whatever the backend, falling back to torch.distributed; torch: never
+            mode = os.environ.get('VN_COMM', 'auto')
             if hasattr(self.engine, 'comm_init_from_torch') and \
-                    (mode == 'rccl' or (mode == 'auto' and self.dist.get_backend() == 'nccl')):
-                # every rank must end up on the SAME route: try the in-engine communicator, then agree (MIN over ranks)
-                # whether it came up everywhere; if not, all ranks drop it and keep the collective in torch.distributed
-                ok, why = 1, ''
-                try:
-                    self.engine.comm_init_from_torch(self.dist)
-                except Exception as e:                      # RCCL missing / refused on this rank
-                    ok, why = 0, str(e)
-                t = self.engine.torch
-                flag = t.tensor([ok], dtype=t.int32,
-                                device=self.engine.device if self.dist.get_backend() == 'nccl' else 'cpu')
-                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
-                if int(flag.item()) == 1:
+                    (mode in ('rccl', 'try') or (mode == 'auto' and self.dist.get_backend() == 'nccl')):
+                # every rank must end up on the SAME route; the bootstrap itself is collective-safe (a rank that cannot
+                # load RCCL makes ALL ranks skip it: VNEngine.comm_init_from_torch), so the decision needs no extra vote
+                ok, why = self.engine.comm_init_from_torch(self.dist)
+                if ok:
                     self.comm = 'rccl'
                 else:
-                    if ok:
-                        self.engine.comm_destroy()
                     if mode == 'rccl':
                         raise RuntimeError('VN_COMM=rccl but the in-engine RCCL communicator did not come up on every rank'
                                            + (': ' + why if why else ''))
