@@ -33,6 +33,40 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources the library is built from: ties a committed counter file to the code it measured."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'varnet_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'varnet_amd', 'csrc', '*.h'))
+                    + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
+def static_traffic(kname, config, world):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the run (they need a
+    rocprofv3 --pmc pass of their own), so the figure is the committed one from profiles/pmc_traffic.json
+    (tools/collect_profiles.sh + tools/summarise_profiles.py: FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as
+    is) -- and ONLY if that file was collected on this exact kernel instantiation, this workload and these kernel sources.
+    Returns (traffic or None, traffic_source string)."""
+    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not os.path.exists(tfile):
+        return None, 'none: profiles/pmc_traffic.json absent'
+    js = json.load(open(tfile))
+    norm = lambda n: ''.join(str(n).split())
+    if config != 3 or world != 1:
+        return None, 'none: profiles/pmc_traffic.json holds the N=1 config-3 launch only'
+    if norm(js.get('kernel')) != norm(kname):
+        return None, 'none: profiles/pmc_traffic.json was collected on %s, this run launches %s' % (js.get('kernel'), kname)
+    if js.get('kernel_source_sha256') != kernel_source_hash():
+        return None, ('none: profiles/pmc_traffic.json (%s) predates the current kernel sources (sha256 differs): re-run '
+                      'tools/collect_profiles.sh' % js.get('round'))
+    return js.get('hbm_bytes_per_launch'), ('profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of round %s on %s, kernel '
+                                            'sources sha256 %s... = this build)' % (js.get('round'), js.get('kernel'), js['kernel_source_sha256'][:12]))
+
+
 def build_problem(cfg):
     from varnet_amd.domain import Domain1D, PolygonDomain2D
     from varnet_amd.adpde import ADPDE
@@ -165,7 +199,55 @@ def cpu_baseline(vn, tdata, budget_s=25.0):
                       % (n_s, fd.nt, rows, nB, n_timed, warm, cores, phys, usable)}
 
 
+def small_step_line(cfg, steps, warmup):
+    """One more workload in the same process, reported under `extra`: BASELINE config 2 (1D+t, 4x50, 160 k points), a step
+    of ~0.16 ms where per-step fixed cost, not the tile loop, decides.  Same timing rules as the headline (inputs resident,
+    K steps between synchronisations, whole-step time; the kernel's own time from HIP events on the engine stream)."""
+    import torch
+    vn, wname = build_problem(cfg)
+    fd, eng = vn.fixData, vn.engine
+    tdata = vn._build_tdata()
+    tdata.select_mor(0)
+    eng.set_weights(np.array([1.0, 1.0, 1.0]))
+    nB = tdata.mor[0]['biInput'].shape[0]
+    eng.train_epoch([0] * warmup, None)
+    torch.cuda.synchronize()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    eng.train_epoch([0] * steps, None)                 # optimIter's one host call per pass (VarNetUtility.py:1043-1045)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms, kl, kname = eng.profile_end()
+    F_pt = 2 * (vn.inpDim * vn.layerWidth[0] + sum(a * b for a, b in zip(vn.layerWidth[:-1], vn.layerWidth[1:])) + vn.layerWidth[-1])
+    flop = 6.0 * F_pt * fd.nT + 3.0 * F_pt * nB
+    out = {"config": {"workload": wname, "training_points_per_step": int(fd.nT), "bc_ic_points": int(nB)},
+           "value": fd.nT * steps / dt, "unit": "training-points/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3,
+           "roofline": {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "kernel": kname,
+                        "kernel_ms": kms, "launches_timed": kl, "algorithmic_flop_per_launch": flop,
+                        "achieved": flop / (kms * 1e-3) / 1e12 if kms else None,
+                        "frac": flop / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if kms else None,
+                        "whole_step_frac": flop / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "traffic_source": "none: no counter pass committed for this workload"}}
+    eng.close()
+    return out
+
+
 def main():
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as e:                                  # noqa: BLE001
+        # a rank that dies must leave a diagnosis on stdout (the driver keeps the tail) and a non-zero status
+        import traceback
+        print(json.dumps({"error": "%s: %s" % (type(e).__name__, e), "rank": int(os.environ.get('RANK', '0')),
+                          "world": int(os.environ.get('WORLD_SIZE', '1')),
+                          "traceback_tail": traceback.format_exc().splitlines()[-6:]}), flush=True)
+        sys.exit(1)
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -173,13 +255,18 @@ def main():
     ap.add_argument('--config', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dedup', action='store_true', help='skip the extra de-duplicated-formulation timing')
+    ap.add_argument('--no-extra', action='store_true', help='skip the extra small-step workload (config 2)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
         # `python bench.py --gpus N`: start the N ranks ourselves, as fresh children, BEFORE anything in this
         # process touches the GPU (this parent never imports torch); rank 0 prints the JSON line.
         from varnet_amd.launch import spawn_ranks
-        raise SystemExit(spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+        rc = spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        if rc != 0:       # the failing rank has printed its own {"error": ...} line if it got as far as Python
+            print(json.dumps({"error": "a rank of the %d-rank launch exited with status %d (its peers were ended)" % (args.gpus, rc),
+                              "n_gpus": args.gpus}), flush=True)
+        raise SystemExit(rc)
 
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -287,13 +374,7 @@ def main():
         flop_of = lambda rows: 6.0 * F_pt * rows + 3.0 * F_pt * nB
         flop_launch = flop_of(rows_local)
         achieved = flop_launch / (kms * 1e-3) / 1e12 if kms > 0 else None
-        # HBM bytes per launch come from the separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the
-        # gfx950 correction, WRITE_SIZE as is) committed under profiles/; only quoted for the exact
-        # workload and kernel they were collected on.
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if args.config == 3 and world == 1 and kname.startswith('vn_fused') and os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+        traffic, traffic_source = static_traffic(kname, args.config, world)
         out = {
             "metric": "training-points/sec (test-funcs x quad-pts), 2D+t AD-PDE" if args.config == 3
             else "training-points/sec (test-funcs x quad-pts), 1D+t AD-PDE",
@@ -314,6 +395,7 @@ def main():
                        "test_functions_per_sec": fd.nt * args.steps / dt, "loss_after": loss_after},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel": kname, "kernel_ms": kms, "launches_timed": klaunches,
                          "algorithmic_flop_per_launch": flop_launch,
                          "note": "rank 0's launch: 6*F_pt per interior point + 3*F_pt per BC/IC point, F_pt=%d; "
@@ -347,6 +429,9 @@ def main():
                         "(tests/test_engine_gpu.py::test_dedup_formulation_parity)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vn, tdata)
+        if world == 1 and args.config == 3 and not args.no_extra:
+            eng.close()
+            out["extra"] = {"config2_small_step": small_step_line(2, 400, 40)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -67,8 +67,8 @@ def report(d, skip):
     prev_end = None
     starts = []
     for r in rows:
-        name = r['Kernel_Name'].split('(')[0]
-        name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+        name = name.split('(')[0].strip()
         s, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
         gap = None if prev_end is None else s - prev_end
         by.setdefault(name, []).append((e_ - s, gap))

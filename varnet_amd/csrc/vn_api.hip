@@ -124,7 +124,7 @@ struct vn_engine {
   std::vector<hipEvent_t> ev0, ev1;
   std::vector<hipEvent_t> cev0, cev1;   // around the all-reduce
   int cprof_n = 0;
-  const char* prof_name = "vn_generic_bwd_kernel";
+  std::string prof_name = "vn_generic_bwd_kernel";
 };
 
 namespace {
@@ -551,7 +551,6 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
   h->use_fused = h->use_fused16 ||
                  (cfg->kernel != VN_KERNEL_GENERIC && vn_fused_supported(net, cfg->integ_num));
   h->two_pass = !h->use_fused && tp_ok && (cfg->kernel == VN_KERNEL_FUSED16 || cfg->kernel == VN_KERNEL_AUTO);
-  if (h->two_pass) h->prof_name = "vn_fused16_kernel";
   h->fused_only = deep_fused;
   if (h->use_fused || h->two_pass) {
     // (the forward-only mode of the 8-wave kernel writes its per-workgroup loss partials here too: vn_forward and
@@ -561,6 +560,11 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
       return fail(VN_ENOMEM, "device allocation failed");
     }
     h->prof_name = (h->use_fused16 || h->two_pass) ? "vn_fused16_kernel" : "vn_fused_kernel";
+    if (h->use_fused16 || h->two_pass) {       // the instantiation that runs, as rocprofv3 prints it (template arguments)
+      char nm[96];
+      snprintf(nm, sizeof nm, "vn_fused16_kernel<%d, %d, %s>", net.L, vn_fused16_ks(net), net.act == VN_ACT_TANH ? "true" : "false");
+      h->prof_name = nm;
+    }
     if (hipMalloc((void**)&h->stamps, 8 * sizeof(unsigned long long)) == hipSuccess)
       (void)hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   }
@@ -1133,7 +1137,7 @@ int vn_profile_end(vn_engine* h, double* mean_ms, int64_t* launches, char* name,
   if (mean_ms) *mean_ms = h->prof_n ? tot / h->prof_n : 0.0;
   if (launches) *launches = h->prof_n;
   if (name && name_len > 0) {
-    strncpy(name, h->prof_name, name_len - 1);
+    strncpy(name, h->prof_name.c_str(), name_len - 1);
     name[name_len - 1] = 0;
   }
   h->prof_on = false;

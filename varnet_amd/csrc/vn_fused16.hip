@@ -90,6 +90,14 @@ struct Lay {
   // Weight-gradient accumulators of the first NST hidden layers live in LDS between their uses
   // (2 x f32x4 per lane and layer): registers are short while the forward pass stores activations,
   // and what the compiler spills instead goes to scratch, i.e. through L2 to HBM.
+  // Final flush: the thin layers' partial sums (input layer with d_in <= 3, output layer: 2 x f32x4 per lane and wave) are
+  // parked in one slot per wave and added in wave order by the store phase -- no serial round per wave.  The slots lie in
+  // the transposition region behind the gradient image where that leaves room, else over the weight images (dead once
+  // the tile loop has ended; they end below sInt, which the flush still uses).
+  static constexpr int SLOT_SZ = NW * 2 * 4 * 64;
+  static constexpr bool SLOT_IN_T = G_LOW || (T_SZ - al4(G_SZ) >= SLOT_SZ);
+  static constexpr int SLOT_OFF = G_LOW ? T_OFF : (SLOT_IN_T ? T_OFF + al4(G_SZ) : 0);
+  static_assert(SLOT_IN_T || SLOT_SZ <= MISC_OFF, "thin-layer slots fit neither behind the gradient image nor over the weight images");
   static constexpr int ST_OFF = T_OFF + T_SZ;
   static constexpr int ST_LAYER = NW * 2 * 64 * 4;
   static constexpr int ST_FIT = (160 * 256 - ST_OFF) / ST_LAYER;
@@ -810,6 +818,18 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         vh[l - 2][it] = (i < LY::HP * WS && k < Hin && pos < 64 && f < Hout) ? A.theta[net.woff[l] + k * Hout + f] : 0.f;
       }
     }
+    // biases (one per thread: L * 64 <= 512) and output weights ride in the same batch of loads
+    static_assert(L * 64 <= NTHREADS && 4 * KS <= NTHREADS, "one bias / output weight per thread");
+    float vb = 0.f, vo = 0.f;
+    if (tid < L * 64) {
+      const int l = tid / 64 + 1, idx = tid % 64;
+      const int mt = idx >> 4, g = (idx >> 2) & 3, r = idx & 3;       // [tile][g][i]
+      const int ks = 4 * mt + r, f = 4 * ks + g;
+      vb = (ks < KS && f < net.H[l]) ? A.theta[net.boff[l] + f] : 0.f;
+    }
+    if (tid < 4 * KS) vo = (tid < net.H[L]) ? A.theta[net.woff[L + 1] + tid] : 0.f;
+    // (the zero fill of the transposition region needs no data: it runs under the latency of the loads above)
+    for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
 #pragma unroll
     for (int it = 0; it < N1IT; ++it) {
       const int i = tid + it * NTHREADS;
@@ -824,14 +844,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         if (i < LY::HP * WS) Wl[i] = vh[l - 2][it];
       }
     }
-    for (int i = tid; i < L * 64; i += NTHREADS) {
-      const int l = i / 64 + 1, idx = i % 64;
-      const int mt = idx >> 4, g = (idx >> 2) & 3, r = idx & 3;       // [tile][g][i]
-      const int ks = 4 * mt + r, f = 4 * ks + g;
-      BI[i] = (ks < KS && f < net.H[l]) ? A.theta[net.boff[l] + f] : 0.f;
-    }
-    for (int i = tid; i < 4 * KS; i += NTHREADS) WO[i] = (i < net.H[L]) ? A.theta[net.woff[L + 1] + i] : 0.f;
-    for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
+    if (tid < L * 64) BI[tid] = vb;
+    if (tid < 4 * KS) WO[tid] = vo;
   }
   __syncthreads();
 
@@ -1284,6 +1298,14 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   for (int i = tid; i < (LY::G_LOW ? LY::G_SZ : LY::T_SZ); i += NTHREADS) lds[LY::G_OFF + i] = 0.f;
   __syncthreads();
   // Accumulators -> LDS gradient image, every sum in a fixed order (bitwise reproducible).
+  // Thin layers first: all eight waves hold partial sums of the same elements; each parks its registers in its own slot
+  // ([wave][input | output layer][register][lane]) and the store phase below adds the slots in wave order.
+  float* SL = lds + LY::SLOT_OFF;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    SL[((wave * 2 + 0) * 4 + i) * 64 + lane] = thin_in ? wacc1[0][i] : 0.f;
+    SL[((wave * 2 + 1) * 4 + i) * 64 + lane] = wacco[0][i];
+  }
   if constexpr (HID13) {
     // 50-wide hidden layers: a tile wave's first slot and the two border jobs own their image elements
     // exclusively (one parallel phase); the shared tile (m,2) gets its two halves in two phases.
@@ -1302,28 +1324,36 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     if (!border && wave < NW / 2) flush_hidden(1, 2);
     __syncthreads();
     if (!border && wave >= NW / 2) flush_hidden(1, 2);
-    __syncthreads();
-    for (int w = 0; w < NW; ++w) {                   // thin layers: all eight waves hold partial sums
-      if (wave == w) {
-        if (thin_in) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
-        else wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
-        thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane, true);
+    if (!thin_in) {                                  // d_in > 3: generic cooperative tiles of the input layer, one round per point split
+      using W1 = WG<KS0, KS>;
+      const int s1 = (W1::NT >= NW) ? 0 : wave / W1::NT;
+      for (int r = 0; r < ((W1::NT >= NW) ? 1 : W1::NS); ++r) {
+        __syncthreads();
+        if (s1 == r) wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
       }
-      __syncthreads();
     }
+    __syncthreads();
   } else {
     // generic tiles: waves with the same point-split index own distinct tiles, so round r serves all waves
-    // of split r at once (one round when a layer has >= 8 tiles); the thin layers need all eight rounds
+    // of split r at once (one round when a layer has >= 8 tiles)
     using W1 = WG<KS0, KS>;
     const int s1 = (W1::NT >= NW) ? 0 : wave / W1::NT;
     const int sh = (WHG::NT >= NW) ? 0 : wave / WHG::NT;
-    for (int r = 0; r < NW; ++r) {
-      if (thin_in) {
-        if (wave == r) thin_flush_in<KS, LY::HP>(wacc1[0], Gacc, lane);
-      } else if (s1 == r) {
-        wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
-      }
-      if (sh == r) {
+    constexpr int R1 = (W1::NT >= NW) ? 1 : W1::NS;
+    constexpr int RH = (L > 1) ? ((WHG::NT >= NW) ? 1 : WHG::NS) : 0;
+    // bias gradients that did not ride in a constant-one row (KS == 16 behind a 64-wide layer) are per-wave partial sums
+    // added in wave order: those rare shapes keep one round per wave
+    bool serial_bias = false;
+    if constexpr (KS == 16) {
+      serial_bias = !ones_o;
+#pragma unroll
+      for (int l = 2; l <= L; ++l) serial_bias = serial_bias || !ones_h[l - 2];
+    }
+    const int r1 = thin_in ? 0 : R1;
+    const int nr = serial_bias ? NW : (r1 > RH ? r1 : RH);
+    for (int r = 0; r < nr; ++r) {
+      if (!thin_in && s1 == r && r < R1) wgrad_flush<KS0, KS, LY::HP>(wacc1, Gacc, lc, wave);
+      if (sh == r && r < RH) {
 #pragma unroll
         for (int l = 2; l <= L; ++l) {
           if constexpr (NHACC == 2) {
@@ -1336,11 +1366,9 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
           wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, ones_h[l - 2]);
         }
       }
-      if (wave == r) {
-        thin_flush_out<KS>(wacco[0], Gacc + LY::GO_OFF, lane, ones_o);
-        if constexpr (KS == 16) {
-          // bias gradients that did not ride in a constant-one row (64-wide input side): per-wave partial sums, added
-          // in wave order.  Hidden: lane = position of the output feature; output layer: sum over the wave's 16 points.
+      if constexpr (KS == 16) {
+        if (serial_bias && wave == r) {
+          // hidden: lane = position of the output feature; output layer: sum over the wave's 16 points
 #pragma unroll
           for (int l = 2; l <= L; ++l)
             if (!ones_h[l - 2] && vfeat(lane) < LY::HP)
@@ -1355,6 +1383,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       }
       __syncthreads();
     }
+    if (nr == 0) __syncthreads();                    // the slots must be visible to the store phase
   }
   FIXSTAMP(3);
   float* out = A.partial + (long)blockIdx.x * P;
@@ -1367,8 +1396,25 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     // 64 consecutive threads write one row of the [Hin+1, Hout] block (coalesced, no integer division)
     const int cc = tid & 63;
     if (cc < Hout) {
-      for (int r = tid >> 6; r <= Hin; r += NTHREADS / 64)
-        out[net.woff[l] + r * Hout + cc] = Gl[(r < Hin ? r : brow) * gs + cc];
+      for (int r = tid >> 6; r <= Hin; r += NTHREADS / 64) {
+        float v = Gl[(r < Hin ? r : brow) * gs + cc];
+        if (l == 1 && thin_in) {
+          // thin_wgrad_in: register i = input row (3 = bias row), lane = column position of feature cc
+          const float* sp = SL + (r < Hin ? r : 3) * 64 + vpos(cc >> 2, cc & 3);
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v += sp[(w * 2 + 0) * 4 * 64];
+        } else if (l == L + 1) {
+          // thin_wgrad_out: lane 4b (column 0 of block b) register i holds position 4b + i; the bias rides at vones(KS)
+          const bool bias = r >= Hin;
+          const int pos = bias ? vones(KS) : vpos(r >> 2, r & 3);
+          if (!bias || ones_o) {
+            const float* sp = SL + (4 + (pos & 3)) * 64 + (pos & ~3);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += sp[(w * 2) * 4 * 64];
+          }
+        }
+        out[net.woff[l] + r * Hout + cc] = v;
+      }
     }
   }
   float v0 = loss_var, v1 = loss_bc, v2 = loss_ic;
@@ -1430,6 +1476,8 @@ int pick_ks(int hmax) {
   X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8) X(7, 8) X(8, 8)  \
   X(1, 13) X(2, 13) X(3, 13) X(4, 13) X(5, 13) X(6, 13) X(7, 13) X(8, 13)  \
   X(1, 16) X(2, 16) X(3, 16) X(4, 16) X(5, 16) X(6, 16)
+
+int vn_fused16_ks(const VnNet& net) { return pick_ks(net.hmax); }
 
 size_t vn_fused16_lds_bytes(const VnNet& net) {
   const int ks = pick_ks(net.hmax);

@@ -397,9 +397,25 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void vn_reduce_kernel(const float*
   __shared__ float sub[RED_GROUPS][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int p = blockIdx.x * 64 + lane;
+  // This kernel sits between two training steps whose tile loops may be shorter than its own latency (a step of the
+  // [10,20,30] net is 50 us), so every global load is issued before anything waits: the optimizer state of this block's
+  // parameters does not depend on the sums and is fetched first, the partials of a lane 16 at a time.
+  const bool upd = grp == 0 && p < P && opt.kind >= 0;
+  float th = 0.f, mo = 0.f, vo = 0.f;
+  if (upd) { th = opt.theta[p]; mo = opt.m[p]; vo = opt.v[p]; }
   float acc = 0.f;
   if (p < P) {
-    for (int g = grp; g < nparts; g += RED_GROUPS) acc += partial[(long)g * P + p];
+    for (int g0 = grp; g0 < nparts; g0 += RED_GROUPS * 16) {
+      float t[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int g = g0 + j * RED_GROUPS;
+        t[j] = g < nparts ? partial[(long)g * P + p] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (g0 + j * RED_GROUPS < nparts) acc += t[j];          // same order as a sequential walk g = grp, grp + 16, ...
+    }
   }
   sub[grp][lane] = acc;
   __syncthreads();
@@ -409,27 +425,33 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void vn_reduce_kernel(const float*
     for (int j = 1; j < RED_GROUPS; ++j) t += sub[j][lane];
     gradbuf[p] = t;
     if (opt.kind == VN_OPT_ADAM) {                   // same arithmetic as vn_adam_kernel
-      const float mi = opt.b1 * opt.m[p] + (1.f - opt.b1) * t;
-      const float vi = opt.b2 * opt.v[p] + (1.f - opt.b2) * t * t;
+      const float mi = opt.b1 * mo + (1.f - opt.b1) * t;
+      const float vi = opt.b2 * vo + (1.f - opt.b2) * t * t;
       opt.m[p] = mi;
       opt.v[p] = vi;
-      opt.theta[p] = opt.theta[p] - opt.lr * mi / (sqrtf(vi) + opt.eps);
+      opt.theta[p] = th - opt.lr * mi / (sqrtf(vi) + opt.eps);
     } else if (opt.kind == VN_OPT_RMSPROP) {         // same arithmetic as vn_rmsprop_kernel
-      const float msi = opt.v[p] + (t * t - opt.v[p]) * (1.f - opt.b1);
-      const float mi = opt.b2 * opt.m[p] + opt.lr * t / sqrtf(msi + opt.eps);
+      const float msi = vo + (t * t - vo) * (1.f - opt.b1);
+      const float mi = opt.b2 * mo + opt.lr * t / sqrtf(msi + opt.eps);
       opt.v[p] = msi;
       opt.m[p] = mi;
-      opt.theta[p] = opt.theta[p] - mi;
+      opt.theta[p] = th - mi;
     }
   }
   // loss scalars: wave 1 of block 0 folds the per-workgroup partials (lane-strided, then a fixed
   // shuffle tree, in fp64)
   if (blockIdx.x == 0 && grp == 1 && losspart != nullptr) {
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    for (int g = lane; g < nlp; g += 64) {
-      t0 += (double)losspart[g * 3 + 0];
-      t1 += (double)losspart[g * 3 + 1];
-      t2 += (double)losspart[g * 3 + 2];
+    for (int gb = lane; gb < nlp; gb += 64 * 4) {       // four rows of partials per lane in flight
+      float a[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int g = gb + 64 * j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[j][c] = g < nlp ? losspart[g * 3 + c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { t0 += (double)a[j][0]; t1 += (double)a[j][1]; t2 += (double)a[j][2]; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

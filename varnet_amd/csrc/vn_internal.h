@@ -104,6 +104,7 @@ hipError_t vn_fused_launch(const VnFusedArgs& a, int grid, hipStream_t s);
 bool vn_fused16_supported(const VnNet& net, int integ_num);
 bool vn_fused16_net_supported(const VnNet& net);   // network instantiated (any integ_num: two-pass route)
 size_t vn_fused16_lds_bytes(const VnNet& net);
+int vn_fused16_ks(const VnNet& net);               // k-steps per hidden layer of the instantiation that serves `net` (0: none)
 hipError_t vn_fused16_launch(const VnFusedArgs& a, int grid, hipStream_t s);
 
 // ---- de-duplicated weak-form assembly (vn_dedup.hip) -----------------------------------------
