@@ -54,13 +54,17 @@ __host__ __device__ constexpr int vfeat(int pos) { return 4 * vks(pos) + ((pos >
 // Position of the constant-one row that carries the bias gradient: the first position past the layer's k-steps.
 // KS == 16 (widths 51..64) has no position to spare, so the row of feature 63 is used where the layer does not have
 // that feature; behind a 64-wide layer the bias gradient is summed by thin_bias instead (ones_row = false).
+// KS == 8 (widths 21..32) likewise: the first spare position would be 32, i.e. a third 16-row tile -- 4 x 2 weight-gradient
+// tiles for a gradient that fits 2 x 2 (the [10,20,30] net of Operator_1DtMOR.py:189 spent a quarter of its matrix work
+// there) -- so the bias row rides at the position of feature 31 unless the layer is exactly 32 wide.
+__host__ __device__ constexpr bool fullpos(int KS) { return KS == 16 || KS == 8; }      // 4*KS fills whole 16-row tiles
 __host__ __device__ constexpr int vones(int KS) {
-  if (KS == 16) return 63;
+  if (fullpos(KS)) return 4 * KS - 1;
   for (int p = 0; p < 64; ++p)
     if (vks(p) >= KS) return p;
   return -1;
 }
-static_assert(vfeat(63) == 63, "position 63 is feature 63");
+static_assert(vfeat(63) == 63 && vfeat(31) == 31 && vpos(7, 3) == 31, "position 4*KS-1 is feature 4*KS-1");
 __host__ __device__ constexpr int mtiles(int KS) { return (KS + 3) / 4; }
 
 template <int L, int KS>
@@ -792,30 +796,35 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   float* Gacc = lds + LY::G_OFF;
 
   FIXSTAMP(0);
+  // lane constants that come from global memory are requested first, so that their latency hides under the prologue:
+  // the quadrature index of this lane's point is the same in every interior tile (tiles start at whole test functions),
+  // so the periodic FE table entries are lane constants
+  const int q = A.integ_num;
+  const int pq_l = (wave * CW + (lane & 15)) % q;
+  const int tf_l = (wave * CW + (lane & 15)) / q;    // ... and so is its test function within the tile
+  const float tab_dnt = A.time_dependent ? A.fedNt[pq_l] : 0.f;
+  const float tab_w = A.feW ? A.feW[pq_l] : 1.f;
+  const float tab_N = A.feN[pq_l];
+  const float bo = A.theta[net.boff[L + 1]];
   // ------------------------------------------------------------------ prologue: LDS images
   {
-    // every thread first issues ALL its parameter loads (L2 latency ~1 us each if taken one by one), then
-    // scatters them into the images
+    // Parameters are read in their own (row-major) order -- consecutive lanes, consecutive floats: a destination-driven
+    // walk of the images gathers 4-byte words all over a layer and costs 4 us per launch on the texture path -- and
+    // scattered into the images [in-feature][out-position]; every load is issued before anything waits, the zero fill of
+    // the images (padding rows / columns must be exact zeros) and of the transposition region runs under their latency.
     const int d_in = net.d_in, H1 = net.H[1];
-    constexpr int N1IT = (8 * WS + NTHREADS - 1) / NTHREADS;
-    constexpr int NHIT = (LY::HP * WS + NTHREADS - 1) / NTHREADS;
-    float v1[N1IT], vh[L > 1 ? L - 1 : 1][NHIT];
-#pragma unroll
-    for (int it = 0; it < N1IT; ++it) {
-      const int i = tid + it * NTHREADS;
-      const int k = i / WS, pos = i % WS;
-      const int f = vfeat(pos & 63);
-      v1[it] = (i < 8 * WS && k < d_in && pos < 64 && f < H1) ? A.theta[net.woff[1] + k * H1 + f] : 0.f;
-    }
+    constexpr int NSRC = (LY::HP * LY::HP + NTHREADS - 1) / NTHREADS;
+    static_assert(8 * 64 <= NTHREADS, "layer 1: one parameter per thread");
+    float v1 = 0.f, vh[L > 1 ? L - 1 : 1][NSRC];
+    if (tid < d_in * H1) v1 = A.theta[net.woff[1] + tid];
 #pragma unroll
     for (int l = 2; l <= L; ++l) {
-      const int Hin = net.H[l - 1], Hout = net.H[l];
+      const int n = net.H[l - 1] * net.H[l];
+      const float* src = A.theta + net.woff[l];
 #pragma unroll
-      for (int it = 0; it < NHIT; ++it) {
-        const int i = tid + it * NTHREADS;
-        const int k = i / WS, pos = i % WS;
-        const int f = vfeat(pos & 63);
-        vh[l - 2][it] = (i < LY::HP * WS && k < Hin && pos < 64 && f < Hout) ? A.theta[net.woff[l] + k * Hout + f] : 0.f;
+      for (int it = 0; it < NSRC; ++it) {
+        const int j = tid + it * NTHREADS;
+        vh[l - 2][it] = j < n ? src[j] : 0.f;
       }
     }
     // biases (one per thread: L * 64 <= 512) and output weights ride in the same batch of loads
@@ -828,20 +837,26 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       vb = (ks < KS && f < net.H[l]) ? A.theta[net.boff[l] + f] : 0.f;
     }
     if (tid < 4 * KS) vo = (tid < net.H[L]) ? A.theta[net.woff[L + 1] + tid] : 0.f;
-    // (the zero fill of the transposition region needs no data: it runs under the latency of the loads above)
-    for (int i = tid; i < LY::T_SZ; i += NTHREADS) lds[LY::T_OFF + i] = 0.f;
-#pragma unroll
-    for (int it = 0; it < N1IT; ++it) {
-      const int i = tid + it * NTHREADS;
-      if (i < 8 * WS) W1[i] = v1[it];
+    static_assert(LY::BI_OFF % 4 == 0 && LY::T_OFF % 4 == 0 && LY::T_SZ % 4 == 0, "16-byte zero fill");
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < LY::BI_OFF / 4; i += NTHREADS) reinterpret_cast<f32x4a*>(lds)[i] = z4;                    // W1 | WH
+    for (int i = tid; i < LY::T_SZ / 4; i += NTHREADS) reinterpret_cast<f32x4a*>(lds + LY::T_OFF)[i] = z4;
+    __syncthreads();
+    if (tid < d_in * H1) {
+      const int k = tid / H1, f = tid - k * H1;
+      W1[k * WS + vpos(f >> 2, f & 3)] = v1;
     }
 #pragma unroll
     for (int l = 2; l <= L; ++l) {
       float* Wl = WH + (l - 2) * LY::HPWS;
+      const int Hout = net.H[l], n = net.H[l - 1] * Hout;
+      const int dq = NTHREADS / Hout, dr = NTHREADS - dq * Hout;      // j -> j + NTHREADS: k += dq, f += dr (one carry)
+      int k = tid / Hout, f = tid - k * Hout;
 #pragma unroll
-      for (int it = 0; it < NHIT; ++it) {
-        const int i = tid + it * NTHREADS;
-        if (i < LY::HP * WS) Wl[i] = vh[l - 2][it];
+      for (int it = 0; it < NSRC; ++it) {
+        if (tid + it * NTHREADS < n) Wl[k * WS + vpos(f >> 2, f & 3)] = vh[l - 2][it];
+        f += dr; k += dq;
+        if (f >= Hout) { f -= Hout; ++k; }
       }
     }
     if (tid < L * 64) BI[tid] = vb;
@@ -889,19 +904,17 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
   for (int t = 0; t < WOG::TPW; ++t) wacco[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float bo = A.theta[net.boff[L + 1]];
   const bool thin_in = net.d_in <= 3;                // input-layer weight gradient without workgroup barriers
   // KS == 16 with a 64-wide layer: its output side has no position left for the constant-one row of the NEXT layer's
   // weight gradient, whose bias gradient is then summed by thin_bias (hidden) / a per-lane scalar (output layer)
   bool ones_h[L > 1 ? L - 1 : 1];                    // layer l = 2..L: input side H[l-1] < 64
 #pragma unroll
-  for (int l = 2; l <= L; ++l) ones_h[l - 2] = (KS != 16) || net.H[l - 1] < 64;
-  const bool ones_o = (KS != 16) || net.H[L] < 64;
+  for (int l = 2; l <= L; ++l) ones_h[l - 2] = !fullpos(KS) || net.H[l - 1] < 4 * KS;
+  const bool ones_o = !fullpos(KS) || net.H[L] < 4 * KS;
   float bsum_h[L > 1 ? L - 1 : 1];
 #pragma unroll
   for (int l = 0; l < (L > 1 ? L - 1 : 1); ++l) bsum_h[l] = 0.f;
   float bsum_o = 0.f;
-  const int q = A.integ_num;
   const int TT = TILE / q;                                   // whole test functions per tile
   const int TPTS = TT * q;                                   // points used in an interior tile (<= TILE)
   const bool qtree = (TILE % q) == 0;                        // q divides the tile: shuffle-tree R_k
@@ -912,13 +925,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
   const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
 
-  // the quadrature index of this lane's point is the same in every interior tile (tiles start at
-  // whole test functions), so the periodic FE table entries are lane constants
-  const int pq_l = (wave * CW + lc.c) % q;
-  const int tf_l = (wave * CW + lc.c) / q;           // ... and so is its test function within the tile
-  const float tab_dnt = A.time_dependent ? A.fedNt[pq_l] : 0.f;
-  const float tab_w = A.feW ? A.feW[pq_l] : 1.f;
-  const float tab_N = A.feN[pq_l];
 #ifdef VN_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -1174,7 +1180,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #ifndef VN_ABL_NOTHIN
     thin_wgrad_out<KS, TANH>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0], ones_o);
 #endif
-    if (KS == 16 && !ones_o && lc.g == 0) bsum_o += ubar;          // d loss / d b_o = sum_p ubar_p
+    if (fullpos(KS) && !ones_o && lc.g == 0) bsum_o += ubar;          // d loss / d b_o = sum_p ubar_p
     if constexpr (HID13) __syncthreads();    // the lane-major images of the hidden layers overlap other waves' columns
     STAMP(4);
 #pragma unroll
@@ -1211,8 +1217,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
           wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
         }
       }
-      else wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], true STAMP_ARGS);
-      if constexpr (KS == 16) {
+      else wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
+      if constexpr (fullpos(KS)) {
         if (!ones_h[l - 2]) thin_bias<KS>(zb, TA, TB, lc, wave, lane, bsum_h[l - 2]);
       }
       STAMP(5);
@@ -1344,7 +1350,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     // bias gradients that did not ride in a constant-one row (KS == 16 behind a 64-wide layer) are per-wave partial sums
     // added in wave order: those rare shapes keep one round per wave
     bool serial_bias = false;
-    if constexpr (KS == 16) {
+    if constexpr (fullpos(KS)) {
       serial_bias = !ones_o;
 #pragma unroll
       for (int l = 2; l <= L; ++l) serial_bias = serial_bias || !ones_h[l - 2];
@@ -1366,7 +1372,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
           wgrad_flush<KS, KS, LY::HP>(wacch[l - 2], Gacc + LY::G1_SZ + (l - 2) * LY::GH_SZ, lc, wave, ones_h[l - 2]);
         }
       }
-      if constexpr (KS == 16) {
+      if constexpr (fullpos(KS)) {
         if (serial_bias && wave == r) {
           // hidden: lane = position of the output feature; output layer: sum over the wave's 16 points
 #pragma unroll
