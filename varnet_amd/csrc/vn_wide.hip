@@ -314,8 +314,17 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
 }
 
 // ---- reverse: rows + seeds + stored activations -> per-workgroup partial parameter gradient ---------------------------
+// Diagnostic build -DVN_WIDE_CAP128 (round-2 experiment, re-run in round 3: DESIGN.md appendix): cap the one-launch reverse
+// kernel at 128 registers so that two workgroups share a CU (it spills 114-269 VGPRs) -- grid and partial buffer double.
+#ifdef VN_WIDE_CAP128
+#define VN_WIDE_BWD_BOUNDS __launch_bounds__(NT, 4)
+constexpr int BWD_WG_PER_CU = 2;
+#else
+#define VN_WIDE_BWD_BOUNDS __launch_bounds__(NT)
+constexpr int BWD_WG_PER_CU = 1;
+#endif
 template <int ML, int BM, int BN>
-__global__ __launch_bounds__(NT) void vn_wide_bwd_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
+__global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
                                                          const float* __restrict__ wf, VnRows sg, long ntiles,
                                                          const float* __restrict__ kept, float* __restrict__ partial) {
   extern __shared__ float lds[];
@@ -987,7 +996,7 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_f);
   if (e == hipSuccess) e = hipFuncSetAttribute(bk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
   if (e == hipSuccess) e = hipMalloc((void**)&w->wf, (size_t)pl.wf_floats * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * (w->variant == 4 ? 2 : 1) * maxplen * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&w->part, (size_t)w->cus * (w->variant == 4 ? 2 : BWD_WG_PER_CU) * maxplen * sizeof(float));
   if (e != hipSuccess) {
     vn_wide_destroy(w);
     return wfail(err, errlen, "vn_wide_create: %s", hipGetErrorString(e));
@@ -1075,7 +1084,7 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
   k.valid = false;                                  // theta moves after this step
   const long ntiles = (seg.n + TP - 1) / TP;
   if (int rc = pack(w, theta, s, err, errlen)) return rc;
-  const long wgs = (long)w->cus * (w->variant == 4 ? 2 : 1);        // layer-serial, one pass: two workgroups per CU
+  const long wgs = (long)w->cus * (w->variant == 4 ? 2 : w->variant < 4 ? BWD_WG_PER_CU : 1);   // layer-serial, one pass: two workgroups per CU
   const int grid = (int)(ntiles < wgs ? ntiles : wgs);
   const VnNet& net = w->net;
   if (w->variant >= 4) {
