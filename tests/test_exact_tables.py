@@ -235,3 +235,54 @@ def test_operator_1dtmor_tables_long_run(tmp_path):
     print('MOR tables, long run: l2Err kappa=0.01/pi %.5f, kappa=0.005 %.5f (swapped pairing: %.5f %.5f)' % (e[0], e[1], swapped[0], swapped[1]))
     assert max(e) <= TABLE_BAR_MOR
     vn.engine.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Operator_2Dt.py:89-132: the reference's analytical solution of its 2D+t demo (Leij & Dane, integrated over time), the
+# known answer behind BASELINE config 3's problem.  tests/golden/cexfun_2dt.npz = outputs of the reference's own function
+# (oracle/gen_golden_cexfun.py); the metric is the script's: l2Err over ALL 151 time nodes (Operator_2Dt.py:174-183).
+GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cexfun_2dt.npz')
+TABLE_BAR_2DT = 0.40        # l2Err(cExFun, HIP field) over all 151 time nodes, down-scaled Operator_2Dt ([20,10] grid), 6000 epochs: measured 0.307
+
+
+def test_cexfun_restatement_matches_reference_outputs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ex_operator_2dt', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'examples', 'operator_2dt.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    g = np.load(GOLD2)
+    np.testing.assert_allclose(g['params'], [ex.T, ex.q[0], ex.q[1], ex.kappa, ex.c0, ex.a, ex.nt])
+    np.testing.assert_allclose(ex.cExFun(g['x']), g['c_all'], rtol=1e-12, atol=1e-14)
+    inlet = (g['x'][:, 0] < 1e-4) & (np.abs(g['x'][:, 1]) < 0.2)
+    assert inlet.sum() >= 3 and np.all(g['c_all'][inlet] == 1.0) and np.all(g['c_all'][:, 0][~inlet] == 0.0)
+
+
+def _l2err_2dt(forward, g):
+    """Operator_2Dt.py:174-183: cEx = cExFun(coord) flattened row-major, cApp on pairMats(coord, tcoord)."""
+    x, T, nt = g['x'], float(g['params'][0]), int(g['params'][6])
+    tcoord = np.linspace(0, T, num=nt).reshape(nt, 1)
+    Input = uf.pairMats(x, tcoord)
+    return float(uf.l2Err(g['c_all'].reshape(-1, 1), forward(Input)))
+
+
+@pytest.mark.gpu
+def test_operator_2dt_analytic_hip_vs_oracle_and_long_run(tmp_path):
+    from tests.test_operator_parity_gpu import run_both
+    from tests.test_varnet_gpu import op2dt
+    g = np.load(GOLD2)
+    vn = op2dt([10, 20], [20, 10], 10, 15)                             # Operator_2Dt.py:136-158, grid scaled down
+    gl, cl, th_g, th_c, _ = run_both(vn, [5., 1., 1.], 400)          # weight: Operator_2Dt.py:167
+    e_g = _l2err_2dt(lambda X: vn.evaluate(x=X[:, :2], t=X[:, 2:3]), g)
+    e_c = _l2err_2dt(lambda X: og.forward(th_c.astype(np.float64), 3, [10, 20], torch.float64, X), g)
+    dev = float(np.max(np.abs(gl - cl) / np.abs(cl)))
+    assert dev <= 1e-2 and abs(e_g - e_c) <= 1e-4, (dev, e_g, e_c)
+    vn.engine.init_params(seed=0)
+    res = vn.train(str(tmp_path), weight=[5., 1., 1.], smpScheme='uniform', epochNum=6000, saveFreq=2000, verbose=False, lossLag=16)
+    e_long = _l2err_2dt(lambda X: vn.evaluate(x=X[:, :2], t=X[:, 2:3]), g)
+    record('operator_2dt_downscaled', dict(budget_steps=400, max_rel_loss_dev=dev, l2Err_cExFun_hip=e_g, l2Err_cExFun_oracle=e_c,
+                                            long_epochs=len(res.lossAll), l2Err_cExFun_hip_long=e_long,
+                                            loss_first_last=[float(res.lossAll[0]), float(res.lossAll[-1])]))
+    print('2Dt analytic: 400 steps l2Err hip %.5f oracle %.5f (loss dev %.1e); %d epochs: %.5f' % (e_g, e_c, dev, len(res.lossAll), e_long))
+    assert e_long <= TABLE_BAR_2DT
+    vn.engine.close()
