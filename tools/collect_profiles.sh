@@ -3,29 +3,29 @@
 # separate --pmc passes the roofline numbers in bench.py / DESIGN.md come from.  Outputs land in
 # gpurun_out/prof_<tag>/ ; tools/summarise_profiles.py copies the summaries into profiles/.
 # (--pmc runs carry --kernel-trace only: no sys/hip/hsa trace domains beside counters.)
-tag=${1:-r2}
+tag=${1:-r3}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd $root
 out=gpurun_out/prof_$tag
 mkdir -p $out
-python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
-python bench.py --config 2 --steps 200 --warmup 20 --no-dedup > $out/bench_cfg2.json 2> $out/bench_cfg2.err
-rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dedup > $out/stats.log 2>&1
+python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
+python3 bench.py --config 2 --steps 400 --warmup 40 --no-dedup --no-cpu-baseline > $out/bench_cfg2.json 2> $out/bench_cfg2.err
+rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-dedup --no-extra > $out/stats.log 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VALU"; do
   t=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --kernel-trace -d $out/pmc_$t -o p --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dedup > $out/pmc_$t.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace -d $out/pmc_$t -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dedup --no-extra > $out/pmc_$t.log 2>&1
 done
 # the other routes: two-pass fused (integNum 216) and the generic kernels (width 64)
-rocprofv3 --kernel-trace --stats -d $out/stats_q216 -o s --output-format csv -- python tools/q216_perf.py > $out/q216.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $out/stats_generic -o s --output-format csv -- python tools/width_perf.py 64 3 > $out/generic_w64.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $out/stats_q216 -o s --output-format csv -- python3 tools/q216_perf.py > $out/q216.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $out/stats_generic -o s --output-format csv -- python3 tools/width_perf.py 64 3 > $out/generic_w64.txt 2>&1
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --kernel-trace -d $out/gpmc_$t -o p --output-format csv -- python tools/width_perf.py 64 3 > $out/gpmc_$t.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace -d $out/gpmc_$t -o p --output-format csv -- python3 tools/width_perf.py 64 3 > $out/gpmc_$t.log 2>&1
 done
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --kernel-trace -d $out/tpmc_$t -o p --output-format csv -- python tools/q216_perf.py > $out/tpmc_$t.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace -d $out/tpmc_$t -o p --output-format csv -- python3 tools/q216_perf.py > $out/tpmc_$t.log 2>&1
 done
 python tools/shard_perf.py > $out/shard_perf.txt 2>&1
 python tools/mor_perf.py > $out/mor_perf.txt 2>&1

@@ -39,11 +39,13 @@ constexpr int TSW = 132;      // transposition image row stride
 // (KS == 13) uses positions 0..47, 48 (feature 48), 52 (feature 49), 49 (bias row) and one all-zero row,
 // so its images are packed into 52 rows (position 52 -> row 51, every unused position -> the zero row 50):
 // the 12 KB this frees hold another layer's accumulators (Lay::NST).
-__host__ __device__ constexpr int t_rows(int KS) { return KS == 13 ? 52 : 64; }
+// Nets up to 32 wide (KS <= 8) use positions 0..31 only: their images keep 32 rows + one all-zero row (33).
+__host__ __device__ constexpr int t_rows(int KS) { return KS == 13 ? 52 : KS <= 8 ? 33 : 64; }
 template <int KS>
 __device__ __forceinline__ int trow(int pos) {
-  if (KS != 13) return pos;
-  return pos < 50 ? pos : pos == 52 ? 51 : 50;
+  if (KS == 13) return pos < 50 ? pos : pos == 52 ? 51 : 50;
+  if (KS <= 8) return pos < 32 ? pos : 32;
+  return pos;
 }
 constexpr int KS0 = 2;        // input layer k-steps (d_in <= 8)
 
