@@ -1117,21 +1117,26 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       t *= wq;
       if (!valid) t = 0.f;
       const int seg = q < CW ? q : CW;
+      // A test function of up to 16 points (1D+t, two-point Gauss: q = 16) lies inside one wave: the butterfly below leaves
+      // its sum R_k in every lane of the group (a + b == b + a bit for bit, so all lanes agree) -- no LDS, no workgroup barrier.
+      const bool rk_in_wave = qtree && q <= CW;
       if (qtree) {
         for (int o = 1; o < seg; o <<= 1) t += __shfl_xor(t, o, 64);
-        if (lc.g == 0 && (lc.c % seg) == 0) sInt[pt / seg] = t;
+        if (!rk_in_wave && lc.g == 0 && (lc.c % seg) == 0) sInt[pt / seg] = t;
       } else if (lc.g == 0) {
         sInt[pt] = t;                                                 // q does not divide the tile: serial sum
       }
       ESTAMP(1);
 #ifndef VN_ABL_NOEPIBAR
-      __syncthreads();
+      if (!rk_in_wave) __syncthreads();
 #endif
       ESTAMP(2);
       // every lane sums the partials of its own test function (same order in all lanes, so all
       // agree bit for bit): no second barrier and no serial section
       float R = 0.f;
-      if (qtree) {
+      if (rk_in_wave) {
+        R = t;
+      } else if (qtree) {
         const int per = q / seg;                                      // partials per test function
         for (int j = 0; j < per; ++j) R += sInt[tf_l * per + j];      // :661
       } else {
