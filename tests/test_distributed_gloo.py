@@ -71,6 +71,19 @@ def test_world2_matches_world1(tmp_path, batchNum):
         assert np.isfinite(b['loss']).all() and b['loss'][-1] < b['loss'][0] * 1.5
 
 
+def test_world4_uneven_blocks_match_world1(tmp_path):
+    """Four towers over 35 test functions: blocks of 9, 9, 9, 8 (batchLen = ceil(nt / puNum), VarNetUtility.py:825-838);
+    the rehearsal of more ranks the one-GPU boxes allow."""
+    out = str(tmp_path)
+    _run(0, 1, _free_port(), out, None)
+    mp.spawn(_run, args=(4, _free_port(), out, None), nprocs=4, join=True)
+    a = np.load(os.path.join(out, 'out_w1_bNone.npz'))
+    b = np.load(os.path.join(out, 'out_w4_bNone.npz'))
+    np.testing.assert_allclose(b['w'] * np.array([4.0, 4.0, 1.0]), a['w'], rtol=1e-10)
+    np.testing.assert_allclose(b['loss'], a['loss'], rtol=1e-9)
+    np.testing.assert_allclose(b['theta'], a['theta'], rtol=1e-7, atol=1e-10)
+
+
 # ---- cases the round-1 review asked for ------------------------------------------------------------
 import multiprocessing
 from tests import rank_worker as rw
