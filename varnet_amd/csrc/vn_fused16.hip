@@ -172,6 +172,11 @@ __device__ __forceinline__ f32x2 act_d2r_2(f32x2 a) {
   return TANH ? (-two * a) : (one - two * a);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -1121,7 +1126,13 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       // its sum R_k in every lane of the group (a + b == b + a bit for bit, so all lanes agree) -- no LDS, no workgroup barrier.
       const bool rk_in_wave = qtree && q <= CW;
       if (qtree) {
-        for (int o = 1; o < seg; o <<= 1) t += __shfl_xor(t, o, 64);
+        // butterfly over the seg <= 16 lanes of a test function's points, inside a 16-lane row: DPP moves (no LDS round
+        // trip on the critical path of the epilogue).  After the two quad steps all lanes of a quad hold the same value, so
+        // mirroring within 8 and within 16 lanes pairs the same sums as xor 4 / xor 8 would (bit-identical results).
+        if (seg > 1) t += dpp_f32<0xB1>(t);        // quad_perm [1,0,3,2]
+        if (seg > 2) t += dpp_f32<0x4E>(t);        // quad_perm [2,3,0,1]
+        if (seg > 4) t += dpp_f32<0x141>(t);       // row_half_mirror
+        if (seg > 8) t += dpp_f32<0x140>(t);       // row_mirror
         if (!rk_in_wave && lc.g == 0 && (lc.c % seg) == 0) sInt[pt / seg] = t;
       } else if (lc.g == 0) {
         sInt[pt] = t;                                                 // q does not divide the tile: serial sum
