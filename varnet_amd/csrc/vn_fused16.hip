@@ -383,28 +383,29 @@ __device__ __forceinline__ void thin_contract(const float* TA, const float* TB, 
   acc += t;
 }
 
-// output layer: rows = the KS*4 positions of a (and the bias row), one column ubar (lanes g == 0 publish it
-// into row 0, the other lane groups publish zeros into rows 4, 8, 12)
+// output layer: d w_o[f] = sum_p (a[f][p] ubar[p] + adot[f][p] udbar[p]).  Both seeds are per-point scalars, so the two products
+// are combined per element IN REGISTERS, c = a ubar + (sigma'(a) zdot) udbar, and ONE transposition pass contracts c against a
+// column of ones (the bias row carries ubar itself: d b_o = sum_p ubar[p]) -- half the LDS round trips and 4x4x1 MFMAs of the
+// two-pass form, on a stretch of the tile where the matrix pipe is idle anyway.  Lanes g == 0 publish the ones into row 0
+// of TB, the other lane groups zeros into rows 4, 8, 12.
 template <int KS, bool TANH, class AV>
 __device__ __forceinline__ void thin_wgrad_out(const AV& av, const AV& azd, float ubar, float udbar,
                                                float* TA, float* TB, const LaneC& lc, int wave, int lane, f32x4& acc,
                                                bool ones_row) {
   using W = WG<KS, 1>;
+  const f32x2 ub2 = {ubar, ubar}, ud2 = {udbar, udbar};
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int j = 0; j < PA<KS>::NP; ++j) {
-      f32x2 v2 = av.p[j];
-      if (half == 1) v2 = act_d1_2<TANH>(opaque2(av.p[j])) * azd.p[j];
-      t_write<KS>(TA, lc, 2 * j, v2[0]);
-      if (2 * j + 1 < KS) t_write<KS>(TA, lc, 2 * j + 1, v2[1]);
-    }
-    if (ones_row && lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
-    TB[lc.twr] = (lc.g == 0) ? (half == 0 ? ubar : udbar) : 0.f;
-    wave_lds_sync();
-    thin_contract<KS, true>(TA, TB, (lane & 3) == 0 ? 0 : 4, wave, lane, acc);
-    wave_lds_sync();
+  for (int j = 0; j < PA<KS>::NP; ++j) {
+    const f32x2 a2 = opaque2(av.p[j]);
+    const f32x2 c2 = a2 * ub2 + (act_d1_2<TANH>(a2) * azd.p[j]) * ud2;
+    t_write<KS>(TA, lc, 2 * j, c2[0]);
+    if (2 * j + 1 < KS) t_write<KS>(TA, lc, 2 * j + 1, c2[1]);
   }
+  if (ones_row && lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = ubar;
+  TB[lc.twr] = (lc.g == 0) ? 1.f : 0.f;
+  wave_lds_sync();
+  thin_contract<KS, true>(TA, TB, (lane & 3) == 0 ? 0 : 4, wave, lane, acc);
+  wave_lds_sync();
 }
 
 template <int KS>
