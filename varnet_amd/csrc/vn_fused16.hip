@@ -172,6 +172,16 @@ __device__ __forceinline__ f32x2 act_d2r_2(f32x2 a) {
   return TANH ? (-two * a) : (one - two * a);
 }
 
+// x summed over the four 16-lane rows of the wave, in every lane: (r0 + r1) + (r2 + r3)
+__device__ __forceinline__ float rowsum4(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = [r0 r0 r2 r2], b = [r1 r1 r3 r3]
+  const float s = a + b;
+  float c = s, d = s;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(c), "+v"(d));     // c = [lo lo], d = [hi hi]
+  return c + d;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
@@ -1096,8 +1106,10 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       u = u2[0] + u2[1];
       ud = ud2[0] + ud2[1];
     }
-    u += __shfl_xor(u, 16, 64);  ud += __shfl_xor(ud, 16, 64);
-    u += __shfl_xor(u, 32, 64);  ud += __shfl_xor(ud, 32, 64);
+    // sum over the four lane groups: row swaps (v_permlane16_swap / v_permlane32_swap, tools/micro/rowsum4_check.hip) instead of
+    // two ds_bpermute round trips per value -- this stretch of the tile has no matrix work to hide an LDS latency behind;
+    // same pairing as xor 16 then xor 32, so the same bits
+    u = rowsum4(u);  ud = rowsum4(ud);
     u += bo;
 
     // ---------------------------------------------------------------- weak-form epilogue
