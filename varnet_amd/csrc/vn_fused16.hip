@@ -1161,8 +1161,15 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       if (rk_in_wave) {
         R = t;
       } else if (qtree) {
-        const int per = q / seg;                                      // partials per test function
-        for (int j = 0; j < per; ++j) R += sInt[tf_l * per + j];      // :661
+        const int per = q / seg;                                      // partials per test function (a power of two <= 8)
+        if (per == 4) {
+          // integNum 64 (2D+t, two-point Gauss): the four partials with one 16-byte read instead of four dependent round
+          // trips right behind the barrier, where every wave of the workgroup waits for them; same order of additions
+          const f32x4 s4 = *reinterpret_cast<const f32x4a*>(&sInt[tf_l * 4]);
+          R = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+        } else {
+          for (int j = 0; j < per; ++j) R += sInt[tf_l * per + j];    // :661
+        }
       } else {
         for (int p = 0; p < q; ++p) R += sInt[tf_l * q + p];
       }
