@@ -187,6 +187,15 @@ __device__ __forceinline__ float dpp_f32(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
 }
 
+// x summed over the 16 lanes of its row, in every lane of the row (fixed order: quads, then 8, then 16)
+__device__ __forceinline__ float rowsum16(float x) {
+  x += dpp_f32<0xB1>(x);         // quad_perm [1,0,3,2]
+  x += dpp_f32<0x4E>(x);         // quad_perm [2,3,0,1]
+  x += dpp_f32<0x141>(x);        // row_half_mirror
+  x += dpp_f32<0x140>(x);        // row_mirror
+  return x;
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -909,7 +918,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   constexpr int NHACC = HID13 ? 2 : WHG::TPW;
   f32x4a* stash = reinterpret_cast<f32x4a*>(lds + LY::ST_OFF) + wave * 2 * 64 + lane;   // [layer][wave][slot][lane]
   constexpr int ST_L = LY::ST_LAYER / 4;
-  f32x4 wacc1[W1G::TPW], wacch[L > 1 ? L - 1 : 1][NHACC], wacco[WOG::TPW];
+  f32x4 wacc1[W1G::TPW], wacch[L > 1 ? L - 1 : 1][NHACC];
+  float woacc = 0.f, boacc = 0.f;                    // output layer: lane (g, c) holds d w_o[4c + g]; d b_o in every lane
 #pragma unroll
   for (int t = 0; t < W1G::TPW; ++t) wacc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -919,8 +929,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       wacch[l][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (l < LY::NST) stash[l * ST_L + t * 64] = wacch[l][t];
     }
-#pragma unroll
-  for (int t = 0; t < WOG::TPW; ++t) wacco[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const bool thin_in = net.d_in <= 3;                // input-layer weight gradient without workgroup barriers
   // KS == 16 with a 64-wide layer: its output side has no position left for the constant-one row of the NEXT layer's
@@ -928,11 +936,9 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   bool ones_h[L > 1 ? L - 1 : 1];                    // layer l = 2..L: input side H[l-1] < 64
 #pragma unroll
   for (int l = 2; l <= L; ++l) ones_h[l - 2] = !fullpos(KS) || net.H[l - 1] < 4 * KS;
-  const bool ones_o = !fullpos(KS) || net.H[L] < 4 * KS;
   float bsum_h[L > 1 ? L - 1 : 1];
 #pragma unroll
   for (int l = 0; l < (L > 1 ? L - 1 : 1); ++l) bsum_h[l] = 0.f;
-  float bsum_o = 0.f;
   const int TT = TILE / q;                                   // whole test functions per tile
   const int TPTS = TT * q;                                   // points used in an interior tile (<= TILE)
   const bool qtree = (TILE % q) == 0;                        // q divides the tile: shuffle-tree R_k
@@ -1121,6 +1127,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       continue;
     }
     float ubar = 0.f, udbar = 0.f;
+    bool epi_barrier = false;                                // this tile's epilogue ran a workgroup barrier (uniform)
     if (interior && A.mode == 2) {                           // seeds were assembled per unique point
       if (valid) {
         ubar = A.seed_u ? A.seed_u[row] : 0.f;
@@ -1152,7 +1159,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       }
       ESTAMP(1);
 #ifndef VN_ABL_NOEPIBAR
-      if (!rk_in_wave) __syncthreads();
+      if (!rk_in_wave) { __syncthreads(); epi_barrier = true; }
 #endif
       ESTAMP(2);
       // every lane sums the partials of its own test function (same order in all lanes, so all
@@ -1213,13 +1220,26 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       const f32x2 zq = adb * sp;
       zdb.p[j] = zq;
       zb.p[j] = ab * sp + zq * act_d2r_2<TANH>(av) * zd[L - 1].p[j];
-    }
-    STAMP(3);
 #ifndef VN_ABL_NOTHIN
-    thin_wgrad_out<KS, TANH>(a[L - 1], zd[L - 1], ubar, udbar, TA, TB, lc, wave, lane, wacco[0], ones_o);
+      // Output-layer weight gradient, no LDS, no MFMA, no barrier: d w_o[f] = sum_p (a[f][p] ubar[p] + adot[f][p] udbar[p]).
+      // Both seeds are per-point scalars, so the products are combined per element in registers and summed over the 16
+      // lanes of a row (= the wave's 16 points of feature 4 ks + g) with DPP moves; lane c == ks of each row keeps the sum
+      // of k-step ks.  This stretch of the tile (epilogue -> first publish round) has no matrix work to hide an LDS round
+      // trip behind, and the images stay untouched until the first publish.
+      const f32x2 c2 = av * f32x2{ubar, ubar} + (sp * zd[L - 1].p[j]) * f32x2{udbar, udbar};
+      const float s0 = rowsum16(c2[0]);
+      woacc += (lc.c == 2 * j) ? s0 : 0.f;
+      if (2 * j + 1 < KS) {
+        const float s1 = rowsum16(c2[1]);
+        woacc += (lc.c == 2 * j + 1) ? s1 : 0.f;
+      }
 #endif
-    if (fullpos(KS) && !ones_o && lc.g == 0) bsum_o += ubar;          // d loss / d b_o = sum_p ubar_p
-    if constexpr (HID13) __syncthreads();    // the lane-major images of the hidden layers overlap other waves' columns
+    }
+    boacc += rowsum16(ubar);                 // d loss / d b_o = sum_p ubar_p (every lane of the wave holds the wave's sum)
+    STAMP(3);
+    // The lane-major images of the hidden layers overlap other waves' columns of the per-wave (input-layer) transposition
+    // at the end of the previous tile: a tile whose epilogue had its own workgroup barrier is already past it.
+    if constexpr (HID13) { if (!epi_barrier) __syncthreads(); }
     STAMP(4);
 #pragma unroll
     for (int l = L; l >= 2; --l) {
@@ -1348,7 +1368,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     SL[((wave * 2 + 0) * 4 + i) * 64 + lane] = thin_in ? wacc1[0][i] : 0.f;
-    SL[((wave * 2 + 1) * 4 + i) * 64 + lane] = wacco[0][i];
+    SL[((wave * 2 + 1) * 4 + i) * 64 + lane] = (i == 0) ? woacc : boacc;
   }
   if constexpr (HID13) {
     // 50-wide hidden layers: a tile wave's first slot and the two border jobs own their image elements
@@ -1389,7 +1409,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     // added in wave order: those rare shapes keep one round per wave
     bool serial_bias = false;
     if constexpr (fullpos(KS)) {
-      serial_bias = !ones_o;
 #pragma unroll
       for (int l = 2; l <= L; ++l) serial_bias = serial_bias || !ones_h[l - 2];
     }
@@ -1417,12 +1436,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
           for (int l = 2; l <= L; ++l)
             if (!ones_h[l - 2] && vfeat(lane) < LY::HP)
               Gacc[LY::G1_SZ + (l - 2) * LY::GH_SZ + LY::HP * LY::HP + vfeat(lane)] += bsum_h[l - 2];
-          if (!ones_o) {
-            float b = bsum_o;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
-            if (lane == 0) Gacc[LY::GO_OFF + 4 * KS] += b;
-          }
         }
       }
       __syncthreads();
@@ -1448,14 +1461,10 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
           for (int w = 0; w < NW; ++w) v += sp[(w * 2 + 0) * 4 * 64];
         } else if (l == L + 1) {
-          // thin_wgrad_out: lane 4b (column 0 of block b) register i holds position 4b + i; the bias rides at vones(KS)
-          const bool bias = r >= Hin;
-          const int pos = bias ? vones(KS) : vpos(r >> 2, r & 3);
-          if (!bias || ones_o) {
-            const float* sp = SL + (4 + (pos & 3)) * 64 + (pos & ~3);
+          // output layer: slot register 0 = woacc (lane 16 g + c holds feature 4 c + g), register 1 = boacc (any lane)
+          const float* sp = SL + (r < Hin ? 4 * 64 + 16 * (r & 3) + (r >> 2) : 5 * 64);
 #pragma unroll
-            for (int w = 0; w < NW; ++w) v += sp[(w * 2) * 4 * 64];
-          }
+          for (int w = 0; w < NW; ++w) v += sp[(w * 2) * 4 * 64];
         }
         out[net.woff[l] + r * Hout + cc] = v;
       }
