@@ -1,6 +1,7 @@
 """Fixed cost of one fused launch: time of vn_grad on an EMPTY batch (n_k = 0, nB = 0: prologue + epilogue only)
 and on 1 / 2 tiles per workgroup, for the 5x50 and 4x50 nets.   python tools/fixed_cost.py"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
+os.environ['VN_FULL_GRID'] = '1'   # fixed cost of a full 256-workgroup launch, also on the empty batch
 sys.path.insert(0, '.')
 from varnet_amd.engine import VNEngine
 for widths, d_in, dim, q in (([50] * 5, 3, 2, 64), ([50] * 4, 2, 1, 16), ([10, 20, 30], 3, 1, 16)):

@@ -18,6 +18,9 @@ import numpy as np
 
 
 def run(workload, steps):
+    import os
+    if workload == 'empty550':
+        os.environ['VN_FULL_GRID'] = '1'          # the fixed cost of a FULL launch (an empty batch would otherwise get one workgroup)
     import torch
     sys.path.insert(0, '.')
     from varnet_amd.engine import VNEngine

@@ -102,6 +102,7 @@ struct vn_engine {
   int64_t step = 0;
   bool use_fused = false;
   bool use_fused16 = false;
+  bool full_grid = false;            // VN_FULL_GRID=1 (diagnostic): #CU workgroups whatever the tile count (fixed-cost measurements)
   VnOptArgs fuse;                    // optimizer step to fold into the next gradient reduction (kind -1: none)
   bool two_pass = false;             // fused kernel twice around the row-wise seed kernel (integ_num > 128)
   bool fused_only = false;           // 7-8 hidden layers: no generic kernels for this net
@@ -552,6 +553,7 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
                  (cfg->kernel != VN_KERNEL_GENERIC && vn_fused_supported(net, cfg->integ_num));
   h->two_pass = !h->use_fused && tp_ok && (cfg->kernel == VN_KERNEL_FUSED16 || cfg->kernel == VN_KERNEL_AUTO);
   h->fused_only = deep_fused;
+  { const char* fg = getenv("VN_FULL_GRID"); h->full_grid = fg && *fg && *fg != '0'; }
   if (h->use_fused || h->two_pass) {
     // (the forward-only mode of the 8-wave kernel writes its per-workgroup loss partials here too: vn_forward and
     // vn_eval_loss of a two-pass engine must not find it NULL)
@@ -830,7 +832,11 @@ int vn_grad(vn_engine* h, int32_t batch) {
     a.Xb = bi_x(h, b); a.label = bi_y(h, b); a.nB = h->nB; a.bDof = h->bDof; a.biDimVal = (float)h->biDimVal;
     a.w0 = (float)h->w[0]; a.w1 = (float)h->w[1]; a.w2 = (float)h->w[2];
     a.partial = h->partial; a.losspart = h->fused_losspart; a.stamps = h->stamps;
-    const int grid = h->ncu;
+    // one persistent workgroup per CU, but never more workgroups than tiles (small mini-batches: idle workgroups would still
+    // image the weights, flush and store an all-zero partial that the reduction then has to read)
+    const long tt = 128 / a.integ_num > 0 ? 128 / a.integ_num : 1;
+    const long tiles = (a.n_k + tt - 1) / tt + (a.nB + 127) / 128;
+    const int grid = h->full_grid ? h->ncu : (int)(tiles < 1 ? 1 : tiles < h->ncu ? tiles : h->ncu);
     const bool rec = h->prof_on && h->prof_n < PROF_CAP;
     if (rec) {
       if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
