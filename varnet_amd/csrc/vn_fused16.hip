@@ -68,6 +68,10 @@ __host__ __device__ constexpr int vones(int KS) {
 }
 static_assert(vfeat(63) == 63 && vfeat(31) == 31 && vpos(7, 3) == 31, "position 4*KS-1 is feature 4*KS-1");
 __host__ __device__ constexpr int mtiles(int KS) { return (KS + 3) / 4; }
+#ifndef VN_MERGED_ROUNDS
+#define VN_MERGED_ROUNDS 1
+#endif
+__host__ __device__ constexpr bool merged_rounds(int L, int KS) { return VN_MERGED_ROUNDS && KS <= 8 && L >= 2; }   // one publish/contract round per hidden layer
 
 template <int L, int KS>
 struct Lay {
@@ -83,7 +87,8 @@ struct Lay {
   static constexpr int GH_SZ = (HP + 1) * HP;
   static constexpr int GO_OFF = G1_SZ + (L - 1) * GH_SZ;
   static constexpr int G_SZ = al4(GO_OFF + HP + 1);
-  static constexpr int T_IMG = 2 * t_rows(KS) * TSW;
+  static constexpr bool MERGE = merged_rounds(L, KS);
+  static constexpr int T_IMG = (MERGE ? 2 : 1) * 2 * t_rows(KS) * TSW;     // TA | TB ( | TA' | TB' : wgrad_layer)
   static constexpr int T_H13 = (KS == 13) ? 27 * (NW * 64 + 4) : 0;         // lane-major images of the 50-wide path (H13)
   static constexpr int T_MAX = T_IMG > T_H13 ? T_IMG : T_H13;
   // The gradient image of the final flush normally shares the transposition region.  Where it is larger than that
@@ -296,7 +301,7 @@ __device__ __forceinline__ void t_write(float* T, const LaneC& lc, int ks, float
 // 128 points into persistent accumulators.
 // ones_row: the layer's input side has a position to spare for the constant-one row that carries the bias gradient
 // (always, except for a 64-wide input side at KS == 16: then the bias gradient comes from thin_bias below).
-template <int KSA, int KSB, bool RAWA, bool TANH, int NACC, class AV, class BV>
+template <int KSA, int KSB, bool RAWA, bool TANH, bool MERGE, int NACC, class AV, class BV>
 __device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const BV& bv, const BV& bt, float* TA,
                                             float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC], bool ones_row STAMP_PARAMS) {
   using W = WG<KSA, KSB>;
@@ -312,40 +317,25 @@ __device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const B
   int rdBt[W::TPW];
 #pragma unroll
   for (int t = 0; t < W::TPW; ++t) rdBt[t] = trow<KSB>(16 * (n0 + t) + lc.c) * TSW + sidx * W::PTS + goff;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if constexpr (RAWA) {
-#pragma unroll
-      for (int ks = 0; ks < KSA; ++ks) t_write<KSA>(TA, lc, ks, half == 0 ? av[ks] : azd[ks]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < PA<KSA>::NP; ++j) {            // sigma'(a) * zdot for two k-steps per packed instruction
-        f32x2 v2 = av.p[j];
-        if (half == 1) v2 = act_d1_2<TANH>(opaque2(av.p[j])) * azd.p[j];
-        t_write<KSA>(TA, lc, 2 * j, v2[0]);
-        if (2 * j + 1 < KSA) t_write<KSA>(TA, lc, 2 * j + 1, v2[1]);
-      }
-    }
-    if (ones_row && lc.g == W::ones_g) TA[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KSB; ++ks) t_write<KSB>(TB, lc, ks, (half == 0) ? bv[ks] : bt[ks]);
-    WSTAMP(2);
-    __syncthreads();
-    WSTAMP(3);
-    f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA]);
+  // Nets up to 32 wide (KS <= 8) have LDS to spare: value and tangent operands are published side by side (a second
+  // image pair T2 floats on) and contracted behind ONE barrier pair per layer instead of two -- a small net's tile is a chain
+  // of short phases between barriers, not matrix work (profiles/r3_small_stamps.txt).
+  constexpr int T2 = MERGE ? 2 * t_rows(KSB) * TSW : 0;
+  auto contract = [&](const float* TAh, const float* TBh) {
+    f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TAh[rdA]);
     f32x4 b4[W::TPW];
 #pragma unroll
-    for (int t = 0; t < W::TPW; ++t) b4[t] = *reinterpret_cast<const f32x4a*>(&TB[rdBt[t]]);
+    for (int t = 0; t < W::TPW; ++t) b4[t] = *reinterpret_cast<const f32x4a*>(&TBh[rdBt[t]]);
 #pragma unroll
     for (int j = 0; j < W::PG / 4; ++j) {
       f32x4 an = a4, bn[W::TPW];
 #pragma unroll
       for (int t = 0; t < W::TPW; ++t) bn[t] = b4[t];
       if (j + 1 < W::PG / 4) {
-        an = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * (j + 1)]);
+        an = *reinterpret_cast<const f32x4a*>(&TAh[rdA + 4 * (j + 1)]);
 #pragma unroll
         for (int t = 0; t < W::TPW; ++t)
-          bn[t] = *reinterpret_cast<const f32x4a*>(&TB[rdBt[t] + 4 * (j + 1)]);
+          bn[t] = *reinterpret_cast<const f32x4a*>(&TBh[rdBt[t] + 4 * (j + 1)]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -357,6 +347,32 @@ __device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const B
 #pragma unroll
       for (int t = 0; t < W::TPW; ++t) b4[t] = bn[t];
     }
+  };
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    float* TAh = TA + half * T2;
+    float* TBh = TB + half * T2;
+    if constexpr (RAWA) {
+#pragma unroll
+      for (int ks = 0; ks < KSA; ++ks) t_write<KSA>(TAh, lc, ks, half == 0 ? av[ks] : azd[ks]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < PA<KSA>::NP; ++j) {            // sigma'(a) * zdot for two k-steps per packed instruction
+        f32x2 v2 = av.p[j];
+        if (half == 1) v2 = act_d1_2<TANH>(opaque2(av.p[j])) * azd.p[j];
+        t_write<KSA>(TAh, lc, 2 * j, v2[0]);
+        if (2 * j + 1 < KSA) t_write<KSA>(TAh, lc, 2 * j + 1, v2[1]);
+      }
+    }
+    if (ones_row && lc.g == W::ones_g) TAh[lc.twr - 4 * lc.g * TSW + W::ONES * TSW] = (half == 0) ? 1.f : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSB; ++ks) t_write<KSB>(TBh, lc, ks, (half == 0) ? bv[ks] : bt[ks]);
+    if (MERGE && half == 0) continue;
+    WSTAMP(2);
+    __syncthreads();
+    WSTAMP(3);
+    if (MERGE) contract(TA, TB);
+    contract(TAh, TBh);
     WSTAMP(4);
     __syncthreads();
     WSTAMP(5);
@@ -808,6 +824,23 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   constexpr int MTM = EDGE ? MT - 1 : MT;            // row tiles produced by MFMA in hidden layers
   constexpr int NVE = (KS == 13) ? 2 : 4;            // edge features that can be non-padding
   constexpr int EPOS = 16 * (MT - 1);                // accumulator row of edge feature 0
+  // KSKIP: nets up to 32 wide are padded to 4*KS features in EVERY layer; a small net's tile is bound by the matrix pipe like
+  // any other (removing MFMAs scales the step: profiles/r3_small_sensitivity.txt), so the k-steps and row tiles that hold
+  // only padding (zero weights: they add +0) are branched over, wave-uniformly, on the layer's real widths -- the [10,20,30]
+  // net of Operator_1DtMOR.py:189 needs 3 and 5 of its 8 forward k-steps, and one of two row tiles in its last input gradient.
+  constexpr bool KSKIP = KS <= 8;
+  // (the bound is made opaque at every use: left to itself the compiler hoists the loop-invariant compares out of the tile
+  // loop as 64-bit lane masks, a pair of scalar registers per guard, and spills them through v_writelane)
+  auto live_k = [](int ks, int& kn) {
+    if (!KSKIP || ks == 0) return true;
+    asm volatile("" : "+s"(kn));
+    return ks < kn;
+  };
+  auto live_m = [](int m, int& mn) {
+    if (!KSKIP || m == 0) return true;
+    asm volatile("" : "+s"(mn));
+    return m < mn;
+  };
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const VnNet& net = A.net;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -913,7 +946,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   // persistent weight-gradient accumulators
   using W1G = WG<KS0, KS>;
   using WHG = WG<KS, KS>;
-  using WOG = WG<KS, 1>;
   constexpr bool HID13 = (KS == 13);                 // 50-wide hidden layers: 3x3 core tiles + 4x4x1 borders
   constexpr int NHACC = HID13 ? 2 : WHG::TPW;
   f32x4a* stash = reinterpret_cast<f32x4a*>(lds + LY::ST_OFF) + wave * 2 * 64 + lane;   // [layer][wave][slot][lane]
@@ -1009,6 +1041,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
     for (int l = 2; l <= L; ++l) {
       const float* Wl = WH + (l - 2) * LY::HPWS;
+      int k_in = (net.H[l - 1] + 3) >> 2, m_out = (net.H[l] + 15) >> 4;      // KSKIP: live k-steps / row tiles of this layer (scalar)
       f32x4 nv[MT], nt[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -1051,10 +1084,13 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
           wen[v] = (EDGE && ks + 1 < KS) ? Wl[4 * (ks + 1) * WS + lc.offF - lc.c + EPOS + 4 * v] : 0.f;
         const float cs = cs2[ks & 1], cq = cq2[ks & 1];
         __builtin_amdgcn_sched_barrier(0);
+        if (live_k(ks, k_in)) {
 #pragma unroll
-        for (int m = 0; m < MTM; ++m) {
-          nv[m] = mfma16(wf[m], cs, nv[m]);
-          nt[m] = mfma16(wf[m], cq, nt[m]);
+          for (int m = 0; m < MTM; ++m) {
+            if (!live_m(m, m_out)) continue;
+            nv[m] = mfma16(wf[m], cs, nv[m]);
+            nt[m] = mfma16(wf[m], cq, nt[m]);
+          }
         }
         if (EDGE) {
 #pragma unroll
@@ -1268,19 +1304,20 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       else if constexpr (NHACC == 2) {
         if (l - 2 < LY::NST) {               // accumulators of this layer live in the LDS stash between tiles
           f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
-          wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, acc2, ones_h[l - 2] STAMP_ARGS);
+          wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, acc2, ones_h[l - 2] STAMP_ARGS);
           stash[(l - 2) * ST_L] = acc2[0];
           stash[(l - 2) * ST_L + 64] = acc2[1];
         } else {
-          wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
+          wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
         }
       }
-      else wgrad_layer<KS, KS, false, TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
+      else wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
       if constexpr (fullpos(KS)) {
         if (!ones_h[l - 2]) thin_bias<KS>(zb, TA, TB, lc, wave, lane, bsum_h[l - 2]);
       }
       STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
+      int k_out = (net.H[l] + 3) >> 2, m_in = (net.H[l - 1] + 15) >> 4;
       f32x4 accv[MT], acct[MT];
 #pragma unroll
       for (int m = 0; m < MT; ++m) { accv[m] = f32x4{0.f, 0.f, 0.f, 0.f}; acct[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1302,10 +1339,13 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         for (int v = 0; v < NVE; ++v)
           wen[v] = (EDGE && ks + 1 < KS) ? Wl[(4 * (KS - 1) + v) * WS + 4 * lc.g + vpos(ks + 1, 0)] : 0.f;
         __builtin_amdgcn_sched_barrier(0);
+        if (live_k(ks, k_out)) {
 #pragma unroll
-        for (int m = 0; m < MTM; ++m) {
-          accv[m] = mfma16(wf[m], zb[ks], accv[m]);
-          acct[m] = mfma16(wf[m], zdb[ks], acct[m]);
+          for (int m = 0; m < MTM; ++m) {
+            if (!live_m(m, m_in)) continue;
+            accv[m] = mfma16(wf[m], zb[ks], accv[m]);
+            acct[m] = mfma16(wf[m], zdb[ks], acct[m]);
+          }
         }
         if (EDGE) {
 #pragma unroll
@@ -1348,7 +1388,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #else
     if (0) {}
 #endif
-    else wgrad_layer<KS0, KS, true, TANH>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1, true STAMP_ARGS);
+    else wgrad_layer<KS0, KS, true, TANH, LY::MERGE>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1, true STAMP_ARGS);
     STAMP(7);
   }
 
