@@ -27,6 +27,9 @@
 //     MFMAs), accumulated in registers over all tiles of the launch and written once as a per-workgroup partial that a
 //     fixed-order sum adds to the gradient (no atomics: same bits every run); the input gradient is the forward loop with
 //     the W^T image, its epilogue forms (zbar, zdbar) of the layer below in registers.  Two barriers per layer.
+//   * nets up to 64 wide have at most four row tiles: waves w and w + 4 then share row tile w, each with the value and the
+//     tangent column tile of one half of the points (SPLIT; +3 %: one wave per SIMD already kept the matrix pipes busy, the
+//     second hides latency);
 //   * widths 129..256: two row-tile passes per wave and layer (LDS matrices of 256 rows); nets whose accumulators do not fit
 //     the registers all at once (5+ layers wider than 96, 7+ wider than 64, widths above 128) run the reverse pass one layer per
 //     launch (vn_wide_lbwd_kernel: accumulators of one layer in registers, the adjoints travel through HBM; up to 128 wide it
@@ -165,14 +168,23 @@ __device__ __forceinline__ Frag frag_issue(const float* __restrict__ img, int wa
 //    iteration -- the prefetch was void).
 //  * The B operand of the next k-step is read while the four MFMAs of the current one issue; the scheduler otherwise
 //    sinks every ds_read to its use to save registers (read, wait, 4 MFMAs, read, ...), hence the group barriers.
-__device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wave, int lane, int nq, const float* B, f32x4 acc[4],
-                                          Frag f) {
+//  * NC = 4: the wave owns all four column tiles of its row tile.  NC = 2 (nets up to 64 wide, whose four row tiles would
+//    leave waves 4..7 idle): waves w and w + 4 share row tile w; wave half `ph` owns the value and the tangent column tile of
+//    points 16 ph .. 16 ph + 15 (columns 4 lm + ph and 4 lm + 2 + ph: two ds_read_b32 instead of one ds_read_b128).
+template <int NC>
+__device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wave, int lane, int nq, const float* B, f32x4 (&acc)[NC],
+                                          Frag f, int ph = 0) {
+  static_assert(NC == 4 || NC == 2, "column tiles per wave");
   const int lm = lane & 15, lk = lane >> 4;
   const f32x4* wp = (const f32x4*)img + (long)wave * nq * 64 + lane;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 ring[4] = {f.w0, f.w1, f.w2, zero4};
-  const float* cb = B + lk * LDW + 4 * lm;
-  f32x4 bv = *(const f32x4*)cb;
+  const float* cb = B + lk * LDW + 4 * lm + (NC == 2 ? ph : 0);
+  auto rdb = [](const float* q) {
+    if constexpr (NC == 4) return *(const f32x4*)q;
+    else return f32x4{q[0], q[2], 0.f, 0.f};
+  };
+  f32x4 bv = rdb(cb);
 #pragma unroll 1
   for (int q0 = 0; q0 < nq; q0 += 4) {
 #pragma unroll
@@ -185,16 +197,16 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wav
         for (int j = 0; j < 4; ++j) {
           cb += 4 * LDW;
           // one row past the last k-step is still inside the matrix or the one behind it (never used)
-          const f32x4 bn = *(const f32x4*)cb;
+          const f32x4 bn = rdb(cb);
           const float av = ring[u][j];
 #if VN_WIDE_ABL == 3
-          acc[j] += av * bv;
+          acc[j % NC] += av * bv;
 #else
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16(av, bv[ct], acc[ct]);
+          for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma16(av, bv[ct], acc[ct]);
 #endif
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // the next step's ds_read first ...
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);     // ... then this step's four MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x100, NC == 4 ? 1 : 2, 0);     // the next step's ds_read(s) first ...
+          __builtin_amdgcn_sched_group_barrier(0x008, NC, 0);                  // ... then this step's MFMAs
           bv = bn;
         }
       }
@@ -204,14 +216,21 @@ __device__ __forceinline__ void wave_gemm(const float* __restrict__ img, int wav
 
 // ---- forward: rows -> (u, ud) [+ stored activations] ----------------------------------------------------------------
 // RP = row-tile passes per layer: wave w owns row tiles w, w + 8, ... (RP = 1: widths <= 128; RP = 2: <= 256)
-template <int RP>
+// SPLIT (nets up to 64 wide, RP = 1): waves w and w + 4 share row tile w, each with the value and tangent column tile of one
+// half of the tile's 32 points (wave_gemm<2>), so all eight waves run the layer GEMMs of a net that has only four row tiles.
+template <int RP, bool SPLIT>
 __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
                                                          const float* __restrict__ wf, VnRows sg, long ntiles,
                                                          float* __restrict__ kept) {
+  static_assert(!SPLIT || RP == 1, "the column split serves nets with at most four row tiles");
+  constexpr int NC = SPLIT ? 2 : 4;          // column tiles per wave
+  constexpr int NH = NC / 2;                 // point halves per wave
   extern __shared__ float lds[];
   // the wave index as a scalar: everything addressed by it (row tile, fragment image, stored-activation block) is then
   // formed on the scalar unit -- the vector unit shares its datapath with the f32 MFMAs
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lm = lane & 15, lk = lane >> 4;
+  const int wrt = SPLIT ? (wave & 3) : wave;     // first row tile of this wave
+  const int ph = SPLIT ? (wave >> 2) : 0;        // SPLIT: which half of the points
   float* buf0 = lds;
   float* buf1 = lds + pl.rows * LDW;
   float* red = buf1 + pl.rows * LDW;         // [8][64]
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
 
   TileIn tin = tile_in_issue(net, sg, (long)blockIdx.x * TP, rows0, tid);
   Frag fr{};
-  if (wave < pl.nrt[1]) fr = frag_issue(wf + pl.wfo[1], wave, lane, pl.nrt[0]);
+  if (wrt < pl.nrt[1]) fr = frag_issue(wf + pl.wfo[1], wrt, lane, pl.nrt[0]);
 
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long r0 = tile * TP;
@@ -233,9 +252,9 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
       const int Hout = net.H[l], act = net.actl[l];
 #pragma unroll
       for (int rp = 0; rp < RP; ++rp) {
-        const int rt = wave + 8 * rp;
+        const int rt = wrt + 8 * rp;
         const bool active = rt < pl.nrt[l];
-        f32x4 acc[4];
+        f32x4 acc[NC];
         float bs[4];
         if (active) {
           const float* bias = theta + net.boff[l];
@@ -245,18 +264,18 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
             bs[i] = m < Hout ? bias[m] : 0.f;
           }
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-          wave_gemm(wf + pl.wfo[l], rt, lane, pl.nrt[l - 1], cur, acc, fr);
+          for (int ct = 0; ct < NC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+          wave_gemm<NC>(wf + pl.wfo[l], rt, lane, pl.nrt[l - 1], cur, acc, fr, ph);
         }
         {   // fragments of the next GEMM this wave runs (its next row tile, the next layer, or layer 1 of the next tile):
             // ahead of the epilogue and the barrier
           const bool same = rp + 1 < RP && rt + 8 < pl.nrt[l];
           const int ln = same ? l : (l < L ? l + 1 : 1);
-          const int rn = same ? rt + 8 : wave;
+          const int rn = same ? rt + 8 : wrt;
           if (rn < pl.nrt[ln]) fr = frag_issue(wf + pl.wfo[ln], rn, lane, pl.nrt[ln - 1]);
         }
         if (active) {
-          f32x4 av[2], adv[2];
+          f32x4 av[NH], adv[NH];
           const ActK ak = act_consts(act);
           // rows past the layer's width (only in its last row tile) must hold zeros, not act(0)
           const bool ragged = 16 * rt + 16 > Hout;
@@ -266,23 +285,30 @@ __global__ __launch_bounds__(NT) void vn_wide_fwd_kernel(VnNet net, Plan pl, con
             const float vm = (!ragged || m < Hout) ? 1.f : 0.f;
             f32x4 o;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NH; ++h) {
 #if VN_WIDE_ABL == 2
               float a = 0.5f + 0.25f * (acc[h][i] + bs[i]);
 #else
               float a = w_act(acc[h][i] + bs[i], ak);
 #endif
-              if (ragged) a *= vm;                       // wave-uniform branch; acc[2 + h] is zero there (zero weights)
-              const float ad = w_d1(a, ak) * acc[2 + h][i];
+              if (ragged) a *= vm;                       // wave-uniform branch; acc[NH + h] is zero there (zero weights)
+              const float ad = w_d1(a, ak) * acc[NH + h][i];
               av[h][i] = a; adv[h][i] = ad;
               o[h] = a; o[2 + h] = ad;
             }
-            *(f32x4*)(nxt + m * LDW + 4 * lm) = o;
+            if constexpr (SPLIT) {
+              nxt[m * LDW + 4 * lm + ph] = o[0];
+              nxt[m * LDW + 4 * lm + 2 + ph] = o[2];
+            } else {
+              *(f32x4*)(nxt + m * LDW + 4 * lm) = o;
+            }
           }
 #if VN_WIDE_ABL != 1
           if (kept != nullptr) {
+            // [column tile][lane] blocks of 16 bytes: value tiles 0, 1, tangent tiles 2, 3 (the same block layout either way)
             f32x4* kp = (f32x4*)(kept + tile * pl.kept_tile + pl.ko[l] + rt * 1024);
-            kp[lane] = av[0]; kp[64 + lane] = av[1]; kp[128 + lane] = adv[0]; kp[192 + lane] = adv[1];
+            if constexpr (SPLIT) { kp[ph * 64 + lane] = av[0]; kp[(2 + ph) * 64 + lane] = adv[0]; }
+            else { kp[lane] = av[0]; kp[64 + lane] = av[1]; kp[128 + lane] = adv[0]; kp[192 + lane] = adv[1]; }
           }
 #endif
         }
@@ -323,12 +349,18 @@ constexpr int BWD_WG_PER_CU = 2;
 #define VN_WIDE_BWD_BOUNDS __launch_bounds__(NT)
 constexpr int BWD_WG_PER_CU = 1;
 #endif
-template <int ML, int BM, int BN>
+// SPLIT (nets up to 64 wide): as in the forward kernel, waves w and w + 4 share row tile w in everything that is per
+// (feature, point) -- the output-layer seeds, the input-gradient GEMMs and their epilogues -- each with one half of the
+// points; the weight-gradient blocks and the bias sums contract over all 64 columns of the LDS matrices and are unchanged.
+template <int ML, int BM, int BN, bool SPLIT>
 __global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const float* __restrict__ theta,
                                                          const float* __restrict__ wf, VnRows sg, long ntiles,
                                                          const float* __restrict__ kept, float* __restrict__ partial) {
+  constexpr int NC = SPLIT ? 2 : 4;          // column tiles per wave: [stream][point half] = NH value tiles, then NH tangent tiles
+  constexpr int NH = NC / 2;
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave0 = tid >> 6, lm0 = lane & 15, lk0 = lane >> 4;
+  const int wrt0 = SPLIT ? (wave0 & 3) : wave0, ph0 = SPLIT ? (wave0 >> 2) : 0;
   float* T = lds;                            // (zbar | zdbar) of the current layer
   float* PV = lds + BROWS * LDW;             // (a | ad) of the layer below (layer 1: the inputs)
   float* sub = PV + BROWS * LDW;             // [TP] ubar
@@ -353,21 +385,23 @@ __global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const 
   float boacc = 0.f;
 
   // stored activations of the last two layers and the seeds of a tile are fetched while the tile before it is processed
-  f32x4 ka[4], kn[4];
+  f32x4 ka[NC], kn[NC];
   float su = 0.f, sd = 0.f;
-  const bool ownL = wave0 < pl.nrt[L];
-  const bool ownL1 = L > 1 && wave0 < pl.nrt[L > 1 ? L - 1 : 0];
+  const bool ownL = wrt0 < pl.nrt[L];
+  const bool ownL1 = L > 1 && wrt0 < pl.nrt[L > 1 ? L - 1 : 0];
+  // stored block of a row tile: [column tile 0..3][lane] x 16 bytes; this wave's tile j is column tile ctile(j)
+  auto ctile = [&](int j, int ph) { return SPLIT ? 2 * j + ph : j; };
   auto fetch_head = [&](long tile) {
     const float* kt = kept + tile * pl.kept_tile;
     if (ownL) {
-      const f32x4* kp = (const f32x4*)(kt + pl.ko[L] + wave0 * 1024);
+      const f32x4* kp = (const f32x4*)(kt + pl.ko[L] + wrt0 * 1024);
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) ka[ct] = kp[ct * 64 + lane];
+      for (int ct = 0; ct < NC; ++ct) ka[ct] = kp[ctile(ct, ph0) * 64 + lane];
     }
     if (ownL1) {
-      const f32x4* kp = (const f32x4*)(kt + pl.ko[L - 1] + wave0 * 1024);
+      const f32x4* kp = (const f32x4*)(kt + pl.ko[L - 1] + wrt0 * 1024);
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) kn[ct] = kp[ct * 64 + lane];
+      for (int ct = 0; ct < NC; ++ct) kn[ct] = kp[ctile(ct, ph0) * 64 + lane];
     }
     if (tid < TP) {
       const long row = tile * TP + tid;
@@ -385,6 +419,7 @@ __global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const 
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
     const int lm = lm0 + oz, lk = lk0 + oz, wave = __builtin_amdgcn_readfirstlane(wave0) + oz, wm = wave >> 1, wn = wave & 1;
+    const int wrt = SPLIT ? (wave & 3) : wave, ph = SPLIT ? (wave >> 2) : 0;      // row tile / point half of this wave
     const long r0 = tile * TP;
     const float* kt = kept + tile * pl.kept_tile;
     TileIn tin{};                                                     // inputs: consumed at layer 1, the end of the tile
@@ -398,22 +433,27 @@ __global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const 
       const float* wo = theta + net.woff[L + 1];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int m = 16 * wave + 4 * lk + i;
+        const int m = 16 * wrt + 4 * lk + i;
         const bool valid = m < HL;
         const float wom = valid ? wo[m] : 0.f;
         f32x4 o;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int p = 16 * h + lm;
+        for (int h = 0; h < NH; ++h) {
+          const int p = 16 * (SPLIT ? ph : h) + lm;
           const float ub = sub[p], udb = sudb[p];
-          const float a = ka[h][i], ad = ka[2 + h][i];
+          const float a = ka[h][i], ad = ka[NH + h][i];
           woacc[i] += ub * a + udb * ad;
           const float ab = ub * wom, adb = udb * wom;
           const float sp = w_d1(a, act);
           o[h] = valid ? ab * sp + w_d2r(a, act) * ad * adb : 0.f;
           o[2 + h] = valid ? adb * sp : 0.f;
         }
-        *(f32x4*)(T + m * LDW + 4 * lm) = o;
+        if constexpr (SPLIT) {
+          T[m * LDW + 4 * lm + ph] = o[0];
+          T[m * LDW + 4 * lm + 2 + ph] = o[2];
+        } else {
+          *(f32x4*)(T + m * LDW + 4 * lm) = o;
+        }
       }
     }
     if (wave == 0 && lane < TP) boacc += sub[lane];
@@ -422,13 +462,18 @@ __global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const 
     for (int l = ML; l >= 1; --l) {
       if (l <= L) {
         const int Hout = net.H[l];
-        const bool own = l > 1 && wave < pl.nrt[l - 1];
+        const bool own = l > 1 && wrt < pl.nrt[l - 1];
         if (l > 1) {
           if (own) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int m = 16 * wave + 4 * lk + i;
-              *(f32x4*)(PV + m * LDW + 4 * lm) = f32x4{kn[0][i], kn[1][i], kn[2][i], kn[3][i]};
+              const int m = 16 * wrt + 4 * lk + i;
+              if constexpr (SPLIT) {
+                PV[m * LDW + 4 * lm + ph] = kn[0][i];
+                PV[m * LDW + 4 * lm + 2 + ph] = kn[1][i];
+              } else {
+                *(f32x4*)(PV + m * LDW + 4 * lm) = f32x4{kn[0][i], kn[1][i], kn[2][i], kn[3][i]};
+              }
             }
           }
         } else {
@@ -441,12 +486,12 @@ __global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const 
         // loads that fly under this layer's work: the W^T fragments of its input-gradient GEMM, the stored activations
         // two layers down (layer 1: the head of the next tile)
         Frag fr{};
-        if (own) fr = frag_issue(wf + pl.wto[l], wave, lane, pl.nrt[l]);
+        if (own) fr = frag_issue(wf + pl.wto[l], wrt, lane, pl.nrt[l]);
         if (l > 2) {
-          if (wave < pl.nrt[l - 2]) {
-            const f32x4* kp = (const f32x4*)(kt + pl.ko[l - 2] + wave * 1024);
+          if (wrt < pl.nrt[l - 2]) {
+            const f32x4* kp = (const f32x4*)(kt + pl.ko[l - 2] + wrt * 1024);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) kn[ct] = kp[ct * 64 + lane];
+            for (int ct = 0; ct < NC; ++ct) kn[ct] = kp[ctile(ct, ph) * 64 + lane];
           }
         } else if (l == 1) {
           if (tile + gridDim.x < ntiles) fetch_head(tile + gridDim.x);
@@ -520,30 +565,38 @@ __global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const 
           }
         }
         // input gradient of the layer: (abar | adbar)_{l-1}[k][col] = sum_n W[k][n] T[n][col]
-        f32x4 acc[4];
+        f32x4 acc[NC];
         if (own) {
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-          wave_gemm(wf + pl.wto[l], wave, lane, pl.nrt[l], T, acc, fr);
+          for (int ct = 0; ct < NC; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+          wave_gemm<NC>(wf + pl.wto[l], wrt, lane, pl.nrt[l], T, acc, fr, ph);
         }
         __syncthreads();      // #2: every wave is done reading T and PV
         if (own) {
           const int Hp = net.H[l - 1], actp = net.actl[l - 1];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int m = 16 * wave + 4 * lk + i;
+            const int m = 16 * wrt + 4 * lk + i;
             const bool valid = m < Hp;
-            const f32x4 pv = *(const f32x4*)(PV + m * LDW + 4 * lm);      // (a | ad) of this lane's positions: rows this wave wrote
+            // (a | ad) of this lane's positions: columns this wave wrote
+            f32x4 pv;
+            if constexpr (SPLIT) pv = f32x4{PV[m * LDW + 4 * lm + ph], 0.f, PV[m * LDW + 4 * lm + 2 + ph], 0.f};
+            else pv = *(const f32x4*)(PV + m * LDW + 4 * lm);
             f32x4 o;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NH; ++h) {
               const float a = pv[h], ad = pv[2 + h];
-              const float ab = acc[h][i], adb = acc[2 + h][i];
+              const float ab = acc[h][i], adb = acc[NH + h][i];
               const float sp = w_d1(a, actp);
               o[h] = valid ? ab * sp + w_d2r(a, actp) * ad * adb : 0.f;
               o[2 + h] = valid ? adb * sp : 0.f;
             }
-            *(f32x4*)(T + m * LDW + 4 * lm) = o;
+            if constexpr (SPLIT) {
+              T[m * LDW + 4 * lm + ph] = o[0];
+              T[m * LDW + 4 * lm + 2 + ph] = o[2];
+            } else {
+              *(f32x4*)(T + m * LDW + 4 * lm) = o;
+            }
           }
         }
       }
@@ -595,12 +648,30 @@ __global__ VN_WIDE_BWD_BOUNDS void vn_wide_bwd_kernel(VnNet net, Plan pl, const 
   }
   {
     const int HL = net.H[L];
+    float wsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float v = woacc[i];
       for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-      const int m = 16 * wave + 4 * lk + i;
-      if (lm == 0 && m < HL) out[net.woff[L + 1] + m] = v;
+      wsum[i] = v;
+    }
+    if constexpr (SPLIT) {
+      // the two waves of a row tile each hold the sum over their half of the points: second half -> LDS -> first half
+      __syncthreads();                       // every wave has left the tile loop: T is free
+      if (ph0 == 1 && lm == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T[(wrt0 * 4 + lk) * 4 + i] = wsum[i];
+      }
+      __syncthreads();
+      if (ph0 == 0 && lm == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wsum[i] += T[(wrt0 * 4 + lk) * 4 + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = 16 * wrt0 + 4 * lk + i;
+      if (ph0 == 0 && lm == 0 && m < HL) out[net.woff[L + 1] + m] = wsum[i];
     }
     if (wave == 0) {
       float v = lane < TP ? boacc : 0.f;
@@ -931,6 +1002,7 @@ struct VnWide {
   // launch, accumulators in registers --  4 / 5: one launch per layer (5+ layers wider than 96, 7+ wider than 64 / widths 129..256)
   int variant = 0;
   int rp = 1;                   // row-tile passes per layer (2: widths 129..256)
+  bool split = false;           // nets up to 64 wide: two waves per row tile, each with half of the points
   int cus = 256;
   size_t lds_f = 0, lds_b = 0;
   float* wf = nullptr;
@@ -974,13 +1046,14 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   pl.wf_floats = off; pl.kept_tile = koff; pl.rows = rows;
   w->rp = hm > 128 ? 2 : 1;
   if (hm > 128) w->variant = 5;
-  else if (hm <= 64) w->variant = net.L <= 4 ? 0 : 2;
+  else if (hm <= 64) w->variant = net.L <= 4 ? 3 : 2;       // at most 4 x 4 tiles per layer: column-split kernels
   else w->variant = net.L <= 4 ? 0 : (net.L <= 6 && hm <= 96) ? 1 : 4;
   {
     // diagnostic: VN_WIDE_SERIAL=1 runs every net up to 128 wide on the layer-serial reverse pass (what it costs, measured)
     const char* sv = getenv("VN_WIDE_SERIAL");
     if (sv && *sv && *sv != '0' && hm <= 128) w->variant = 4;
   }
+  w->split = hm <= 64;
   w->zstride = maxnrt * 1024;
   w->lds_f = ((size_t)2 * rows * LDW + 512) * sizeof(float);
   w->lds_b = ((size_t)2 * BROWS * w->rp * LDW + 2 * TP) * sizeof(float);
@@ -988,10 +1061,12 @@ int vn_wide_create(VnWide** out, const VnNet& net, char* err, size_t errlen) {
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     w->cus = prop.multiProcessorCount;
-  const void* fk = w->rp == 2 ? (const void*)vn_wide_fwd_kernel<2> : (const void*)vn_wide_fwd_kernel<1>;
-  const void* bk = w->variant == 0 ? (const void*)vn_wide_bwd_kernel<4, 2, 4>
-                   : w->variant == 1 ? (const void*)vn_wide_bwd_kernel<6, 2, 3>
-                   : w->variant == 2 ? (const void*)vn_wide_bwd_kernel<16, 1, 2>
+  const void* fk = w->rp == 2 ? (const void*)vn_wide_fwd_kernel<2, false>
+                   : w->split ? (const void*)vn_wide_fwd_kernel<1, true> : (const void*)vn_wide_fwd_kernel<1, false>;
+  const void* bk = w->variant == 0 ? (const void*)vn_wide_bwd_kernel<4, 2, 4, false>
+                   : w->variant == 1 ? (const void*)vn_wide_bwd_kernel<6, 2, 3, false>
+                   : w->variant == 2 ? (const void*)vn_wide_bwd_kernel<16, 1, 2, true>
+                   : w->variant == 3 ? (const void*)vn_wide_bwd_kernel<4, 1, 2, true>
                    : w->variant == 4 ? (const void*)vn_wide_lbwd_kernel<1, 2, 4> : (const void*)vn_wide_lbwd_kernel<2, 4, 8>;
   hipError_t e = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_f);
   if (e == hipSuccess) e = hipFuncSetAttribute(bk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_b);
@@ -1057,10 +1132,13 @@ int vn_wide_forward(VnWide* w, const float* theta, const VnRows& seg, int keep_s
   if (int rc = pack(w, theta, s, err, errlen)) return rc;
   const long grid = ntiles < 2l * w->cus ? ntiles : 2l * w->cus;
   if (w->rp == 2)
-    hipLaunchKernelGGL(vn_wide_fwd_kernel<2>, dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf,
+    hipLaunchKernelGGL((vn_wide_fwd_kernel<2, false>), dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf,
+                       seg, ntiles, kbuf);
+  else if (w->split)
+    hipLaunchKernelGGL((vn_wide_fwd_kernel<1, true>), dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf,
                        seg, ntiles, kbuf);
   else
-    hipLaunchKernelGGL(vn_wide_fwd_kernel<1>, dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf,
+    hipLaunchKernelGGL((vn_wide_fwd_kernel<1, false>), dim3((unsigned)grid), dim3(NT), w->lds_f, s, w->net, w->pl, theta, (const float*)w->wf,
                        seg, ntiles, kbuf);
   WHIP(hipGetLastError());
   if (kbuf) {
@@ -1107,12 +1185,13 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
     }
     return 0;
   }
-#define VN_WIDE_BWD(ML_, BM_, BN_)                                                                                     \
-  hipLaunchKernelGGL((vn_wide_bwd_kernel<ML_, BM_, BN_>), dim3(grid), dim3(NT), w->lds_b, s, w->net, w->pl, theta,         \
+#define VN_WIDE_BWD(ML_, BM_, BN_, SP_)                                                                                \
+  hipLaunchKernelGGL((vn_wide_bwd_kernel<ML_, BM_, BN_, SP_>), dim3(grid), dim3(NT), w->lds_b, s, w->net, w->pl, theta,    \
                      (const float*)w->wf, seg, ntiles, (const float*)k.buf, w->part)
-  if (w->variant == 0) VN_WIDE_BWD(4, 2, 4);
-  else if (w->variant == 1) VN_WIDE_BWD(6, 2, 3);
-  else VN_WIDE_BWD(16, 1, 2);
+  if (w->variant == 0) VN_WIDE_BWD(4, 2, 4, false);
+  else if (w->variant == 1) VN_WIDE_BWD(6, 2, 3, false);
+  else if (w->variant == 3) VN_WIDE_BWD(4, 1, 2, true);
+  else VN_WIDE_BWD(16, 1, 2, true);
 #undef VN_WIDE_BWD
   WHIP(hipGetLastError());
   hipLaunchKernelGGL(vn_wide_sum_kernel, dim3((unsigned)((w->net.P + 63) / 64)), dim3(64 * SUMG), 0, s, (const float*)w->part, grid,
