@@ -176,3 +176,13 @@ bool vn_wide_has_kept(const VnWide* w, int slot, const VnRows& seg);
 // grad[0..P) += d loss / d theta from the rows of seg (needs the activations stored by the forward of the same rows)
 int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* grad, int keep_slot, hipStream_t s, char* err,
                      size_t errlen);
+
+// ---- fp32 GEMMs of the layer-by-layer route (widths beyond the tile kernels): vn_gemm.hip ---------------------------
+// Row-major operands; return value = hipError_t of the launch (0 = ok).
+int vn_gemm_nn(const float* A, const float* W, float* C, long M, int N, int K, hipStream_t s);          // C[M,N] = A[M,K] W[K,N]
+int vn_transpose(const float* W, float* Wt, int K, int N, hipStream_t s);                               // Wt[N,K] = W[K,N]^T
+// parts[g][K1,N] = A_g^T Z_g over the rows g*rows .. min(M,(g+1)*rows) of A[M,K1], Z[M,N]; ceil(M/rows) groups
+long vn_gemm_tn_rows(long M, int K1, int N, int ncu);       // rows per group that fill the chip evenly
+int vn_gemm_tn_parts(const float* A, const float* Z, float* parts, long M, int K1, int N, long rows, hipStream_t s);
+int vn_rowdot(const float* A, const float* w, float* y, long M, int H, float beta, hipStream_t s);      // y = beta y + A w
+

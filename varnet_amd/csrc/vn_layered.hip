@@ -358,13 +358,17 @@ inline unsigned blocks(long n) { return (unsigned)((n + EB - 1) / EB); }
 
 struct VnLayered {
   VnNet net{};
-  rocblas_handle handle = nullptr;
+  rocblas_handle handle = nullptr;  // created at first use: fp64 entry points, or every GEMM under VN_LAYERED_ROCBLAS=1
+  int ncu = 256;
+  bool use_blas = false;            // VN_LAYERED_ROCBLAS=1 (diagnostic): library GEMMs for the fp32 passes instead of vn_gemm.hip
   long sumH = 0;           // sum of H[0..L]
   int hmax_all = 0;        // max of H[0..L]
   // one workspace, carved per call
   void* ws = nullptr;
   size_t ws_bytes = 0;
   float* part = nullptr;   // partial sums of the row reductions
+  float* wt = nullptr;     // W_l^T for the input-gradient product (vn_gemm.hip)
+  size_t wt_elems = 0;
   size_t part_elems = 0;
   // Activations of a whole row set kept from the forward of a gradient evaluation to its reverse pass (slot 0: interior
   // rows, slot 1: BC/IC rows): 288 GB of HBM hold them for every problem size the kernels' route is measured on, and
@@ -414,6 +418,35 @@ int colsum_add(VnLayered* w, const float* A, const float* x, long n, int H, floa
   return 0;
 }
 
+int ensure_wt(VnLayered* w, size_t elems, char* err, size_t errlen) {
+  if (elems <= w->wt_elems) return 0;
+  if (w->wt) (void)hipFree(w->wt);
+  w->wt = nullptr; w->wt_elems = 0;
+  LHIP(hipMalloc((void**)&w->wt, elems * sizeof(float)));
+  w->wt_elems = elems;
+  return 0;
+}
+
+// rocBLAS is needed by the fp64 entry points (and by the fp32 passes only under VN_LAYERED_ROCBLAS=1): loaded and given
+// a handle at first use, so that a net trained in fp32 never loads the library.
+int ensure_blas(VnLayered* w, hipStream_t s, char* err, size_t errlen) {
+  if (!w->handle) {
+    if (int rc = load_blas(err, errlen)) return rc;
+    rocblas_status st = g_blas.create_handle(&w->handle);
+    (void)hipGetLastError();
+    if (st != rocblas_status_success) { w->handle = nullptr; return lfail(err, errlen, "rocblas_create_handle: %s", g_blas.status_to_string(st)); }
+    // no atomics: the weight-gradient GEMMs reduce over millions of rows and must give the same bits on every run
+    (void)g_blas.set_atomics_mode(w->handle, rocblas_atomics_not_allowed);
+  }
+  LBLAS(g_blas.set_stream(w->handle, s));
+  return 0;
+}
+#define LGEMM(expr)                                                                             \
+  do {                                                                                          \
+    int e_ = (expr);                                                                            \
+    if (e_ != 0) return lfail(err, errlen, "%s: %s", #expr, hipGetErrorString((hipError_t)e_)); \
+  } while (0)
+
 // dW (Hin x Hout, row-major) += A^T Zbar over M stacked rows.  The rows are cut into groups; one strided-batched GEMM
 // gives a partial product per group (parallelism = groups x output tiles instead of output tiles), a fixed-order sum
 // adds them up.
@@ -422,19 +455,25 @@ int wgrad_add(VnLayered* w, const float* A, const float* Zbar, long M, int Hin, 
   const long tiles = ((Hin + 127) / 128) * (long)((Hout + 127) / 128);
   long rows = 8192;                                   // rows per group: about 1 000 workgroups for small layers ...
   while (rows < M && tiles * ((M + rows - 1) / rows) > 2048) rows *= 2;   // ... and no more partials than needed for big ones
+  if (!w->use_blas) rows = vn_gemm_tn_rows(M, Hin, Hout, w->ncu);
   const int G = (int)(M / rows);                      // full groups; the ragged rest is one more GEMM
   const long rest = M - (long)G * rows;
   const int np = G + (rest > 0 ? 1 : 0);
   const long len = (long)Hin * Hout;
   if (int rc = ensure_part(w, (size_t)np * len, err, errlen)) return rc;
-  const float one = 1.f, zero = 0.f;
-  // column-major: P_g'(Hout x Hin) = Zbar_g'(Hout x rows) A_g'(Hin x rows)^T
-  if (G > 0)
-    LBLAS(g_blas.sgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rows, &one,
-                                       Zbar, Hout, rows * Hout, A, Hin, rows * Hin, &zero, w->part, Hout, len, G));
-  if (rest > 0)
-    LBLAS(g_blas.sgemm(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rest, &one,
-                       Zbar + (long)G * rows * Hout, Hout, A + (long)G * rows * Hin, Hin, &zero, w->part + (long)G * len, Hout));
+  if (!w->use_blas) {
+    LGEMM(vn_gemm_tn_parts(A, Zbar, w->part, M, Hin, Hout, rows, s));          // np partial products, one launch
+  } else {
+    if (int rc = ensure_blas(w, s, err, errlen)) return rc;
+    const float one = 1.f, zero = 0.f;
+    // column-major: P_g'(Hout x Hin) = Zbar_g'(Hout x rows) A_g'(Hin x rows)^T
+    if (G > 0)
+      LBLAS(g_blas.sgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rows, &one,
+                                         Zbar, Hout, rows * Hout, A, Hin, rows * Hin, &zero, w->part, Hout, len, G));
+    if (rest > 0)
+      LBLAS(g_blas.sgemm(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rest, &one,
+                         Zbar + (long)G * rows * Hout, Hout, A + (long)G * rows * Hin, Hin, &zero, w->part + (long)G * len, Hout));
+  }
   hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((len + 63) / 64)), dim3(64 * SUMG), 0, s, w->part, np, len, dW);
   LHIP(hipGetLastError());
   return 0;
@@ -447,36 +486,59 @@ long chunk_rows(long n, long per_row) {
   if (c < 1024) c = 1024;
   // the stacked GEMMs take S*c rows in a 32-bit rocblas_int
   if (c > (1l << 26)) c = 1l << 26;
-  return c < n ? c : n;
+  return c < n ? (c & ~3l) : n;             // several chunks: a multiple of 4 rows, so that every chunk's matrices stay 16-byte aligned
 }
 
-// Z(S n x Hout) = A(S n x Hin) W(Hin x Hout), all row-major  ==  column-major  Z'(Hout x M) = W'(Hout x Hin) A'(Hin x M)
+// Z(M x Hout) = A(M x Hin) W(Hin x Hout), all row-major (fp32: vn_gemm.hip; fp64, or VN_LAYERED_ROCBLAS=1: the library, where
+// it is the column-major product  Z'(Hout x M) = W'(Hout x Hin) A'(Hin x M))
 template <typename T>
-rocblas_status gemm_fwd(rocblas_handle h, long M, int Hin, int Hout, const T* A, const T* W, T* Z) {
+int gemm_fwd(VnLayered* w, long M, int Hin, int Hout, const T* A, const T* W, T* Z, hipStream_t s, char* err, size_t errlen) {
+  if constexpr (sizeof(T) == 4) {
+    if (!w->use_blas) {
+      LGEMM(vn_gemm_nn(A, W, Z, M, Hout, Hin, s));
+      return 0;
+    }
+  }
+  if (int rc = ensure_blas(w, s, err, errlen)) return rc;
   const T one = T(1), zero = T(0);
-  return BlasT<T>::gemm(h, rocblas_operation_none, rocblas_operation_none, Hout, (int)M, Hin, &one, W, Hout, A, Hin, &zero, Z, Hout);
+  LBLAS(BlasT<T>::gemm(w->handle, rocblas_operation_none, rocblas_operation_none, Hout, (int)M, Hin, &one, W, Hout, A, Hin, &zero, Z, Hout));
+  return 0;
+}
+// y(M) = beta y + A(M x H) w
+template <typename T>
+int gemv_rows(VnLayered* w, long M, int H, const T* A, const T* x, T beta, T* y, hipStream_t s, char* err, size_t errlen) {
+  if constexpr (sizeof(T) == 4) {
+    if (!w->use_blas) {
+      LGEMM(vn_rowdot(A, x, y, M, H, beta, s));
+      return 0;
+    }
+  }
+  if (int rc = ensure_blas(w, s, err, errlen)) return rc;
+  const T one = T(1);
+  LBLAS(BlasT<T>::gemv(w->handle, rocblas_operation_transpose, H, (int)M, &one, A, H, x, &beta, y));
+  return 0;
 }
 
 }  // namespace
 
 int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errlen) {
   *out = nullptr;
-  if (int rc = load_blas(err, errlen)) return rc;
   VnLayered* w = new VnLayered();
   w->net = net;
+  const char* ub = getenv("VN_LAYERED_ROCBLAS");
+  w->use_blas = ub && *ub && *ub != '0';
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      w->ncu = prop.multiProcessorCount;
+  }
   const char* nk = getenv("VN_LAYERED_NOKEEP");
   w->never_keep = nk && *nk && *nk != '0';
   for (int l = 0; l <= net.L; ++l) {
     w->sumH += net.H[l];
     if (net.H[l] > w->hmax_all) w->hmax_all = net.H[l];
   }
-  rocblas_status st = g_blas.create_handle(&w->handle);
-  if (st != rocblas_status_success) {
-    delete w;
-    return lfail(err, errlen, "rocblas_create_handle: %s", g_blas.status_to_string(st));
-  }
-  // no atomics: the weight-gradient GEMMs reduce over millions of rows and must give the same bits on every run
-  (void)g_blas.set_atomics_mode(w->handle, rocblas_atomics_not_allowed);
   if (vn_wide_supported(net)) {
     if (int rc = vn_wide_create(&w->wide, net, err, errlen)) {
       vn_layered_destroy(w);
@@ -490,7 +552,8 @@ int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errle
 void vn_layered_destroy(VnLayered* w) {
   if (!w) return;
   vn_wide_destroy(w->wide);
-  if (w->handle) (void)g_blas.destroy_handle(w->handle);
+  if (w->wt) (void)hipFree(w->wt);
+  if (w->handle) (void)g_blas.destroy_handle(w->handle);      // (a handle exists only if the library was loaded)
   if (w->ws) (void)hipFree(w->ws);
   if (w->part) (void)hipFree(w->part);
   for (auto& k : w->kept) if (k.buf) (void)hipFree(k.buf);
@@ -506,7 +569,7 @@ int chunk_forward(VnLayered* w, const float* theta, const float* X, const float*
   hipLaunchKernelGGL(k_pack_train, dim3(blocks(c * net.d_in)), dim3(EB), 0, s, X, G, c, net.d_in, net.dim, S, act[0]);
   LHIP(hipGetLastError());
   for (int l = 1; l <= net.L; ++l) {
-    LBLAS(gemm_fwd<float>(w->handle, (long)S * c, net.H[l - 1], net.H[l], act[l - 1], theta + net.woff[l], act[l]));
+    if (int rc = gemm_fwd<float>(w, (long)S * c, net.H[l - 1], net.H[l], act[l - 1], theta + net.woff[l], act[l], s, err, errlen)) return rc;
     hipLaunchKernelGGL(k_act_train, dim3(blocks(c * net.H[l])), dim3(EB), 0, s, act[l], theta + net.boff[l], c, net.H[l], S, net.actl[l]);
     LHIP(hipGetLastError());
   }
@@ -519,7 +582,7 @@ long carve_act(const VnLayered* w, float* base, long c, int S, float** act) {
   long used = 0;
   for (int l = 0; l <= net.L; ++l) {
     act[l] = base ? base + used : nullptr;
-    used += (long)S * c * net.H[l];
+    used = (used + (long)S * c * net.H[l] + 3) & ~3l;      // every matrix starts on a 16-byte boundary (vn_gemm.hip: b128 loads)
   }
   return used;
 }
@@ -529,7 +592,7 @@ long carve(VnLayered* w, long c, int S, bool train, float** act, float** adj, bo
   if (train) {
     for (int i = 0; i < 2; ++i) {
       adj[i] = p ? p + used : nullptr;
-      used += (long)S * c * w->hmax_all;
+      used = (used + (long)S * c * w->hmax_all + 3) & ~3l;
     }
   }
   return used;
@@ -539,7 +602,8 @@ long carve(VnLayered* w, long c, int S, bool train, float** act, float** adj, bo
 bool kept_reserve(VnLayered* w, int slot, long n, long c, int S) {
   if (w->never_keep) return false;
   VnLayered::Kept& k = w->kept[slot];
-  const size_t need = (size_t)((n + c - 1) / c) * (size_t)S * c * w->sumH;
+  // (chunks of c rows, c a multiple of 4 when there is more than one; + the 16-byte rounding of a ragged last chunk's matrices)
+  const size_t need = (size_t)((n + c - 1) / c) * (size_t)S * c * w->sumH + 4 * (VN_MAX_LAYERS + 2);
   if (need > k.cap) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
@@ -561,7 +625,6 @@ int vn_layered_forward(VnLayered* w, const float* theta, const VnRows& seg, hipS
   if (w->wide) return vn_wide_forward(w->wide, theta, seg, keep_slot, !w->never_keep, s, err, errlen);
   const VnNet& net = w->net;
   const int S = (seg.G && seg.ud) ? 2 : 1;
-  LBLAS(g_blas.set_stream(w->handle, s));
   // with keep_slot >= 0 the chunking is the reverse pass's, and the activations go to the slot instead of the workspace
   long c = chunk_rows<float>(seg.n, (long)S * w->sumH);
   bool keep = false;
@@ -609,7 +672,6 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
   if (w->wide && vn_wide_has_kept(w->wide, keep_slot, seg)) return vn_wide_backward(w->wide, theta, seg, grad, keep_slot, s, err, errlen);
   const VnNet& net = w->net;
   const int S = (seg.G && seg.udbar) ? 2 : 1;
-  LBLAS(g_blas.set_stream(w->handle, s));
   const long per_row = (long)S * w->sumH + 2l * S * w->hmax_all;
   long c = chunk_rows<float>(seg.n, per_row);
   // activations kept by the forward of this gradient evaluation (same rows, same stacking): no recompute
@@ -654,8 +716,16 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
       LTRACE(s, "bwd layer %d colsum + wgrad done", l);
       if (l > 1) {
         // [abar; adbar]_{l-1} (M x Hin) = Zbar (M x Hout) W_l^T  ==  column-major (Hin x M) = W'(Hout x Hin)^T Zbar'(Hout x M)
-        LBLAS(BlasT<float>::gemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, Hin, (int)M, Hout, &one,
-                                 theta + net.woff[l], Hout, cur, Hout, &zero, nxt, Hin));
+        if (!w->use_blas) {
+          // dA = Zb W^T as a plain product with the transposed weights (a few hundred KB, rewritten per call)
+          if (int rc = ensure_wt(w, (size_t)Hin * Hout, err, errlen)) return rc;
+          LGEMM(vn_transpose(theta + net.woff[l], w->wt, Hin, Hout, s));
+          LGEMM(vn_gemm_nn(cur, w->wt, nxt, M, Hin, Hout, s));
+        } else {
+          if (int rc = ensure_blas(w, s, err, errlen)) return rc;
+          LBLAS(BlasT<float>::gemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, Hin, (int)M, Hout, &one,
+                                   theta + net.woff[l], Hout, cur, Hout, &zero, nxt, Hin));
+        }
         float* t = cur; cur = nxt; nxt = t;
       }
     }
@@ -670,7 +740,6 @@ int pointwise_streams(VnLayered* w, const T* theta, const T* X, long n, int S, i
                       const T* src, const T* ddx, int td, T* u, T* res, hipStream_t s, char* err, size_t errlen) {
   if (n <= 0) return 0;
   const VnNet& net = w->net;
-  LBLAS(g_blas.set_stream(w->handle, s));
   // two ping-pong buffers of S x c x hmax and the S x c output vector
   const long per_row = 2l * S * w->hmax_all + S;
   const long c = chunk_rows<T>(n, per_row);
@@ -690,7 +759,7 @@ int pointwise_streams(VnLayered* w, const T* theta, const T* X, long n, int S, i
     }
     for (int l = 1; l <= net.L; ++l) {
       const T* in = (l == 1 && !res) ? X + r0 * net.d_in : cur;
-      LBLAS(gemm_fwd<T>(w->handle, (long)S * cn, net.H[l - 1], net.H[l], in, theta + net.woff[l], nxt));
+      if (int rc = gemm_fwd<T>(w, (long)S * cn, net.H[l - 1], net.H[l], in, theta + net.woff[l], nxt, s, err, errlen)) return rc;
       hipLaunchKernelGGL(k_act_res<T>, dim3(blocks(cn * net.H[l])), dim3(EB), 0, s, nxt, theta + net.boff[l], cn, net.H[l],
                          res ? nd1 : 0, res ? dim : 0, net.actl[l]);
       LHIP(hipGetLastError());
@@ -699,9 +768,9 @@ int pointwise_streams(VnLayered* w, const T* theta, const T* X, long n, int S, i
     if (!res) {
       hipLaunchKernelGGL(k_fill_from<T>, dim3(blocks(cn)), dim3(EB), 0, s, u + r0, cn, theta + net.boff[net.L + 1]);
       LHIP(hipGetLastError());
-      LBLAS(BlasT<T>::gemv(w->handle, rocblas_operation_transpose, HL, (int)cn, &one, cur, HL, theta + net.woff[net.L + 1], &one, u + r0));
+      if (int rc = gemv_rows<T>(w, cn, HL, cur, theta + net.woff[net.L + 1], one, u + r0, s, err, errlen)) return rc;
     } else {
-      LBLAS(BlasT<T>::gemv(w->handle, rocblas_operation_transpose, HL, (int)(S * cn), &one, cur, HL, theta + net.woff[net.L + 1], &zero, y));
+      if (int rc = gemv_rows<T>(w, (long)S * cn, HL, cur, theta + net.woff[net.L + 1], zero, y, s, err, errlen)) return rc;
       hipLaunchKernelGGL(k_res_combine<T>, dim3(blocks(cn)), dim3(EB), 0, s, y, theta + net.boff[net.L + 1], diff + r0,
                          vel + r0 * dim, src ? src + r0 : nullptr, ddx ? ddx + r0 * dim : nullptr, td, cn, dim, nd1,
                          u ? u + r0 : nullptr, res + r0);
