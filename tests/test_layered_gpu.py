@@ -158,6 +158,44 @@ def test_layered_chunks_and_shard_additivity(widths, keep, monkeypatch):
     setattr(test_layered_chunks_and_shard_additivity, key, g)
 
 
+@pytest.mark.parametrize('widths', [[272, 260], [300, 262, 257], [512, 384]], ids=['x4-widths', 'odd-widths', 'tile-multiples'])
+def test_hand_written_gemms_against_the_library_form(widths, monkeypatch):
+    """Widths above 256 run their fp32 passes on the MFMA GEMMs of vn_gemm.hip (128 x 128 / 128 x 256 tiles, thin input-layer
+    kernels, forward epilogue fused).  VN_LAYERED_ROCBLAS=1 keeps the same route on library GEMMs with the separate
+    elementwise kernels: two implementations of every product (vectorised and element-wise load paths, ragged tiles in all three
+    dimensions, several chunks) must agree to fp32 rounding, and the hand-written form must be run-to-run reproducible."""
+    d_in, dim, integNum, n_k, nB, bDof = 3, 2, 64, 3001, 1501, 700
+    d = synth(9, d_in, dim, widths, integNum, n_k, nB, bDof)
+    from varnet_amd.engine import VNEngine
+    out = []
+    for lib in (False, True):
+        if lib:
+            monkeypatch.setenv('VN_LAYERED_ROCBLAS', '1')
+        else:
+            monkeypatch.delenv('VN_LAYERED_ROCBLAS', raising=False)
+        eng = VNEngine(dim, d_in, widths, True, integNum, kernel=0)
+        assert eng.kernel_path()[0] == LAYERED
+        eng.init_params(seed=4)
+        eng.set_fe_table(d['N1'], d['dNt1'], None)
+        eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=n_k, detJ=d['detJ'])
+        eng.set_bic(d['biInput'], d['biLabel'], bDof, 2.0)
+        eng.set_weights(d['w'])
+        gb = eng.bind_grad_buffer()
+        eng.grad(0)
+        torch.cuda.synchronize()
+        g = gb.cpu().numpy().astype(np.float64)
+        eng.grad(0)
+        torch.cuda.synchronize()
+        assert np.array_equal(gb.cpu().numpy().astype(np.float64), g)
+        u = eng.forward(d['Input'][:4099]).cpu().numpy()
+        out.append((g, u))
+        eng.close()
+    (g0, u0), (g1, u1) = out
+    assert np.max(np.abs(g0[:-4] - g1[:-4])) <= 3e-5 * np.max(np.abs(g1[:-4]))
+    assert abs(g0[-4] - g1[-4]) <= 1e-5 * abs(g1[-4])
+    assert np.max(np.abs(u0 - u1)) <= 2e-6 * max(1.0, np.max(np.abs(u1)))
+
+
 @pytest.mark.parametrize('widths,d_in,dim', [([100, 80], 3, 2), ([20] * 9, 2, 1), ([40, 40], 10, 3)])
 def test_forward_and_residual_parity_layered(widths, d_in, dim):
     rng = np.random.default_rng(0)

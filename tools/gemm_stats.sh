@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/gs_mine gpurun_out/gs_blas
-rocprofv3 --kernel-trace --stats -d gpurun_out/gs_mine -o s --output-format csv -- python3 tools/layered_perf.py "300,300,300" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/gs_mine -o s --output-format csv -- python3 tools/layered_perf.py "${NET:-300,300,300}" > /dev/null 2>&1
 export VN_LAYERED_ROCBLAS=1
-rocprofv3 --kernel-trace --stats -d gpurun_out/gs_blas -o s --output-format csv -- python3 tools/layered_perf.py "300,300,300" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/gs_blas -o s --output-format csv -- python3 tools/layered_perf.py "${NET:-300,300,300}" > /dev/null 2>&1
 for d in mine blas; do echo "== $d"; f=$(find gpurun_out/gs_$d -name "*kernel_stats.csv" | head -1); python3 - $f <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))

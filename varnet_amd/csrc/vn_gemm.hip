@@ -302,6 +302,204 @@ __global__ __launch_bounds__(128 * WC, 4) void vn_gemm_tn_kernel(const float* __
   else gemm_tn_loop<WC, VEC, true>(A, Z, out, K1, N, r0, r1, k0, n0, wm, wn, in, jn, sA, sZ, t, lm, lk);
 }
 
+// ---- forward product with the layer's epilogue fused: a = act(z + b), ad = act'(z) zd -------------------------------------
+// A and C are the stacked matrices of a chunk, [S][c][*]: stream 0 = values, stream 1 = tangents of the same c points.  With
+// S = 2 (PAIRED) a workgroup's 128 tile rows are 64 points' value rows (wave row 0) and the same points' tangent rows (wave
+// row 1), so act'(z) of a point and its zd are in two waves of one workgroup: the value waves hand s1 = act'(z) over through
+// LDS (the operand buffers are free after the K loop), 32 columns per pass.  Saves one read and one write of the M x N
+// matrix per layer (the elementwise kernel this replaces ran at the HBM roofline).
+__device__ __forceinline__ float gact_f(float z, int act) { return act == VN_ACT_TANH ? tanhf(z) : 1.0f / (1.0f + expf(-z)); }
+__device__ __forceinline__ float gact_s1(float a, int act) { return act == VN_ACT_TANH ? 1.f - a * a : a * (1.f - a); }
+
+// tile row tr of a PAIRED workgroup -> row of the stacked matrix; pt = the point
+template <bool VEC, int NTHR, bool PAIRED>
+__device__ __forceinline__ Stage<512 / NTHR> load_rowk_st(const float* __restrict__ P, long ld, long p0, long c, int k0, int K, int t) {
+  Stage<512 / NTHR> s;
+#pragma unroll
+  for (int e = 0; e < 512 / NTHR; ++e) {
+    const int idx = t + e * NTHR;
+    const int tr = idx >> 2;
+    const long pt = PAIRED ? p0 + (tr & 63) : p0 + tr;
+    const long row = PAIRED ? (tr < 64 ? pt : c + pt) : pt;
+    const int kq = k0 + (idx & 3) * 4;
+    const float* p = P + row * ld + kq;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (pt < c) {
+      if constexpr (VEC) {
+        if (kq < K) v = *(const f32x4*)p;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (kq + q < K) v[q] = p[q];
+      }
+    }
+    s.v[e] = v;
+  }
+  return s;
+}
+
+template <int WC, bool VEC, bool PAIRED, bool EDGE>
+__device__ __forceinline__ void gemm_st_loop(const float* __restrict__ A, const float* __restrict__ B, long c, int N, int K, long p0,
+                                             int n0, int wm, int wn, int in, int jn, float* sA0, float* sB0, int t, int lm, int lk,
+                                             f32x4 (&acc)[4][4]) {
+  using G = Geo<WC>;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nk = (K + BK - 1) / BK;
+  auto ga = load_rowk_st<VEC, G::NTHR, PAIRED>(A, K, p0, c, 0, K, t);
+  auto gb = load_kcol<VEC, G::NTHR, G::BN>(B, N, 0, K, n0, N, t);
+  store_rowk<G::NTHR>(sA0, ga, t);
+  store_kcol<G::NTHR, G::BN>(sB0, gb, t);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const int k1 = (kt + 1) * BK;
+      ga = load_rowk_st<VEC, G::NTHR, PAIRED>(A, K, p0, c, k1, K, t);
+      gb = load_kcol<VEC, G::NTHR, G::BN>(B, N, k1, K, n0, N, t);
+    }
+    if (!EDGE || (in > 0 && jn > 0)) {
+      f32x4 fa[4], fb[4];
+      frag_rowk(sA0 + cur * ROWK_SZ, 64 * wm, lm, lk, fa);
+      frag_kcol<G::LDN>(sB0 + cur * G::KCOLN_SZ, 64 * wn, lm, lk, fb);
+      if (EDGE) mma_step_edge(fa, fb, acc, in, jn); else mma_step(fa, fb, acc);
+    }
+    if (kt + 1 < nk) {
+      store_rowk<G::NTHR>(sA0 + (cur ^ 1) * ROWK_SZ, ga, t);
+      store_kcol<G::NTHR, G::BN>(sB0 + (cur ^ 1) * G::KCOLN_SZ, gb, t);
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int XLD = 36;      // exchange buffer: [64 rows][32 columns + 4] per wave pair
+
+// (the 256-thread geometry carries two staged 16-byte pieces per operand and thread: at the 128-register cap its K loop
+// spills once the epilogue's operands are live across it, so it is compiled for three waves per SIMD)
+template <int WC> struct FusedOcc { static constexpr int W = WC == 2 ? 3 : 4; };
+template <int WC, bool VEC, bool PAIRED>
+__global__ __launch_bounds__(128 * WC, FusedOcc<WC>::W) void vn_gemm_fwd_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                                  const float* __restrict__ bias, float* __restrict__ C, long c, int N,
+                                                                  int K, int act, int ntn) {
+  using G = Geo<WC>;
+  __shared__ __attribute__((aligned(16))) float smem[2 * ROWK_SZ + 2 * G::KCOLN_SZ];
+  static_assert(WC * 64 * XLD <= 2 * ROWK_SZ + 2 * G::KCOLN_SZ, "exchange buffer fits the operand buffers");
+  float* sA0 = smem;
+  float* sB0 = smem + 2 * ROWK_SZ;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), lm = lane & 15, lk = lane >> 4;
+  const long bid = blockIdx.x;
+  const int quad = (wave + (int)(bid % (2 * WC))) % (2 * WC);
+  const int wm = quad / WC, wn = quad % WC;
+  const long p0 = (bid / ntn) * (PAIRED ? 64 : BM);           // first point of this workgroup
+  const int n0 = (int)(bid % ntn) * G::BN;
+  const long q0 = PAIRED ? p0 : p0 + 64 * wm;                  // first point of this wave's quadrant
+  const int in = live_tiles(q0, c), jn = live_tiles(n0 + 64 * wn, N);
+  f32x4 acc[4][4];
+  if (in == 4 && jn == 4) gemm_st_loop<WC, VEC, PAIRED, false>(A, W, c, N, K, p0, n0, wm, wn, in, jn, sA0, sB0, t, lm, lk, acc);
+  else gemm_st_loop<WC, VEC, PAIRED, true>(A, W, c, N, K, p0, n0, wm, wn, in, jn, sA0, sB0, t, lm, lk, acc);
+  // epilogue
+  float bs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + 64 * wn + 16 * j + lm;
+    bs[j] = col < N ? bias[col] : 0.f;
+  }
+  if constexpr (!PAIRED) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long pt = q0 + 16 * i + 4 * lk + e;
+        if (pt < c) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int col = n0 + 64 * wn + 16 * j + lm;
+            if (col < N) C[pt * N + col] = gact_f(acc[i][j][e] + bs[j], act);
+          }
+        }
+      }
+    }
+  } else {
+    float* X = smem + wn * (64 * XLD);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (wm == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = 16 * i + 4 * lk + e;
+            const long pt = q0 + row;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const int j = 2 * pass + jj;
+              const int col = n0 + 64 * wn + 16 * j + lm;
+              const float a = gact_f(acc[i][j][e] + bs[j], act);
+              X[row * XLD + 16 * jj + lm] = gact_s1(a, act);
+              if (pt < c && col < N) C[pt * N + col] = a;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (wm == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = 16 * i + 4 * lk + e;
+            const long pt = q0 + row;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const int j = 2 * pass + jj;
+              const int col = n0 + 64 * wn + 16 * j + lm;
+              if (pt < c && col < N) C[(c + pt) * N + col] = X[row * XLD + 16 * jj + lm] * acc[i][j][e];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// the input layer (K = d_in <= 32) with the same epilogue: a thread forms 4 (VEC) or 1 outputs of a point, both streams
+template <bool VEC>
+__global__ __launch_bounds__(256) void vn_gemm_fwd_thin_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ C, long c, int S,
+                                                              int N, int K, int act) {
+  constexpr int V = VEC ? 4 : 1;
+  const int nq = (N + V - 1) / V;
+  const long total = c * nq;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / nq;
+    const int n = (int)(idx - r * nq) * V;
+    const float* a = A + r * K;
+    const float* ad = A + (c + r) * K;
+    float z[V], zd[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) { z[v] = bias[n + v]; zd[v] = 0.f; }
+    for (int k = 0; k < K; ++k) {
+      const float av = a[k], adv = S == 2 ? ad[k] : 0.f;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float w = W[(long)k * N + n + v];
+        z[v] += av * w;
+        zd[v] += adv * w;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const float av = gact_f(z[v], act);
+      C[r * N + n + v] = av;
+      if (S == 2) C[(c + r) * N + n + v] = gact_s1(av, act) * zd[v];
+    }
+  }
+}
+
 // Wt[N x K] = W[K x N]^T (the input-gradient product runs as  dA = Zb (W^T)  on the kernel above; W is a few hundred KB)
 __global__ __launch_bounds__(256) void vn_transpose_kernel(const float* __restrict__ W, float* __restrict__ Wt, int K, int N) {
   __shared__ float tile[32][33];
@@ -422,6 +620,35 @@ int vn_gemm_nn(const float* A, const float* W, float* C, long M, int N, int K, h
   if (wc == 4) { if (vec) VN_LAUNCH_NN(4, true); else VN_LAUNCH_NN(4, false); }
   else         { if (vec) VN_LAUNCH_NN(2, true); else VN_LAUNCH_NN(2, false); }
 #undef VN_LAUNCH_NN
+  return (int)hipGetLastError();
+}
+
+// C[S][c][N] = epilogue(A[S][c][K] W[K x N] + b): a = act(z + b) in stream 0, ad = act'(z) zd in stream 1 (S = 2)
+int vn_gemm_fwd(const float* A, const float* W, const float* bias, float* C, long c, int S, int N, int K, int act, hipStream_t s) {
+  if (c <= 0 || N <= 0 || K <= 0) return 0;
+  if (K <= 32) {
+    const bool v4 = (N % 4 == 0);
+    const long total = c * (v4 ? N / 4 : N);
+    long nbt = (total + 255) / 256;
+    if (nbt > 256 * 64) nbt = 256 * 64;
+    if (v4) hipLaunchKernelGGL(vn_gemm_fwd_thin_kernel<true>, dim3((unsigned)nbt), dim3(256), 0, s, A, W, bias, C, c, S, N, K, act);
+    else hipLaunchKernelGGL(vn_gemm_fwd_thin_kernel<false>, dim3((unsigned)nbt), dim3(256), 0, s, A, W, bias, C, c, S, N, K, act);
+    return (int)hipGetLastError();
+  }
+  const int wc = wave_cols(N);
+  const int bn = 64 * wc;
+  const int ntn = (N + bn - 1) / bn;
+  const long nb = ((c + (S == 2 ? 63 : BM - 1)) / (S == 2 ? 64 : BM)) * ntn;
+  const bool vec = (K % 4 == 0) && (N % 4 == 0) && aligned16(A) && aligned16(W) && (S == 1 || (c * (long)K) % 4 == 0);
+#define VN_LAUNCH_FW(WC_, VEC_, P_) hipLaunchKernelGGL((vn_gemm_fwd_kernel<WC_, VEC_, P_>), dim3((unsigned)nb), dim3(128 * WC_), 0, s, A, W, bias, C, c, N, K, act, ntn)
+  if (S == 2) {
+    if (wc == 4) { if (vec) VN_LAUNCH_FW(4, true, true); else VN_LAUNCH_FW(4, false, true); }
+    else         { if (vec) VN_LAUNCH_FW(2, true, true); else VN_LAUNCH_FW(2, false, true); }
+  } else {
+    if (wc == 4) { if (vec) VN_LAUNCH_FW(4, true, false); else VN_LAUNCH_FW(4, false, false); }
+    else         { if (vec) VN_LAUNCH_FW(2, true, false); else VN_LAUNCH_FW(2, false, false); }
+  }
+#undef VN_LAUNCH_FW
   return (int)hipGetLastError();
 }
 

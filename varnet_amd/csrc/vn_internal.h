@@ -180,6 +180,8 @@ int vn_wide_backward(VnWide* w, const float* theta, const VnRows& seg, float* gr
 // ---- fp32 GEMMs of the layer-by-layer route (widths beyond the tile kernels): vn_gemm.hip ---------------------------
 // Row-major operands; return value = hipError_t of the launch (0 = ok).
 int vn_gemm_nn(const float* A, const float* W, float* C, long M, int N, int K, hipStream_t s);          // C[M,N] = A[M,K] W[K,N]
+// stacked forward with the layer epilogue: C[S][c][N] = (act(A0 W + b) | act'(.) (A1 W)), A = [S][c][K]
+int vn_gemm_fwd(const float* A, const float* W, const float* bias, float* C, long c, int S, int N, int K, int act, hipStream_t s);
 int vn_transpose(const float* W, float* Wt, int K, int N, hipStream_t s);                               // Wt[N,K] = W[K,N]^T
 // parts[g][K1,N] = A_g^T Z_g over the rows g*rows .. min(M,(g+1)*rows) of A[M,K1], Z[M,N]; ceil(M/rows) groups
 long vn_gemm_tn_rows(long M, int K1, int N, int ncu);       // rows per group that fill the chip evenly

@@ -569,6 +569,11 @@ int chunk_forward(VnLayered* w, const float* theta, const float* X, const float*
   hipLaunchKernelGGL(k_pack_train, dim3(blocks(c * net.d_in)), dim3(EB), 0, s, X, G, c, net.d_in, net.dim, S, act[0]);
   LHIP(hipGetLastError());
   for (int l = 1; l <= net.L; ++l) {
+    if (!w->use_blas) {
+      // product and layer epilogue in one kernel (vn_gemm.hip)
+      LGEMM(vn_gemm_fwd(act[l - 1], theta + net.woff[l], theta + net.boff[l], act[l], c, S, net.H[l], net.H[l - 1], net.actl[l], s));
+      continue;
+    }
     if (int rc = gemm_fwd<float>(w, (long)S * c, net.H[l - 1], net.H[l], act[l - 1], theta + net.woff[l], act[l], s, err, errlen)) return rc;
     hipLaunchKernelGGL(k_act_train, dim3(blocks(c * net.H[l])), dim3(EB), 0, s, act[l], theta + net.boff[l], c, net.H[l], S, net.actl[l]);
     LHIP(hipGetLastError());
@@ -721,6 +726,9 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
           if (int rc = ensure_wt(w, (size_t)Hin * Hout, err, errlen)) return rc;
           LGEMM(vn_transpose(theta + net.woff[l], w->wt, Hin, Hout, s));
           LGEMM(vn_gemm_nn(cur, w->wt, nxt, M, Hin, Hout, s));
+          // (the reverse epilogue of layer l-1 fused into this product was built and measured: its loads of the stored
+          // (a | ad) in accumulator order cost what k_act_bwd costs -- 512,512: 2 128 us against 1 500 + 425 -- so it stays
+          // a separate, HBM-bound elementwise kernel)
         } else {
           if (int rc = ensure_blas(w, s, err, errlen)) return rc;
           LBLAS(BlasT<float>::gemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, Hin, (int)M, Hout, &one,
