@@ -537,35 +537,53 @@ __global__ __launch_bounds__(256) void vn_gemm_nn_thin_kernel(const float* __res
     }
   }
 }
-// parts[g][K1 x N] = A_g^T Z_g, K1 <= 32: a workgroup takes the rows of group g for 64 columns; 4 row lanes x 64 column lanes,
-// eight rows of A^T per pass in registers, the row lanes meet in LDS in a fixed order
+// parts[g][K1 x N] = A_g^T Z_g, K1 <= 32: a workgroup takes the rows of group g for 64 V columns (V = 4: 16-byte loads of Z);
+// 4 row lanes x 64 column lanes, eight rows of A^T per pass in registers, the row lanes meet in LDS in a fixed order
+template <int V>
 __global__ __launch_bounds__(256) void vn_gemm_tn_thin_kernel(const float* __restrict__ A, const float* __restrict__ Z,
                                                              float* __restrict__ parts, long M, int K1, int N, long rows) {
-  __shared__ float red[4][8][64];
+  __shared__ float red[4][8][64 * V];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + tx;
+  const int c = (blockIdx.y * 64 + tx) * V;
   const long r0 = (long)blockIdx.x * rows;
   const long r1 = (r0 + rows < M) ? r0 + rows : M;
   float* out = parts + (long)blockIdx.x * K1 * N;
   for (int kc = 0; kc < K1; kc += 8) {
     const int kn = (K1 - kc < 8) ? K1 - kc : 8;
-    float acc[8];
+    float acc[8][V];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[j][v] = 0.f;
+    }
     if (c < N) {
       for (long r = r0 + ty; r < r1; r += 4) {
-        const float v = Z[r * N + c];
+        float z[V];
+        if constexpr (V == 4) { const f32x4 z4 = *(const f32x4*)(Z + r * N + c); z[0] = z4[0]; z[1] = z4[1]; z[2] = z4[2]; z[3] = z4[3]; }
+        else z[0] = Z[r * N + c];
         const float* a = A + r * K1 + kc;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < kn) acc[j] += a[j] * v;
+        for (int j = 0; j < 8; ++j) {
+          if (j < kn) {
+            const float aj = a[j];
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[j][v] += aj * z[v];
+          }
+        }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[ty][j][tx] = acc[j];
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) red[ty][j][tx * V + v] = acc[j][v];
+    }
     __syncthreads();
     if (c < N) {
-      for (int j = ty; j < kn; j += 4) out[(long)(kc + j) * N + c] = (red[0][j][tx] + red[1][j][tx]) + (red[2][j][tx] + red[3][j][tx]);
+      for (int j = ty; j < kn; j += 4) {
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          out[(long)(kc + j) * N + c + v] = (red[0][j][tx * V + v] + red[1][j][tx * V + v]) + (red[2][j][tx * V + v] + red[3][j][tx * V + v]);
+      }
     }
     __syncthreads();
   }
@@ -662,7 +680,7 @@ int vn_transpose(const float* W, float* Wt, int K, int N, hipStream_t s) {
 // fill those slots evenly (a launch of 585 equal workgroups on 256 CUs runs as long as one of 768); the thin kernel streams
 // and wants many small groups
 long vn_gemm_tn_rows(long M, int K1, int N, int ncu) {
-  if (K1 <= 32) return M < 2048 ? (M > 0 ? M : 1) : 2048;
+  if (K1 <= 32) return M < 512 ? (M > 0 ? M : 1) : 512;
   const int wc = wave_cols(N);
   const int bn = 64 * wc;
   const long tiles = ((K1 + BM - 1) / BM) * (long)((N + bn - 1) / bn);
@@ -677,8 +695,12 @@ long vn_gemm_tn_rows(long M, int K1, int N, int ncu) {
 int vn_gemm_tn_parts(const float* A, const float* Z, float* parts, long M, int K1, int N, long rows, hipStream_t s) {
   if (M <= 0 || N <= 0 || K1 <= 0 || rows <= 0) return 0;
   if (K1 <= 32) {
-    hipLaunchKernelGGL(vn_gemm_tn_thin_kernel, dim3((unsigned)((M + rows - 1) / rows), (unsigned)((N + 63) / 64)), dim3(256), 0, s, A, Z,
-                       parts, M, K1, N, rows);
+    if (N % 4 == 0 && aligned16(Z))
+      hipLaunchKernelGGL(vn_gemm_tn_thin_kernel<4>, dim3((unsigned)((M + rows - 1) / rows), (unsigned)((N + 255) / 256)), dim3(256), 0, s, A,
+                         Z, parts, M, K1, N, rows);
+    else
+      hipLaunchKernelGGL(vn_gemm_tn_thin_kernel<1>, dim3((unsigned)((M + rows - 1) / rows), (unsigned)((N + 63) / 64)), dim3(256), 0, s, A, Z,
+                         parts, M, K1, N, rows);
     return (int)hipGetLastError();
   }
   const int wc = wave_cols(N);

@@ -185,6 +185,26 @@ __global__ __launch_bounds__(EB) void k_seed_outer(const float* __restrict__ uba
   if (S == 2) out[n * H + i] = udbar[r] * w;
 }
 
+// both at once for the last hidden layer: (zbar, zdbar)_L straight from the seeds and the stored (a, ad)_L -- the adjoints
+// (abar, adbar) = (ubar, udbar) w_o^T are never written
+__global__ __launch_bounds__(EB) void k_seed_act_bwd(const float* __restrict__ ubar, const float* __restrict__ udbar,
+                                                    const float* __restrict__ wo, const float* __restrict__ A, long n, int H, int S,
+                                                    int act, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * EB + threadIdx.x;
+  if (i >= n * H) return;
+  const long r = i / H;
+  const float w = wo[i % H];
+  const float a = A[i];
+  const float s1 = act_s1<float>(a, act);
+  float zbar = s1 * (ubar[r] * w);
+  if (S == 2) {
+    const float adbar = udbar[r] * w;
+    zbar += act_s2r<float>(a, act) * A[n * H + i] * adbar;
+    out[n * H + i] = s1 * adbar;
+  }
+  out[i] = zbar;
+}
+
 // (abar, adbar) -> (zbar, zdbar) in place; A = the layer's stored (a, ad)
 __global__ __launch_bounds__(EB) void k_act_bwd(float* __restrict__ B, const float* __restrict__ A, long n, int H, int S, int act) {
   const long i = (long)blockIdx.x * EB + threadIdx.x;
@@ -304,6 +324,38 @@ __global__ __launch_bounds__(EB) void k_colsum_part(const float* __restrict__ A,
   __syncthreads();
   if (ty == 0 && c < H) part[(long)blockIdx.x * H + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
+// the same with 16-byte loads (H a multiple of 4, rows 16-byte aligned): a workgroup is 64 column quads x 4 row lanes over
+// RSV_ROWS rows -- a wave streams 1 KB per row instead of 256 B, and four times as many workgroups are in flight
+constexpr int RSV_ROWS = 512;
+typedef float lf32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(EB) void k_colsum_part_v4(const float* __restrict__ A, const float* __restrict__ x, long n, int H,
+                                                      float* __restrict__ part) {
+  __shared__ lf32x4 red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + 4 * tx;
+  const long r0 = (long)blockIdx.x * RSV_ROWS;
+  const long r1 = r0 + RSV_ROWS < n ? r0 + RSV_ROWS : n;
+  lf32x4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = lf32x4{0.f, 0.f, 0.f, 0.f};
+  if (c < H) {
+    long r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const lf32x4 v = *(const lf32x4*)(A + (r + 4 * k) * H + c);
+        acc[k] += x ? v * x[r + 4 * k] : v;
+      }
+    }
+    for (; r < r1; r += 4) {
+      const lf32x4 v = *(const lf32x4*)(A + r * H + c);
+      acc[0] += x ? v * x[r] : v;
+    }
+  }
+  red[ty][tx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (ty == 0 && c < H) *(lf32x4*)(part + (long)blockIdx.x * H + c) = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
 // narrow matrices (H < 8): the column lanes of the kernel above would mostly idle; here a workgroup's threads split
 // the rows, lane = row, and a fixed-order LDS tree adds them (H == 1: the output-bias gradient, sum of ubar)
 __global__ __launch_bounds__(EB) void k_colsum_part_narrow(const float* __restrict__ A, const float* __restrict__ x, long n, int H,
@@ -406,10 +458,12 @@ int ensure_part(VnLayered* w, size_t elems, char* err, size_t errlen) {
 
 // dst[0..H) += sum over the n rows of A (n x H, row-major) weighted by x (or 1): two launches, fixed summation order
 int colsum_add(VnLayered* w, const float* A, const float* x, long n, int H, float* dst, hipStream_t s, char* err, size_t errlen) {
-  const int nb = (int)((n + RS_ROWS - 1) / RS_ROWS);
+  const bool v4 = H >= 64 && H % 4 == 0 && ((size_t)A & 15) == 0;
+  const int nb = (int)(v4 ? (n + RSV_ROWS - 1) / RSV_ROWS : (n + RS_ROWS - 1) / RS_ROWS);
   if (int rc = ensure_part(w, (size_t)nb * H, err, errlen)) return rc;
   LTRACE(s, "colsum A=%p x=%p n=%ld H=%d nb=%d part=%p dst=%p", (const void*)A, (const void*)x, n, H, nb, (void*)w->part, (void*)dst);
-  if (H >= 8) hipLaunchKernelGGL(k_colsum_part, dim3(nb, (H + 63) / 64), dim3(EB), 0, s, A, x, n, H, w->part);
+  if (v4) hipLaunchKernelGGL(k_colsum_part_v4, dim3(nb, (H + 255) / 256), dim3(EB), 0, s, A, x, n, H, w->part);
+  else if (H >= 8) hipLaunchKernelGGL(k_colsum_part, dim3(nb, (H + 63) / 64), dim3(EB), 0, s, A, x, n, H, w->part);
   else hipLaunchKernelGGL(k_colsum_part_narrow, dim3(nb), dim3(EB), 0, s, A, x, n, H, w->part);
   LHIP(hipGetLastError());
   LTRACE(s, "colsum partial kernel done");
@@ -707,13 +761,16 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
     LTRACE(s, "bwd output-layer sums done");
     float* cur = adj[0];
     float* nxt = adj[1];
-    hipLaunchKernelGGL(k_seed_outer, dim3(blocks(cn * HL)), dim3(EB), 0, s, ubar, udbar, theta + net.woff[L + 1], cn, HL, S, cur);
+    hipLaunchKernelGGL(k_seed_act_bwd, dim3(blocks(cn * HL)), dim3(EB), 0, s, ubar, udbar, theta + net.woff[L + 1], act[L], cn, HL, S,
+                       net.actl[L], cur);
     LHIP(hipGetLastError());
     for (int l = L; l >= 1; --l) {
       const int Hin = net.H[l - 1], Hout = net.H[l];
       const long M = (long)S * cn;
-      hipLaunchKernelGGL(k_act_bwd, dim3(blocks(cn * Hout)), dim3(EB), 0, s, cur, act[l], cn, Hout, S, net.actl[l]);
-      LHIP(hipGetLastError());
+      if (l < L) {
+        hipLaunchKernelGGL(k_act_bwd, dim3(blocks(cn * Hout)), dim3(EB), 0, s, cur, act[l], cn, Hout, S, net.actl[l]);
+        LHIP(hipGetLastError());
+      }
       LTRACE(s, "bwd layer %d act_bwd done", l);
       // db_l += sum over the value-stream rows of zbar;  dW_l += [a; ad]^T [zbar; zdbar]
       if (int rc = colsum_add(w, cur, nullptr, cn, Hout, grad + net.boff[l], s, err, errlen)) return rc;
