@@ -188,9 +188,11 @@ def test_hand_written_gemms_against_the_library_form(widths, monkeypatch):
         torch.cuda.synchronize()
         assert np.array_equal(gb.cpu().numpy().astype(np.float64), g)
         u = eng.forward(d['Input'][:4099]).cpu().numpy()
-        out.append((g, u))
+        u64 = eng.forward_f64(np.asarray(d['Input'][:1031], dtype=np.float64)).cpu().numpy()     # fp64 MFMA product vs dgemm
+        out.append((g, u, u64))
         eng.close()
-    (g0, u0), (g1, u1) = out
+    (g0, u0, d0), (g1, u1, d1) = out
+    assert np.max(np.abs(d0 - d1)) <= 1e-12 * max(1.0, np.max(np.abs(d1)))
     assert np.max(np.abs(g0[:-4] - g1[:-4])) <= 3e-5 * np.max(np.abs(g1[:-4]))
     assert abs(g0[-4] - g1[-4]) <= 1e-5 * abs(g1[-4])
     assert np.max(np.abs(u0 - u1)) <= 2e-6 * max(1.0, np.max(np.abs(u1)))

@@ -603,6 +603,86 @@ __global__ __launch_bounds__(256) void vn_rowdot_kernel(const float* __restrict_
   }
 }
 
+// ---- fp64: the forward product of the fp64 entry points (vn_forward_f64, vn_residual_f64 of nets on this route) --------
+// C[M x N] = A[M x K] W[K x N] in double on v_mfma_f64_16x16x4_f64: workgroup = 4 waves, C tile 64 x 64, wave quadrant
+// 32 x 32 (2 x 2 accumulator tiles of 4 doubles), K step 16, one LDS buffer pair, guarded element-wise loads (any
+// dimensions).  A check path (the strong residual of Operator_1DtMOR.py:216-224 style post-processing), not a training path:
+// written for correctness and a sane fraction of the fp64 matrix rate, not tuned further.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int DLA = 18;       // [row][k] doubles: 16 + 2
+constexpr int DLB = 66;       // [k][col] doubles: 64 + 2
+__global__ __launch_bounds__(256) void vn_dgemm_nn_kernel(const double* __restrict__ A, const double* __restrict__ W,
+                                                        double* __restrict__ C, long M, int N, int K, int ntn) {
+  __shared__ double sA[64 * DLA];
+  __shared__ double sB[16 * DLB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 15, lk = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)(blockIdx.x / ntn) * 64;
+  const int n0 = (int)(blockIdx.x % ntn) * 64;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0., 0., 0., 0.};
+  }
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // A tile 64 x 16: thread t -> row t / 4, four k's; W tile 16 x 64: thread t -> k-row t / 16, four columns
+    {
+      const long row = m0 + (t >> 2);
+      const int kq = k0 + (t & 3) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sA[(t >> 2) * DLA + (t & 3) * 4 + e] = (row < M && kq + e < K) ? A[row * K + kq + e] : 0.;
+      const int kr = k0 + (t >> 4);
+      const int cq = n0 + (t & 15) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sB[(t >> 4) * DLB + (t & 15) * 4 + e] = (kr < K && cq + e < N) ? W[(long)kr * N + cq + e] : 0.;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = sA[(32 * wm + 16 * i + lm) * DLA + 4 * s4 + lk];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = sB[(4 * s4 + lk) * DLB + 32 * wn + 16 * j + lm];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // accumulator tile (i, j), register e: row 32 wm + 16 i + 4 e + lk, column 32 wn + 16 j + lm  (the fp64 MFMA interleaves the
+  // rows of a lane group: register e holds row 4 e + lk, where the fp32 16x16x4 holds row 4 lk + e)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long row = m0 + 32 * wm + 16 * i + 4 * e + lk;
+      if (row < M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + 32 * wn + 16 * j + lm;
+          if (col < N) C[row * N + col] = acc[i][j][e];
+        }
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void vn_drowdot_kernel(const double* __restrict__ A, const double* __restrict__ w, double* __restrict__ y,
+                                                        long M, int H, double beta) {
+  const int lane = threadIdx.x & 63;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (long r = wid; r < M; r += (long)gridDim.x * 4) {
+    double acc = 0.;
+    for (int h = lane; h < H; h += 64) acc += A[r * H + h] * w[h];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) y[r] = (beta != 0. ? beta * y[r] : 0.) + acc;
+  }
+}
+
 bool aligned16(const void* p) { return ((size_t)p & 15) == 0; }
 
 }  // namespace
@@ -721,5 +801,21 @@ int vn_rowdot(const float* A, const float* w, float* y, long M, int H, float bet
   long nb = (M + 3) / 4;
   if (nb > 65536) nb = 65536;
   hipLaunchKernelGGL(vn_rowdot_kernel, dim3((unsigned)nb), dim3(256), 0, s, A, w, y, M, H, beta);
+  return (int)hipGetLastError();
+}
+
+int vn_dgemm_nn(const double* A, const double* W, double* C, long M, int N, int K, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int ntn = (N + 63) / 64;
+  const long nb = ((M + 63) / 64) * ntn;
+  hipLaunchKernelGGL(vn_dgemm_nn_kernel, dim3((unsigned)nb), dim3(256), 0, s, A, W, C, M, N, K, ntn);
+  return (int)hipGetLastError();
+}
+
+int vn_drowdot(const double* A, const double* w, double* y, long M, int H, double beta, hipStream_t s) {
+  if (M <= 0) return 0;
+  long nb = (M + 3) / 4;
+  if (nb > 65536) nb = 65536;
+  hipLaunchKernelGGL(vn_drowdot_kernel, dim3((unsigned)nb), dim3(256), 0, s, A, w, y, M, H, beta);
   return (int)hipGetLastError();
 }

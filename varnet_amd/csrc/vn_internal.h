@@ -187,4 +187,6 @@ int vn_transpose(const float* W, float* Wt, int K, int N, hipStream_t s);       
 long vn_gemm_tn_rows(long M, int K1, int N, int ncu);       // rows per group that fill the chip evenly
 int vn_gemm_tn_parts(const float* A, const float* Z, float* parts, long M, int K1, int N, long rows, hipStream_t s);
 int vn_rowdot(const float* A, const float* w, float* y, long M, int H, float beta, hipStream_t s);      // y = beta y + A w
-
+// fp64 forward product / output layer of the fp64 entry points (v_mfma_f64_16x16x4_f64)
+int vn_dgemm_nn(const double* A, const double* W, double* C, long M, int N, int K, hipStream_t s);
+int vn_drowdot(const double* A, const double* w, double* y, long M, int H, double beta, hipStream_t s);

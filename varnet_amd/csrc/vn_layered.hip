@@ -11,9 +11,10 @@
 // Data layout: the streams of a chunk of rows are STACKED along the row axis -- buffer [S][n][H], read by the GEMMs as
 // one (S n) x H row-major matrix -- so every layer is ONE GEMM forward and TWO in the reverse pass, whatever S is
 // (S = 1: BC/IC rows and vn_forward; S = 2: interior rows; S = 1 + nd1 + dim: the strong residual with its first and
-// second derivative streams).  The GEMMs are rocBLAS (plain library GEMMs on huge-M, small-N/K shapes), resolved with
-// dlopen at first use so that libvarnet_hip.so neither links it nor loads it for networks the kernels cover; atomics
-// are switched off, so results are run-to-run reproducible.  Everything between the GEMMs is hand-written below.
+// second derivative streams).  The GEMMs are the MFMA kernels of vn_gemm.hip (fp32 with the forward epilogue fused, fp64 for
+// the fp64 entry points); VN_LAYERED_ROCBLAS=1 runs the same products on rocBLAS instead (a cross-check: resolved with
+// dlopen at first use, atomics off), so libvarnet_hip.so neither links the library nor loads it otherwise.  Everything between
+// the GEMMs is hand-written below; all reductions have a fixed order, results are run-to-run reproducible.
 // Rows are processed in chunks sized to a fixed workspace.  The seeds need R_k of whole test functions first, so a gradient
 // evaluation is forward (all rows) -> seed kernel -> reverse (all rows): the forward KEEPS the activations of all rows in
 // HBM when they fit half of the free memory (6.4 M rows of a 3 x 256 net: 39 GB of the 288) and the reverse pass reads
@@ -553,6 +554,12 @@ int gemm_fwd(VnLayered* w, long M, int Hin, int Hout, const T* A, const T* W, T*
       return 0;
     }
   }
+  if constexpr (sizeof(T) == 8) {
+    if (!w->use_blas) {
+      LGEMM(vn_dgemm_nn(A, W, Z, M, Hout, Hin, s));
+      return 0;
+    }
+  }
   if (int rc = ensure_blas(w, s, err, errlen)) return rc;
   const T one = T(1), zero = T(0);
   LBLAS(BlasT<T>::gemm(w->handle, rocblas_operation_none, rocblas_operation_none, Hout, (int)M, Hin, &one, W, Hout, A, Hin, &zero, Z, Hout));
@@ -564,6 +571,12 @@ int gemv_rows(VnLayered* w, long M, int H, const T* A, const T* x, T beta, T* y,
   if constexpr (sizeof(T) == 4) {
     if (!w->use_blas) {
       LGEMM(vn_rowdot(A, x, y, M, H, beta, s));
+      return 0;
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
+    if (!w->use_blas) {
+      LGEMM(vn_drowdot(A, x, y, M, H, beta, s));
       return 0;
     }
   }
