@@ -9,6 +9,6 @@ cd $root/varnet_amd/csrc
 make -j8 > /dev/null
 tmp=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize $extra -c vn_fused16.hip -o $tmp/vn_fused16.o
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 vn_api.o vn_generic.o vn_pointwise.o vn_fused.o $tmp/vn_fused16.o vn_dedup.o vn_layered.o vn_wide.o -o ../libvarnet_hip_$name.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 vn_api.o vn_generic.o vn_pointwise.o vn_fused.o $tmp/vn_fused16.o vn_dedup.o vn_layered.o vn_wide.o vn_gemm.o -o ../libvarnet_hip_$name.so
 rm -rf $tmp
 echo built libvarnet_hip_$name.so
