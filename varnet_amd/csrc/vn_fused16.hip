@@ -68,13 +68,6 @@ __host__ __device__ constexpr int vones(int KS) {
 }
 static_assert(vfeat(63) == 63 && vfeat(31) == 31 && vpos(7, 3) == 31, "position 4*KS-1 is feature 4*KS-1");
 __host__ __device__ constexpr int mtiles(int KS) { return (KS + 3) / 4; }
-// VN_H13_PIPE (50-wide hidden layers): the lane-major images hold 64 points each and there are two of them -- the publish of
-// the next 64 points is issued ahead of the contraction of the current 64 and lands under its MFMAs (same LDS footprint as
-// one 128-point image; five barriers per layer instead of four).  0 = the round-2/3 form: one 128-point image, publish and
-// contraction strictly alternate.
-#ifndef VN_H13_PIPE
-#define VN_H13_PIPE 1
-#endif
 #ifndef VN_MERGED_ROUNDS
 #define VN_MERGED_ROUNDS 1
 #endif
@@ -88,15 +81,15 @@ struct Lay {
   static constexpr int WH_OFF = al4(8 * WS);                // [L-1][HP][WS]
   static constexpr int BI_OFF = WH_OFF + (L - 1) * HPWS;    // [L][64] biases in (tile, g, i) order
   static constexpr int WO_OFF = BI_OFF + L * 64;            // [4*KS]
-  static constexpr int MISC_OFF = WO_OFF + al4(4 * KS);     // sInt[128]
-  static constexpr int T_OFF = MISC_OFF + 128;              // TA | TB
+  static constexpr int MISC_OFF = WO_OFF + al4(4 * KS);     // sInt[128] (+128 spare)
+  static constexpr int T_OFF = MISC_OFF + 256;              // TA | TB
   static constexpr int G1_SZ = (4 * KS0 + 1) * HP;
   static constexpr int GH_SZ = (HP + 1) * HP;
   static constexpr int GO_OFF = G1_SZ + (L - 1) * GH_SZ;
   static constexpr int G_SZ = al4(GO_OFF + HP + 1);
   static constexpr bool MERGE = merged_rounds(L, KS);
   static constexpr int T_IMG = (MERGE ? 2 : 1) * 2 * t_rows(KS) * TSW;     // TA | TB ( | TA' | TB' : wgrad_layer)
-  static constexpr int T_H13 = (KS == 13) ? (VN_H13_PIPE ? 2 * 27 * (NW / 2 * 64 + 4) : 27 * (NW * 64 + 4)) : 0;   // lane-major images of the 50-wide path (H13)
+  static constexpr int T_H13 = (KS == 13) ? 27 * (NW * 64 + 4) : 0;         // lane-major images of the 50-wide path (H13)
   static constexpr int T_MAX = T_IMG > T_H13 ? T_IMG : T_H13;
   // The gradient image of the final flush normally shares the transposition region.  Where it is larger than that
   // region AND the layout would then exceed the 160 KB (six 64-wide layers), it is laid over the weight images
@@ -526,17 +519,15 @@ __device__ __forceinline__ void thin_flush_in(const f32x4& acc, float* Gl, int l
 // so the six tile waves run one instruction stream (48 MFMAs per round) and share the A fragment.
 // D layout of the 4x4x1 MFMA: lane 4b+j, register i  =  sum_p A[lane 4b+i] * B[lane 4b+j].
 // Image layout of this path ("lane-major"): element (position pos, point (w, c)) of an image sits at
-//   vks(pos)*RS + w*64 + g(pos)*16 + c          (g(pos) = (pos>>2)&3; w = publishing wave within the image, RS = 64 PW + 4 floats)
+//   vks(pos)*RS + w*64 + g(pos)*16 + c          (g(pos) = (pos>>2)&3, RS = 8*64 + 4 floats)
 // i.e. one image row per k-step holds, per wave, the 64 lanes of that wave's register in lane order.  A
 // publishing store is then `ds_write_addtid_b32` (address = M0 + offset + 4*lane, no address VGPR,
 // 128 B/clk/CU instead of the 64 B/clk of ds_write_b32 -- the publish rounds are bound by the LDS store
 // path), and a reader still finds 4 consecutive points of one feature in one ds_read_b128.
 // TA: rows 0..12 = k-steps, row 13 = [bias ones | zeros | zeros | zeros]; TB: rows 0..12.
 struct H13 {
-  static constexpr int PW = VN_H13_PIPE ? NW / 2 : NW;               // publishing waves per image
-  static constexpr int RS = PW * 64 + 4;
+  static constexpr int RS = NW * 64 + 4;
   static constexpr int TA_ROWS = 14, TB_ROWS = 13;
-  static constexpr int IMG = (TA_ROWS + TB_ROWS) * RS;               // floats per image (TA | TB)
   static constexpr int P48 = vpos(12, 0), P49 = vpos(12, 1);          // positions of features 48, 49
   static constexpr int ONES = vones(13);                              // position (13, g=0): the bias row
   static constexpr int ZERO = ONES + 4;                               // position (13, g=1): always zero (TA only)
@@ -548,7 +539,7 @@ struct H13 {
   __device__ static __forceinline__ int tile_n(int wave) { return wave >= 4 ? 1 : 0; }
 };
 static_assert(H13::ZERO == 53 && vks(H13::ZERO) == 13, "zero position");
-static_assert(Lay<5, 13>::T_H13 == (VN_H13_PIPE ? 2 : 1) * H13::IMG, "image size");
+static_assert(Lay<5, 13>::T_H13 == (H13::TA_ROWS + H13::TB_ROWS) * H13::RS, "image size");
 
 // ds_write_addtid_b32: LDS[M0 + OFF + 4*lane] = v.  M0 is written once per publishing round (the wait
 // state is the documented SALU-writes-M0 -> add-TID hazard); nothing else in this kernel uses M0.
@@ -566,95 +557,6 @@ __device__ __forceinline__ void addtid_drain() {     // the compiler does not co
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-#if VN_H13_PIPE
-// One sub-round: contraction over the 64 points of one image (TA | TB).  Core waves: tile (m, n0) always; tile (m, 2), which
-// waves w and w + 4 share, is taken by the wave whose own points are in this image (`shared`) -- the other one of the pair
-// has the next publish to issue, and the two sit on one SIMD, so the matrix work per SIMD and sub-round is the same.
-__device__ __forceinline__ void h13_contract(const float* TA, const LaneC& lc, int wave, int lane, bool shared, f32x4 (&acc)[2]) {
-  const float* TB = TA + H13::TA_ROWS * H13::RS;
-  const int role = H13::role(wave);
-  if (role == 1 || role == 2) {
-    // border job: every lane walks the 64 points, 4 per ds_read_b128; two accumulators alternate
-    const int sel = lane & 3;
-    constexpr int TBO = H13::TA_ROWS * H13::RS;
-    const int lane_off = vks(lane) * H13::RS + ((lane >> 2) & 3) * 16;        // lane = position
-    const int oA = (role == 1) ? H13::off(H13::edge_row(sel)) : lane_off;
-    const int oB = (role == 1) ? TBO + lane_off
-                               : (sel == 0 ? TBO + H13::off(H13::P48) : sel == 1 ? TBO + H13::off(H13::P49) : H13::off(H13::ZERO));
-    const float* pA = TA + oA;
-    const float* pB = TA + oB;
-    constexpr int NSTG = 64 / 8;                                              // 8 points per stage
-    f32x4 a0[2], b0[2], a1[2], b1[2];
-    auto load = [&](f32x4 (&a4)[2], f32x4 (&b4)[2], int stage) {
-      const int o = (stage >> 1) * 64 + (stage & 1) * 8;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        a4[h] = *reinterpret_cast<const f32x4a*>(&pA[o + 4 * h]);
-        b4[h] = *reinterpret_cast<const f32x4a*>(&pB[o + 4 * h]);
-      }
-    };
-    auto compute = [&](const f32x4 (&a4)[2], const f32x4 (&b4)[2]) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0] = mfma4(a4[0][e], b4[0][e], acc[0]);
-        acc[1] = mfma4(a4[1][e], b4[1][e], acc[1]);
-      }
-    };
-    load(a0, b0, 0);
-#pragma unroll 1
-    for (int q = 0; q < NSTG; q += 2) {
-      load(a1, b1, q + 1);
-      compute(a0, b0);
-      if (q + 2 < NSTG) load(a0, b0, q + 2);
-      compute(a1, b1);
-    }
-    return;
-  }
-  // core tiles: lane (c, g) reads feature position 16m+c; lane group g contracts the 16 points of the image's g-th publishing
-  // wave (lane groups 64 floats apart: conflict-free ds_read_b128, rows 4 banks apart)
-  const int m = H13::tile_m(wave), n0 = H13::tile_n(wave);
-  const int fo = (lc.c & 3) * H13::RS + (lc.c >> 2) * 16 + lc.g * 64;      // + 4m*RS for tile row m
-  const int rdA = 4 * m * H13::RS + fo;
-  const int rdB = 4 * n0 * H13::RS + fo;
-  const int rdC = 4 * 2 * H13::RS + fo;
-  f32x4 a4 = *reinterpret_cast<const f32x4a*>(&TA[rdA]);
-  f32x4 b4 = *reinterpret_cast<const f32x4a*>(&TB[rdB]);
-  if (shared) {
-    f32x4 c4 = *reinterpret_cast<const f32x4a*>(&TB[rdC]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 an = a4, bn = b4, cn = c4;
-      if (j + 1 < 4) {
-        an = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * (j + 1)]);
-        bn = *reinterpret_cast<const f32x4a*>(&TB[rdB + 4 * (j + 1)]);
-        cn = *reinterpret_cast<const f32x4a*>(&TB[rdC + 4 * (j + 1)]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0] = mfma16(a4[e], b4[e], acc[0]);
-        acc[1] = mfma16(a4[e], c4[e], acc[1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      a4 = an; b4 = bn; c4 = cn;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 an = a4, bn = b4;
-      if (j + 1 < 4) {
-        an = *reinterpret_cast<const f32x4a*>(&TA[rdA + 4 * (j + 1)]);
-        bn = *reinterpret_cast<const f32x4a*>(&TB[rdB + 4 * (j + 1)]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[0] = mfma16(a4[e], b4[e], acc[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      a4 = an; b4 = bn;
-    }
-  }
-}
-#else
 __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, const LaneC& lc, int wave, int lane,
                                              f32x4 (&acc)[2]) {
   const int role = H13::role(wave);
@@ -745,8 +647,6 @@ __device__ __forceinline__ void h13_contract(const float* TA, const float* TB, c
   }
 }
 
-#endif
-
 template <int KS_, int I, bool TANH>
 struct H13Pub {      // unrolled stores with compile-time offsets (inline-asm immediates)
   static __device__ __forceinline__ void run(int half, const PA<13>& av, const PA<13>& azd, const PA<13>& bv,
@@ -764,38 +664,6 @@ struct H13Pub {      // unrolled stores with compile-time offsets (inline-asm im
   }
 };
 
-#if VN_H13_PIPE
-// A 50-wide hidden layer: four sub-rounds (value operands of points 0..63, of points 64..127, tangent operands likewise).
-// Waves 0..3 publish into image 0, waves 4..7 into image 1 (t_base_bytes = byte address of this wave's 64 columns of its
-// image's TA); the stores of sub-round s+1 are issued in front of the contraction of sub-round s -- other image -- and land under
-// its MFMAs.  One barrier per sub-round: it makes the next image visible and hands the current one back.
-template <bool TANH>
-__device__ __forceinline__ void h13_wgrad_layer(const PA<13>& av, const PA<13>& azd, const PA<13>& bv,
-                                                const PA<13>& bt, float* TA, const LaneC& lc, int wave, int lane,
-                                                unsigned t_base_bytes, f32x4 (&acc)[2] STAMP_PARAMS) {
-  const int mine = wave >> 2;                    // the image this wave's 16 points go to
-  auto publish = [&](int half) {
-    addtid_base(t_base_bytes);
-    H13Pub<13, 0, TANH>::run(half, av, azd, bv, bt);
-    addtid_store<13 * H13::RS * 4>((half == 0 && lc.g == 0) ? 1.f : 0.f);      // bias row | zeros
-  };
-  if (mine == 0) publish(0);
-  addtid_drain();
-  WSTAMP(2);
-  __syncthreads();
-  WSTAMP(3);
-#pragma unroll 1                  // one copy of the sub-round's code: the tile loop must stay inside the instruction cache
-  for (int s = 0; s < 4; ++s) {
-    const int img = s & 1;
-    if (s < 3 && mine == ((s + 1) & 1)) publish((s + 1) >> 1);
-    h13_contract(TA + img * H13::IMG, lc, wave, lane, mine == img, acc);
-    addtid_drain();
-    WSTAMP(4);
-    __syncthreads();
-    WSTAMP(5);
-  }
-}
-#else
 // both rounds of a 50-wide hidden layer; t_base_bytes = byte address of this wave's 64 columns of TA
 template <bool TANH>
 __device__ __forceinline__ void h13_wgrad_layer(const PA<13>& av, const PA<13>& azd, const PA<13>& bv,
@@ -827,8 +695,6 @@ __device__ __forceinline__ void h13_wgrad_layer(const PA<13>& av, const PA<13>& 
     WSTAMP(5);
   }
 }
-
-#endif
 
 template <int GS>
 __device__ __forceinline__ void h13_flush(const f32x4 (&acc)[2], float* Gl, const LaneC& lc, int wave, int lane,
@@ -986,8 +852,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   float* sInt = lds + LY::MISC_OFF;
   float* TA = lds + LY::T_OFF;
   float* TB = TA + t_rows(KS) * TSW;
-  const unsigned t_base_bytes = VN_H13_PIPE ? (unsigned)((LY::T_OFF + (wave >> 2) * H13::IMG + (wave & 3) * 64) * 4)
-                                            : (unsigned)((LY::T_OFF + wave * 64) * 4);      // lane-major images: this wave's columns
+  const unsigned t_base_bytes = (unsigned)((LY::T_OFF + wave * 64) * 4);      // lane-major images: this wave's columns
   float* Gacc = lds + LY::G_OFF;
 
   FIXSTAMP(0);
