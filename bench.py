@@ -81,6 +81,23 @@ def build_problem(cfg):
         pde = ADPDE(Domain1D(), diff=0.1 / np.pi, vel=1.0, tInterval=[0, 2.0], IC=lambda x: -np.sin(np.pi * x))
         vn = VarNet(pde, layerWidth=[50] * 4, discNum=50, bDiscNum=None, tDiscNum=200)
         name = '1D+t AD-PDE (Operator_1Dt), 4x50 MLP, 1e4 test functions x 16 quadrature points'
+    elif cfg == 1:
+        pde = ADPDE(Domain1D(), diff=0.1 / np.pi, vel=1.0, tInterval=[0, 2.0], IC=lambda x: -np.sin(np.pi * x))
+        vn = VarNet(pde, layerWidth=[20] * 3, discNum=20, bDiscNum=None, tDiscNum=300)
+        name = '1D+t AD-PDE (Operator_1Dt), 3x20 MLP, 6e3 test functions x 16 quadrature points'
+    elif cfg == 5:
+        from varnet_amd.mor import MOR
+
+        def diffFun(x, t=0, D=0.01):
+            return D * np.ones([np.shape(x)[0], 1])
+
+        def disc(discNum=6):
+            return np.array([0.003 * (11 ** (n / (discNum - 1))) for n in range(discNum)])[np.newaxis].T
+        mor = MOR(diffFun, ['D'], [[0.003, 0.033]])
+        pde = ADPDE(Domain1D(), diff=diffFun, vel=1.0, timeDependent=True, tInterval=[0, 2.0], IC=lambda x: -np.sin(np.pi * x),
+                    MORvar=mor)
+        vn = VarNet(pde, layerWidth=[10, 20, 30], discNum=150, bDiscNum=None, tDiscNum=800, MORdiscScheme=disc)
+        name = '1D+t parametric-kappa AD-PDE (Operator_1DtMOR), [10,20,30] MLP, 6 kappa x 20 mini-batches of 6e3 test functions x 16 points'
     else:
         raise SystemExit('unknown --config')
     return vn, name
@@ -233,6 +250,44 @@ def small_step_line(cfg, steps, warmup):
     return out
 
 
+def mor_epoch_line(epochs, warmup):
+    """BASELINE config 5 under `extra`: one epoch = 6 diffusivities x 20 mini-batches, each mini-batch its own Adam step
+    (VarNetUtility.py:1021-1047: batch loop inside the MOR loop), driven like VarNet.train drives it."""
+    import torch
+    vn, wname = build_problem(5)
+    fd, eng = vn.fixData, vn.engine
+    td = vn._build_tdata(batchNum=20)
+    eng.set_weights(np.array([1.0, 1.0, 1.0]))
+    acc = torch.zeros((), device='cuda')
+
+    def epoch():
+        for mb in range(fd.MORbatchNum):
+            td.select_mor(mb)
+            vn.optimIter(td, mb, acc)
+    for _ in range(warmup):
+        epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(epochs):
+        epoch()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / epochs
+    steps = fd.MORbatchNum * td.batchNum
+    F_pt = 2 * (vn.inpDim * vn.layerWidth[0] + sum(a * b for a, b in zip(vn.layerWidth[:-1], vn.layerWidth[1:])) + vn.layerWidth[-1])
+    nB = td.mor[0]['biInput'].shape[0]
+    flop = (6.0 * F_pt * fd.nT + 3.0 * F_pt * nB * td.batchNum) * fd.MORbatchNum
+    out = {"config": {"workload": wname, "training_points_per_epoch": int(fd.nT * fd.MORbatchNum), "adam_steps_per_epoch": int(steps),
+                      "training_points_per_step": int(fd.nT // td.batchNum), "bc_ic_points": int(nB)},
+           "value": fd.nT * fd.MORbatchNum / dt, "unit": "training-points/s", "epochs": epochs, "warmup": warmup,
+           "ms_per_epoch": dt * 1e3, "us_per_step": dt / steps * 1e6,
+           "roofline": {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "whole_step_frac": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                        "note": "whole epoch incl. the host loop over mini-batches; a step is ~16 us of fixed cost (two dependent kernel "
+                                "boundaries: 7.6 us floor) plus 3 tiles per workgroup"}}
+    eng.close()
+    return out
+
+
 def main():
     try:
         _main()
@@ -255,7 +310,7 @@ def _main():
     ap.add_argument('--config', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dedup', action='store_true', help='skip the extra de-duplicated-formulation timing')
-    ap.add_argument('--no-extra', action='store_true', help='skip the extra small-step workload (config 2)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the extra small-step workloads (configs 1, 2, 5)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -431,7 +486,9 @@ def _main():
             out["cpu_baseline"] = cpu_baseline(vn, tdata)
         if world == 1 and args.config == 3 and not args.no_extra:
             eng.close()
-            out["extra"] = {"config2_small_step": small_step_line(2, 400, 40)}
+            out["extra"] = {"config2_small_step": small_step_line(2, 400, 40),
+                            "config1_small_step": small_step_line(1, 1000, 100),
+                            "config5_mor_epoch": mor_epoch_line(5, 2)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
