@@ -1,24 +1,29 @@
-// fp32 GEMMs of the layer-by-layer route (vn_layered.hip), hand-written for gfx950: the three products a layer needs when
-// its width is beyond the tile kernels of vn_wide.hip (hidden widths above 256; TFModel.py:208-221 accepts any list).
+// GEMMs of the layer-by-layer route (vn_layered.hip), hand-written for gfx950: the products a layer needs when its width is
+// beyond the tile kernels of vn_wide.hip (hidden widths above 256; TFModel.py:208-221 accepts any list).
 //
-//   forward          Z [M x N]   = A [M x K] W [K x N]            (vn_gemm_nn: M = stacked rows of a chunk, K = H_in, N = H_out)
-//   input gradient   dA[M x N]   = Zb[M x K] W^T, W [N x K]        (vn_gemm_nt: K = H_out, N = H_in)
-//   weight gradient  P_g[K1 x N] = A_g^T Zb_g over the rows of group g   (vn_gemm_tn_parts; a fixed-order sum adds the groups)
+//   forward          (a | ad) [S][c][N] = epilogue(A [S][c][K] W [K x N] + b)   vn_gemm_fwd   (K = H_in, N = H_out; a = act(z + b),
+//                                                                                ad = act'(z) zd fused into the product)
+//   input gradient   dA [M x N]  = Zb [M x K] (W^T) [K x N]                      vn_transpose + vn_gemm_nn   (K = H_out, N = H_in)
+//   weight gradient  P_g [K1 x N] = A_g^T Zb_g over the rows of group g          vn_gemm_tn_parts   (a fixed-order sum adds the groups)
+//   fp64 forward     C [M x N]   = A [M x K] W [K x N]                           vn_dgemm_nn   (fp64 entry points)
 //
-// All matrices row-major.  M is millions of rows, K / N a few hundred: the shapes are tall and skinny, every product is
-// compute-bound on the fp32 matrix pipe (32 FLOP per byte of operand traffic per 128 x 128 x 16 step).
+// All matrices row-major.  M is millions of rows, K / N a few hundred: the shapes are tall and skinny and compute-bound on the
+// fp32 matrix pipe (43 FLOP per byte of operand traffic per 128 x 256 x 16 step, 32 per 128 x 128 x 16 step).
 //
-// Geometry: workgroup = 4 waves (256 threads), C tile 128 x 128, K step 16, v_mfma_f32_16x16x4_f32; wave (wm, wn) owns a
-// 64 x 64 quadrant = 4 x 4 accumulator tiles (64 registers), so the kernels fit 128 registers and four workgroups share a CU
-// (four waves per SIMD: the loads of one hide under the MFMAs of the others).  Operand tiles are double-buffered in LDS, one
-// workgroup barrier per K step; the global loads of step k+1 are issued before the MFMAs of step k and written to LDS after
-// them.  Two LDS tile layouts, chosen so that the global side is always 16-byte loads along the contiguous dimension:
-//   * [row][k]   (row stride 20 floats): operands whose K runs along memory (A of nn / nt, W of nt).  A lane's fragment of
+// Geometry: workgroup = 2 x WC waves, C tile 128 x 64 WC (WC = 4: 128 x 256, 512 threads; WC = 2: 128 x 128, 256 threads --
+// whichever pads N less), K step 16, v_mfma_f32_16x16x4_f32; wave (wm, wn) owns a 64 x 64 quadrant = 4 x 4 accumulator tiles
+// (64 registers), 128 registers per wave, 16 waves per CU.  Operand tiles are double-buffered in LDS, one workgroup barrier per
+// K step; the global loads of step k+1 are issued before the MFMAs of step k and written to LDS after them.  Quadrant tiles
+// that lie outside the matrix are skipped (whole 16 x 16 tiles), and the wave -> quadrant map rotates with the workgroup so
+// that the idle quadrants of edge tiles do not always idle the same SIMD.
+// Two LDS tile layouts, chosen so that the global side is always 16-byte loads along the contiguous dimension:
+//   * [row][k]   (row stride 20 floats): operands whose K runs along memory (the A side of nn / fwd).  A lane's fragment of
 //     one 16-row tile for all four MFMAs of a K step is ONE ds_read_b128: MFMA step s of lane group lk uses k = 4 lk + s --
 //     any assignment of the 16 k's to (step, lane group) is valid as long as both operands use the same one.
-//   * [k][col]   (row stride 132 floats): operands whose K runs across rows (W of nn; both operands of tn, whose K is the
-//     row index of the chunk).  Fragment = four ds_read_b32 (conflict-free: 16 consecutive columns per lane group, lane
+//   * [k][col]   (row stride 64 WC + 4 floats): operands whose K runs across rows (W of nn / fwd; both operands of tn, whose K is
+//     the row index of the chunk).  Fragment = four ds_read_b32 (conflict-free: 16 consecutive columns per lane group, lane
 //     groups 4 rows = 16 banks apart).
+// The input layer (K = d_in <= 32) is served by streaming kernels in both directions: an MFMA tile would be 97 % padding.
 // No atomics anywhere; every sum has a fixed order, so results are bitwise reproducible.
 // Dimensions that are not multiples of 4, or operands that are not 16-byte aligned, take the same kernels with element-wise
 // guarded loads (VEC = false): correct for any width the reference accepts, slower.
