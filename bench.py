@@ -33,38 +33,74 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 
 
-def kernel_source_hash():
-    """sha256 over the kernel sources the library is built from: ties a committed counter file to the code it measured."""
-    import glob
+# which translation units determine the code of a profiled kernel (the instantiation's name starts with the key)
+KERNEL_SOURCES = {'vn_fused16_kernel': ('varnet_amd/csrc/vn_fused16.hip', 'varnet_amd/csrc/vn_internal.h')}
+# counter files bench.py may quote `roofline.traffic` from, by --config (tools/collect_profiles.sh + tools/summarise_profiles.py)
+TRAFFIC_FILES = {3: 'pmc_traffic.json', 2: 'pmc_traffic_cfg2.json'}
+
+
+def strip_comments(src):
+    """C/C++ source without comments and with runs of white space collapsed (string and character literals kept):
+    what is left decides the generated code, a reworded comment or a re-wrapped line does not."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c == '/' and i + 1 < n and src[i + 1] == '/':
+            while i < n and src[i] != '\n':
+                i += 1
+        elif c == '/' and i + 1 < n and src[i + 1] == '*':
+            j = src.find('*/', i + 2)
+            i = n if j < 0 else j + 2
+            out.append(' ')
+        elif c in '"\'':
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == '\\' else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return ' '.join(''.join(out).split())
+
+
+def kernel_source_hash(kernel='vn_fused16_kernel'):
+    """sha256 over the comment-stripped, white-space-normalised translation units that determine `kernel`'s code: ties a
+    committed counter file to the code it measured.  Edits to other kernels' files, comments and layout do not move it."""
     import hashlib
+    key = [k for k in KERNEL_SOURCES if str(kernel).startswith(k)]
+    if not key:
+        return None
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'varnet_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'varnet_amd', 'csrc', '*.h'))
-                    + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, 'rb').read())
+    for f in KERNEL_SOURCES[key[0]]:
+        h.update(f.encode())
+        h.update(strip_comments(open(os.path.join(ROOT, f)).read()).encode())
     return h.hexdigest()
 
 
 def static_traffic(kname, config, world):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the run (they need a
-    rocprofv3 --pmc pass of their own), so the figure is the committed one from profiles/pmc_traffic.json
+    rocprofv3 --pmc pass of their own), so the figure is the committed one from profiles/pmc_traffic*.json
     (tools/collect_profiles.sh + tools/summarise_profiles.py: FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as
-    is) -- and ONLY if that file was collected on this exact kernel instantiation, this workload and these kernel sources.
+    is) -- and ONLY if that file was collected on this exact kernel instantiation, this workload and this kernel's code.
     Returns (traffic or None, traffic_source string)."""
-    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if world != 1 or config not in TRAFFIC_FILES:
+        return None, 'none: counter passes are committed for the N=1 launches of configs %s only' % sorted(TRAFFIC_FILES)
+    rel = 'profiles/' + TRAFFIC_FILES[config]
+    tfile = os.path.join(ROOT, rel)
     if not os.path.exists(tfile):
-        return None, 'none: profiles/pmc_traffic.json absent'
+        return None, 'none: %s absent' % rel
     js = json.load(open(tfile))
     norm = lambda n: ''.join(str(n).split())
-    if config != 3 or world != 1:
-        return None, 'none: profiles/pmc_traffic.json holds the N=1 config-3 launch only'
+    if js.get('config') != config:
+        return None, 'none: %s holds the config-%s launch' % (rel, js.get('config'))
     if norm(js.get('kernel')) != norm(kname):
-        return None, 'none: profiles/pmc_traffic.json was collected on %s, this run launches %s' % (js.get('kernel'), kname)
-    if js.get('kernel_source_sha256') != kernel_source_hash():
-        return None, ('none: profiles/pmc_traffic.json (%s) predates the current kernel sources (sha256 differs): re-run '
-                      'tools/collect_profiles.sh' % js.get('round'))
-    return js.get('hbm_bytes_per_launch'), ('profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of round %s on %s, kernel '
-                                            'sources sha256 %s... = this build)' % (js.get('round'), js.get('kernel'), js['kernel_source_sha256'][:12]))
+        return None, 'none: %s was collected on %s, this run launches %s' % (rel, js.get('kernel'), kname)
+    if js.get('kernel_source_sha256') != kernel_source_hash(kname):
+        return None, ('none: %s (%s) predates the current code of this kernel (sha256 of its comment-stripped sources differs): '
+                      're-run tools/collect_profiles.sh' % (rel, js.get('round')))
+    return js.get('hbm_bytes_per_launch'), ('%s (static: rocprofv3 --pmc passes of round %s on %s, sha256 of its comment-stripped '
+                                            'sources %s... = this build)' % (rel, js.get('round'), js.get('kernel'), js['kernel_source_sha256'][:12]))
 
 
 def build_problem(cfg):
@@ -237,6 +273,7 @@ def small_step_line(cfg, steps, warmup):
     kms, kl, kname = eng.profile_end()
     F_pt = 2 * (vn.inpDim * vn.layerWidth[0] + sum(a * b for a, b in zip(vn.layerWidth[:-1], vn.layerWidth[1:])) + vn.layerWidth[-1])
     flop = 6.0 * F_pt * fd.nT + 3.0 * F_pt * nB
+    traffic, traffic_source = static_traffic(kname, cfg, 1)
     out = {"config": {"workload": wname, "training_points_per_step": int(fd.nT), "bc_ic_points": int(nB)},
            "value": fd.nT * steps / dt, "unit": "training-points/s", "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3,
@@ -244,8 +281,8 @@ def small_step_line(cfg, steps, warmup):
                         "kernel_ms": kms, "launches_timed": kl, "algorithmic_flop_per_launch": flop,
                         "achieved": flop / (kms * 1e-3) / 1e12 if kms else None,
                         "frac": flop / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if kms else None,
-                        "whole_step_frac": flop / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                        "traffic_source": "none: no counter pass committed for this workload"}}
+                        "whole_step_frac": flop / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                        "traffic_source": traffic_source}}
     eng.close()
     return out
 
@@ -461,6 +498,10 @@ def _main():
                 "backend": ("RCCL communicator inside the engine (vn_comm_init / vn_allreduce_grad)" if vn.comm == 'rccl'
                             else "torch.distributed " + dist.get_backend()),
                 "ranks_reported": int(n_ranks), "payload_bytes": (P + 4) * 4,
+                # what summed the gradient: the version of the RCCL library this process loaded (ncclGetVersion) and the
+                # (ranks, rank) the engine's communicator reports (vn_comm_size; [1, 0] when the collective is torch's)
+                "rccl_version": eng.comm_version(), "vn_comm_size": list(eng.comm_size()),
+                "bc_ic_weight_divisor": world,          # VarNetUtility.py:900-901: every tower is fed the whole BC/IC set
                 "allreduce_ms": comm_ms,
                 "note": "HIP events around the collective on the engine stream (includes waiting for the slowest rank)"}
             for r in per_rank:

@@ -64,7 +64,7 @@ enum { VN_KERNEL_AUTO = 0, VN_KERNEL_GENERIC = 1, VN_KERNEL_FUSED = 2 /* 4 waves
         * more than 8 inputs).  Hidden widths <= 256: tile
         * kernels that carry 32 points through all layers with the activations in LDS and keep (a, ad) of every layer
         * in HBM for the reverse kernel (6 F_pt per point).  Otherwise: activations of a chunk of rows live in HBM,
-        * every layer is one GEMM over the stacked (value, tangent) rows -- rocBLAS, loaded with dlopen at first use --
+        * every layer is one GEMM over the stacked (value, tangent) rows -- the hand-written MFMA products of vn_gemm.hip --
         * plus hand-written elementwise kernels (6 F_pt when a step's activations fit in HBM, else 8).  Same results
         * contract as the other routes. */
        VN_KERNEL_LAYERED = 4 };
@@ -96,8 +96,9 @@ typedef struct vn_config {
 const char* vn_last_error(void);
 int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_kernel_path, vn_profile_comm;
                                 * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, layer_act, VN_KERNEL_LAYERED;
-                                * 4: vn_comm_available, Adam hyper-parameters validated (no silent NaN from a zeroed config) */
-#define VN_ABI_VERSION 4     /* what this header describes: a binding must refuse a library that reports another number */
+                                * 4: vn_comm_available, Adam hyper-parameters validated (no silent NaN from a zeroed config);
+                                * 5: vn_comm_version */
+#define VN_ABI_VERSION 5     /* what this header describes: a binding must refuse a library that reports another number */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
 int vn_create(const vn_config* cfg, vn_engine** out);
@@ -205,12 +206,15 @@ int vn_residual_f64(vn_engine* h, const double* X_dev, const double* diff_dev,
  *   all ranks: vn_comm_init(h, rank, world, id) -> collective; returns when every rank has joined
  * With a communicator attached, vn_train_step / vn_train_epoch run gradient -> all-reduce -> optimizer on
  * the engine stream without a host round trip; vn_grad + vn_allreduce_grad + vn_apply is the same step in
- * three calls.  RCCL is loaded at run time (librccl.so.1 by SONAME, or $VN_RCCL_LIB); without it these four
+ * three calls.  RCCL is loaded at run time (librccl.so.1 by SONAME, or $VN_RCCL_LIB); without it the vn_comm_* 
  * entry points return VN_EUNSUPPORTED and everything else works. */
 #define VN_COMM_ID_BYTES 128
 /* VN_OK if RCCL can be loaded in this process (no collective, no GPU work): lets every rank probe locally BEFORE any
  * rank enters the collective bootstrap, so that all ranks take the same route. */
 int vn_comm_available(void);
+/* Version of the RCCL library this process loaded, as ncclGetVersion reports it (e.g. 22205 = 2.22.5); VN_EUNSUPPORTED
+ * when it cannot be loaded.  No collective, no GPU work: a first multi-GPU record can say which library summed the gradient. */
+int vn_comm_version(int32_t* version_out);
 int vn_comm_unique_id(void* id_out_host);
 int vn_comm_init(vn_engine* h, int32_t rank, int32_t world, const void* unique_id_host);
 /* Ranks RCCL reports for the attached communicator (1 if none); rank_out may be NULL. */

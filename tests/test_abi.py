@@ -29,9 +29,9 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), 'missing export ' + n
     assert set(names) == set(engine.ABI_SYMBOLS), set(names) ^ set(engine.ABI_SYMBOLS)
-    assert lib.vn_abi_version() == engine.VN_ABI_VERSION == 4
+    assert lib.vn_abi_version() == engine.VN_ABI_VERSION == 5
     hdr = open(os.path.join(ROOT, 'include', 'varnet_hip.h')).read()
-    assert re.search(r'#define\s+VN_ABI_VERSION\s+4\b', hdr)
+    assert re.search(r'#define\s+VN_ABI_VERSION\s+5\b', hdr)
 
 
 def test_no_silent_cpu_fallback():
@@ -119,6 +119,22 @@ def test_product_package_never_imports_oracle():
         if f.endswith('.py'):
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+def test_product_library_knows_no_vendor_gemm_library():
+    """the env-switched rocBLAS twin of the layer-by-layer route was a dual path inside the product
+    library.  Neither the sources of the package nor the built .so (strings, DT_NEEDED) name a BLAS library any more; the
+    only library the engine opens by name is RCCL (the one collective)."""
+    import subprocess
+    for d in ('varnet_amd', os.path.join('varnet_amd', 'csrc'), 'include'):
+        for f in os.listdir(os.path.join(ROOT, d)):
+            if f.endswith(('.py', '.hip', '.h', '.c', '.cpp')) or f == 'Makefile':
+                assert not re.search(r'(?i)blas', open(os.path.join(ROOT, d, f)).read()), os.path.join(d, f)
+    lib = os.path.join(ROOT, 'varnet_amd', 'libvarnet_hip.so')
+    blob = open(lib, 'rb').read()
+    assert b'rocblas' not in blob.lower() and b'hipblas' not in blob.lower()
+    needed = subprocess.run(['readelf', '-d', lib], capture_output=True, text=True).stdout
+    assert 'NEEDED' in needed and not re.search(r'(?i)blas', needed)
 
 
 @pytest.mark.gpu

@@ -41,17 +41,44 @@ def test_self_launch_reports_a_failed_rank():
     assert any('exited with status' in js['error'] and js.get('n_gpus') == 2 for js in lines)
 
 
-def test_static_traffic_is_refused_for_another_kernel_or_source():
+def test_static_traffic_is_refused_for_another_kernel_or_config():
     sys.path.insert(0, ROOT)
     import bench
     js = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-    assert 'kernel_source_sha256' in js and '<' in js['kernel']                   # template arguments recorded
+    assert 'kernel_source_sha256' in js and '<' in js['kernel'] and js['config'] == 3        # template arguments recorded
     t, src = bench.static_traffic('vn_fused16_kernel<4, 13, false>', 3, 1)
     assert t is None and 'was collected on' in src
-    t, src = bench.static_traffic(js['kernel'], 2, 1)
-    assert t is None and 'config-3' in src
-    t, src = bench.static_traffic(js['kernel'], 3, 1)
-    if js['kernel_source_sha256'] == bench.kernel_source_hash():
-        assert t == js['hbm_bytes_per_launch'] and src.startswith('profiles/pmc_traffic.json (static')
-    else:                                                                         # sources moved on since the counter pass
-        assert t is None and 'predates' in src
+    t, src = bench.static_traffic(js['kernel'], 3, 2)
+    assert t is None and 'N=1' in src
+    t, src = bench.static_traffic(js['kernel'], 5, 1)
+    assert t is None
+
+
+def test_committed_counter_files_match_the_tree():
+    """the driver's bench line lost `roofline.traffic` to a commit made after the counter pass.  The
+    committed counter files must carry the hash of the CURRENT code of the kernel they profiled (comment-stripped
+    vn_fused16.hip + vn_internal.h): a kernel edit without a re-run of tools/collect_profiles.sh +
+    tools/summarise_profiles.py fails here, in the CPU tier, before the driver's run can print traffic: null."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for cfg, name in bench.TRAFFIC_FILES.items():
+        path = os.path.join(ROOT, 'profiles', name)
+        assert os.path.exists(path), 'no counter file for config %d: run tools/collect_profiles.sh' % cfg
+        js = json.load(open(path))
+        assert js['config'] == cfg
+        assert js['kernel_source_sha256'] == bench.kernel_source_hash(js['kernel']), \
+            '%s predates the kernel code in the tree: re-run tools/collect_profiles.sh + tools/summarise_profiles.py' % name
+        t, src = bench.static_traffic(js['kernel'], cfg, 1)
+        assert t == js['hbm_bytes_per_launch'] and t > 0 and src.startswith('profiles/' + name)
+
+
+def test_kernel_hash_ignores_comments_and_layout_only():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = 'int f(int x) { /* doc */ return x + 1;   // one\n}\nconst char* s = "// not a comment";'
+    b = 'int f(int x) {\n    return x + 1;\n}\n// trailing words\nconst char* s = "// not a comment";'
+    c = 'int f(int x) { return x + 2; }\nconst char* s = "// not a comment";'
+    assert bench.strip_comments(a) == bench.strip_comments(b) != bench.strip_comments(c)
+    assert '// not a comment' in bench.strip_comments(a)
+    assert bench.kernel_source_hash('vn_fused16_kernel<5, 13, false>') == bench.kernel_source_hash('vn_fused16_kernel')
+    assert bench.kernel_source_hash('some_other_kernel') is None

@@ -84,6 +84,20 @@ def test_world4_uneven_blocks_match_world1(tmp_path):
     np.testing.assert_allclose(b['theta'], a['theta'], rtol=1e-7, atol=1e-10)
 
 
+def test_world8_uneven_blocks_match_world1(tmp_path):
+    """The driver's SCALE run ends at 8 ranks; the one-GPU boxes admit at most 6 processes on a card, so the 8-rank case
+    is rehearsed here on the CPU engine: eight towers over 35 test functions = blocks of 5 x 7 and an EMPTY eighth tower
+    (batchLen = ceil(35 / 8) = 5, VarNetUtility.py:825-838), BC/IC weights / 8 (:900-901), one SUM all-reduce per step."""
+    out = str(tmp_path)
+    _run(0, 1, _free_port(), out, None)
+    mp.spawn(_run, args=(8, _free_port(), out, None), nprocs=8, join=True)
+    a = np.load(os.path.join(out, 'out_w1_bNone.npz'))
+    b = np.load(os.path.join(out, 'out_w8_bNone.npz'))
+    np.testing.assert_allclose(b['w'] * np.array([8.0, 8.0, 1.0]), a['w'], rtol=1e-10)
+    np.testing.assert_allclose(b['loss'], a['loss'], rtol=1e-9)
+    np.testing.assert_allclose(b['theta'], a['theta'], rtol=1e-7, atol=1e-10)
+
+
 # ---- cases the round-1 review asked for ------------------------------------------------------------
 import multiprocessing
 from tests import rank_worker as rw
@@ -181,3 +195,29 @@ def test_failed_tower_does_not_wedge_the_controller(method, needle):
     assert rc == 0, val
     msg, dt, alive = val
     assert needle in msg and dt < 30 and alive == [], (msg, dt, alive)
+
+
+def _tower_bad_processor(q):
+    os.environ['VN_DIST_BACKEND'] = 'nccl'               # the reference's case: real devices are asked for
+    from varnet_amd.towers import TowerGroup
+    try:
+        TowerGroup(rw.FailingTower, (), {}, ['GPU:0', 'GPU:97'])
+        q.put((1, 'no error raised'))
+    except ValueError as e:
+        q.put((0, str(e)))
+    except Exception as e:                                # noqa: BLE001
+        q.put((1, '%s: %s' % (type(e).__name__, e)))
+
+
+def test_unavailable_processor_is_a_value_error_in_the_controller():
+    """the device check lives in the forked tower (the controller must not initialise the GPU), but the
+    reference raises ValueError('requested processor ... is unavailable!') for it (TFModel.py:121-124): the controller
+    re-raises a tower's ValueError under its own type instead of wrapping it into RuntimeError."""
+    ctx = _spawn_ctx()
+    q = ctx.Queue()
+    p = ctx.Process(target=_tower_bad_processor, args=(q,))
+    p.start()
+    rc, val = q.get(timeout=120)
+    p.join(30)
+    assert rc == 0, val
+    assert 'requested processor GPU:' in val and 'is unavailable!' in val

@@ -167,14 +167,45 @@ def test_bench_self_launch_two_ranks_gloo(tmp_path):
     assert js['per_rank'][0]['rows'] + js['per_rank'][1]['rows'] == js['config']['training_points_per_step']
 
 
-def _bench_child(q):
+def _bench_child(q, gpus=2, extra=()):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VN_DIST_BACKEND='gloo')
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1'],
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '3', '--warmup', '1'] + list(extra),
                        capture_output=True, text=True, env=env, timeout=800)
     q.put((r.returncode, r.stdout + '\n' + r.stderr))
+
+
+def test_bench_three_ranks_uneven_blocks_reproduce_the_one_rank_loss():
+    """Rehearsal of the driver's SCALE run with UNEVEN shards: 100 000 test functions over 3 ranks = 33 334 + 33 334 +
+    33 332 (VarNetUtility.py:825-838: batchLen = ceil(nt / puNum), the last tower takes the rest), BC/IC set replicated with
+    its weights / 3 (:900-901).  The three ranks share this box's GPU over gloo (the pool allows at most 6 processes on a
+    card, so the 8-rank case is rehearsed on the CPU engine: tests/test_distributed_gloo.py).  The whole-job loss after
+    the same 4 steps must equal the one-rank run's to fp32 summation order: a wrong shard boundary, a doubled BC/IC term
+    or a missed weight division all show up there."""
+    import json
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    lines = []
+    for gpus in (3, 1):
+        q = conftest.FORKSERVER.Queue()
+        p = conftest.FORKSERVER.Process(target=_bench_child, args=(q, gpus, ('--no-cpu-baseline', '--no-dedup', '--no-extra')))
+        p.start()
+        rc, text = q.get(timeout=900)
+        p.join(60)
+        assert rc == 0, text[-2000:]
+        lines.append(json.loads([ln for ln in text.splitlines() if ln.startswith('{')][-1]))
+    js, one = lines
+    q = js['config']['quad_points_per_test_function']
+    assert js['n_gpus'] == 3 and [r['rows'] for r in js['per_rank']] == [33334 * q, 33334 * q, 33332 * q]
+    assert sum(r['rows'] for r in js['per_rank']) == js['config']['training_points_per_step'] == 6400000
+    assert js['comm']['bc_ic_weight_divisor'] == 3 and js['comm']['payload_bytes'] == (10451 + 4) * 4
+    assert isinstance(js['comm']['rccl_version'], int) and js['comm']['rccl_version'] > 20000     # RCCL loads on this box
+    assert js['comm']['vn_comm_size'] == [1, 0]                     # gloo rehearsal: the collective is torch's, not the engine's
+    assert one['n_gpus'] == 1 and 'comm' not in one
+    la, lb = js['config']['loss_after'], one['config']['loss_after']
+    assert abs(la - lb) <= 2e-5 * abs(lb), (la, lb)
 
 
 def test_processors_list_in_one_user_process(tmp_path):

@@ -3,7 +3,7 @@
 # separate --pmc passes the roofline numbers in bench.py / DESIGN.md come from.  Outputs land in
 # gpurun_out/prof_<tag>/ ; tools/summarise_profiles.py copies the summaries into profiles/.
 # (--pmc runs carry --kernel-trace only: no sys/hip/hsa trace domains beside counters.)
-tag=${1:-r3}
+tag=${1:-r4}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd $root
@@ -15,6 +15,11 @@ rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- pytho
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VALU"; do
   t=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --kernel-trace -d $out/pmc_$t -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dedup --no-extra > $out/pmc_$t.log 2>&1
+done
+# config 2 (small step): HBM traffic + matrix-pipe counters of its own launch (bench.py quotes them in extra.config2_small_step)
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"; do
+  t=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace -d $out/c2pmc_$t -o p --output-format csv -- python3 bench.py --config 2 --steps 50 --warmup 5 --no-cpu-baseline --no-dedup > $out/c2pmc_$t.log 2>&1
 done
 # the other routes: two-pass fused (integNum 216) and the generic kernels (width 64)
 rocprofv3 --kernel-trace --stats -d $out/stats_q216 -o s --output-format csv -- python3 tools/q216_perf.py > $out/q216.txt 2>&1

@@ -1,0 +1,116 @@
+"""Exploration behind tests/test_exact_tables.py (round 4): how many epochs of the reference's own settings bring the trained
+field to the reference-held known answers, sampled along ONE run (the hook rides on VarNet.residual, which the training loop
+calls every saveFreq epochs).  Output -> gpurun_out/r4_explore_<case>.txt
+
+    python tools/explore_tables.py mor [epochs] | cfg1 [epochs] [scheme] | 2dt nx ny nb nt [epochs]
+"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.test_exact_tables import _mor_setup, tables, uf  # noqa: E402
+
+pi = np.pi
+case = sys.argv[1]
+os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+out = open(os.path.join(ROOT, 'gpurun_out', 'r4_explore_%s.txt' % '_'.join(sys.argv[1:]).replace(' ', '').replace('[', '').replace(']', '').replace(',', 'x')), 'w')
+
+
+def say(s):
+    print(s, flush=True)
+    out.write(s + '\n')
+    out.flush()
+
+
+def hook(vn, fn):
+    """fn(epoch_counter) runs whenever the loop's monitor (VarNet.residual) runs."""
+    orig, n = vn.residual, [0]
+
+    def wrapped(*a, **k):
+        n[0] += 1
+        fn(n[0])
+        return orig(*a, **k)
+    vn.residual = wrapped
+
+
+if case == 'mor':
+    epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 12000
+    inp, d3, d4, kappa = tables()
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'cexact_1dt.npz'))
+    vn = _mor_setup()
+    ev = lambda X, k: vn.evaluate(x=X[:, 0:1], t=X[:, 1:2], MORarg=[[k]])
+    t0 = time.time()
+    sf = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+    inner = inp[:, 0] <= 0.9
+
+    def mon(i):
+        u0, u1, u2 = ev(inp, kappa[0]), ev(inp, kappa[1]), ev(inp, 0.1 / pi)
+        gi = g['mor_input']
+        ex = uf.l2Err(g['c_mor_grid_D_0p1_over_pi'], ev(gi, 0.1 / pi))
+        ex_far = uf.l2Err(g['c_mor_grid_D_0p1_over_pi'], ev(gi, kappa[0]))
+        ex01 = uf.l2Err(g['c_mor_grid_D_0p1'], ev(gi, 0.1))
+        dd = uf.l2Err((d3 - d4)[inner], (u0 - u1)[inner])
+        say('epoch %6d  %6.0f s  correct %.4f %.4f  swapped %.4f %.4f  decade-away kappa on the tables %.4f %.4f  cExact(0.1/pi) %.4f '
+            '(net at kappa0: %.4f)  cExact(0.1) %.4f  inner diff metric %.4f  inner errs %.4f %.4f  loss %.4e'
+            % (i * sf, time.time() - t0, uf.l2Err(d3, u0), uf.l2Err(d4, u1), uf.l2Err(d4, u0), uf.l2Err(d3, u1), uf.l2Err(d3, u2),
+               uf.l2Err(d4, u2), ex, ex_far, ex01, dd, uf.l2Err(d3[inner], u0[inner]), uf.l2Err(d4[inner], u1[inner]),
+               vn.trainRes.lossAll[-1] if len(vn.trainRes.lossAll) else float('nan')))
+    hook(vn, mon)
+    np.random.seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        res = vn.train(tmp, weight=[10., 10., 1.], smpScheme='uniform', saveMORdata=True, batchNum=20, shuffleData=True,
+                       epochNum=epochs, saveFreq=sf, verbose=False)
+    import hashlib
+    say('done %d epochs in %.0f s, loss %.4e -> %.4e, theta sha %s' % (len(res.lossAll), time.time() - t0, res.lossAll[0], res.lossAll[-1],
+                                                                      hashlib.sha256(vn.engine.get_params().tobytes()).hexdigest()[:16]))
+
+elif case == 'cfg1':
+    from varnet_amd import ADPDE, Domain1D, VarNet
+    from tests.test_varnet_host import cExact
+    epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+    scheme = sys.argv[3] if len(sys.argv) > 3 else 'uniform'
+    width = eval(sys.argv[4]) if len(sys.argv) > 4 else [20, 20, 20]
+    pde = ADPDE(Domain1D(), diff=0.1 / pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0], IC=lambda x: -np.sin(pi * x), cEx=cExact)
+    vn = VarNet(pde, layerWidth=width, discNum=20, bDiscNum=None, tDiscNum=300)
+    sf = 10000
+    t0 = time.time()
+
+    def mon(i):
+        say('epoch %7d  %6.0f s  l2Err(fixData.cEx, evaluate()) %.5f' % (i * sf, time.time() - t0, uf.l2Err(vn.fixData.cEx, vn.evaluate())))
+    hook(vn, mon)
+    np.random.seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        res = vn.train(tmp, weight=[10., 10., 1.], smpScheme=scheme, adjustWeight=True, epochNum=epochs, saveFreq=sf, verbose=False,
+                       lossLag=32)
+    say('done %s %s: %d epochs in %.0f s, loss %.4e -> %.4e, training sets %s' % (scheme, width, len(res.lossAll), time.time() - t0,
+                                                                               res.lossAll[0], res.lossAll[-1], res.inpIter))
+
+elif case == '2dt':
+    from tests.test_varnet_gpu import op2dt
+    from tests.test_exact_tables import _l2err_2dt, GOLD2
+    nx, ny, nb, ntd = (int(a) for a in sys.argv[2:6])
+    epochs = int(sys.argv[6]) if len(sys.argv) > 6 else 20000
+    g = np.load(GOLD2)
+    width = eval(sys.argv[7]) if len(sys.argv) > 7 else [10, 20]
+    vn = op2dt(width, [nx, ny], nb, ntd)
+    sf = 2000
+    t0 = time.time()
+    T = float(g['params'][0])
+
+    def mon(i):
+        e_all = _l2err_2dt(lambda X: vn.evaluate(x=X[:, :2], t=X[:, 2:3]), g)
+        x = g['x']
+        e_T = uf.l2Err(g['c_all'][:, -1:], vn.evaluate(x=x, t=T * np.ones([len(x), 1])))
+        say('epoch %6d  %6.0f s  all time nodes %.4f  t=T %.4f' % (i * sf, time.time() - t0, e_all, e_T))
+    hook(vn, mon)
+    np.random.seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        res = vn.train(tmp, weight=[5., 1., 1.], smpScheme='uniform', epochNum=epochs, saveFreq=sf, verbose=False, lossLag=16)
+    say('done grid [%d,%d] b%d t%d (%d points): %d epochs in %.0f s, loss %.4e -> %.4e'
+        % (nx, ny, nb, ntd, vn.fixData.nT, len(res.lossAll), time.time() - t0, res.lossAll[0], res.lossAll[-1]))
+vn.engine.close()

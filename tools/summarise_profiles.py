@@ -51,35 +51,54 @@ if gen:
     json.dump(gen, open('profiles/%s_pmc_generic_bwd.json' % pre, 'w'), indent=1)
 st = glob.glob(src + '/stats/**/s_kernel_stats.csv', recursive=True)[0]
 shutil.copy(st, 'profiles/%s_fused16_kernel_stats.csv' % pre)
-tot = {}
-kfull = None
-for f in glob.glob(src + '/pmc_*/**/p_counter_collection.csv', recursive=True):
-    d = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if 'vn_fused16_kernel' in r['Kernel_Name']:
-            d[r['Counter_Name']].append(float(r['Counter_Value']))
-            kn = r['Kernel_Name']
-            kfull = kn[kn.index('vn_fused16_kernel'):].split('(')[0].strip()      # with its template arguments
-    for k, v in d.items():
-        v = sorted(v); tot[k] = v[len(v) // 2]
-    name = os.path.basename(os.path.dirname(os.path.dirname(f))) if 'pmc_' not in os.path.basename(os.path.dirname(f)) else os.path.basename(os.path.dirname(f))
-    shutil.copy(f, 'profiles/%s_%s_fused16.csv' % (pre, [p for p in f.split('/') if p.startswith('pmc_')][0].lower()))
-cyc = tot['GRBM_GUI_ACTIVE'] / 8.0
 sys.path.insert(0, '.')
 import bench
-out = {
-    'kernel': kfull, 'kernel_source_sha256': bench.kernel_source_hash(), 'workload': 'bench.py config 3 (6.4M points/step)',
-    'FETCH_SIZE_KB_per_launch': tot['FETCH_SIZE'], 'WRITE_SIZE_KB_per_launch': tot['WRITE_SIZE'],
-    'correction': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE taken as is',
-    'hbm_bytes_per_launch': (2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0,
-    'algorithmic_input_bytes_per_launch': 128224000,
-    'mfma': {'SQ_VALU_MFMA_BUSY_CYCLES': tot['SQ_VALU_MFMA_BUSY_CYCLES'], 'GRBM_GUI_ACTIVE_sum_over_8_XCD': tot['GRBM_GUI_ACTIVE'],
-             'shader_cycles_per_launch': cyc, 'mfma_pipe_utilisation': tot['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / cyc,
-             'SQ_LDS_IDX_ACTIVE': tot['SQ_LDS_IDX_ACTIVE'], 'SQ_LDS_BANK_CONFLICT': tot['SQ_LDS_BANK_CONFLICT'],
-             'lds_utilisation': tot['SQ_LDS_IDX_ACTIVE'] / 256.0 / cyc},
-    'waves': {k: tot[k] for k in ('SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU') if k in tot},
-    'round': pre, 'command': 'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-dedup',
-}
+
+
+def pmc_summary(prefix, config, workload, alg_bytes, command, copy_csv):
+    """Median per launch of every counter of the --pmc passes gpurun_out/prof_<tag>/<prefix>*/ for the dominant kernel."""
+    tot, kfull = {}, None
+    for f in glob.glob(src + '/' + prefix + '*/**/p_counter_collection.csv', recursive=True):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if 'vn_fused16_kernel' in r['Kernel_Name']:
+                d[r['Counter_Name']].append(float(r['Counter_Value']))
+                kn = r['Kernel_Name']
+                kfull = kn[kn.index('vn_fused16_kernel'):].split('(')[0].strip()      # with its template arguments
+        for k, v in d.items():
+            v = sorted(v); tot[k] = v[len(v) // 2]
+        if copy_csv:
+            shutil.copy(f, 'profiles/%s_%s_fused16.csv' % (pre, [q for q in f.split('/') if q.startswith(prefix)][0].lower()))
+    if 'FETCH_SIZE' not in tot or 'WRITE_SIZE' not in tot:
+        return None
+    out = {
+        'kernel': kfull, 'kernel_source_sha256': bench.kernel_source_hash(kfull), 'config': config, 'workload': workload,
+        'FETCH_SIZE_KB_per_launch': tot['FETCH_SIZE'], 'WRITE_SIZE_KB_per_launch': tot['WRITE_SIZE'],
+        'correction': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE taken as is',
+        'hbm_bytes_per_launch': (2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0,
+        'algorithmic_input_bytes_per_launch': alg_bytes, 'round': pre, 'command': command}
+    if 'GRBM_GUI_ACTIVE' in tot:
+        cyc = tot['GRBM_GUI_ACTIVE'] / 8.0
+        out['mfma'] = {'SQ_VALU_MFMA_BUSY_CYCLES': tot['SQ_VALU_MFMA_BUSY_CYCLES'], 'GRBM_GUI_ACTIVE_sum_over_8_XCD': tot['GRBM_GUI_ACTIVE'],
+                       'shader_cycles_per_launch': cyc, 'mfma_pipe_utilisation': tot['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / cyc,
+                       'SQ_LDS_IDX_ACTIVE': tot.get('SQ_LDS_IDX_ACTIVE'), 'SQ_LDS_BANK_CONFLICT': tot.get('SQ_LDS_BANK_CONFLICT'),
+                       'lds_utilisation': tot['SQ_LDS_IDX_ACTIVE'] / 256.0 / cyc if 'SQ_LDS_IDX_ACTIVE' in tot else None}
+    out['waves'] = {k: tot[k] for k in ('SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA',
+                                       'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES') if k in tot}
+    return out
+
+
+out = pmc_summary('pmc_', 3, 'bench.py config 3 (6.4M points/step)', 128224000,
+                  'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 '
+                  '--no-cpu-baseline --no-dedup --no-extra', True)
 json.dump(out, open('profiles/%s_pmc_traffic.json' % pre, 'w'), indent=1)
-json.dump(out, open('profiles/pmc_traffic.json', 'w'), indent=1)      # the file bench.py quotes `traffic` from
+json.dump(out, open('profiles/' + bench.TRAFFIC_FILES[3], 'w'), indent=1)      # the file bench.py quotes `traffic` from
 print(json.dumps(out, indent=1))
+# config 2 (1D+t, 160 000 points, 4x50): Input [nT,2] + gcoef [nT,1] + BC/IC rows, f32
+out2 = pmc_summary('c2pmc_', 2, 'bench.py --config 2 (160k points/step)', 160000 * 3 * 4 + 450 * 3 * 4,
+                   'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --config 2 --steps 50 '
+                   '--warmup 5 --no-cpu-baseline --no-dedup', False)
+if out2:
+    json.dump(out2, open('profiles/%s_pmc_traffic_cfg2.json' % pre, 'w'), indent=1)
+    json.dump(out2, open('profiles/' + bench.TRAFFIC_FILES[2], 'w'), indent=1)
+    print(json.dumps(out2, indent=1))

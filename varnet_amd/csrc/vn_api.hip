@@ -451,7 +451,7 @@ int load_rccl() {
 extern "C" {
 
 const char* vn_last_error(void) { return g_err.c_str(); }
-int vn_abi_version(void) { return VN_ABI_VERSION; }   // 4: vn_comm_available, validated Adam hyper-parameters (3: vn_config.widths[16], VN_KERNEL_LAYERED)
+int vn_abi_version(void) { return VN_ABI_VERSION; }   // 5: vn_comm_version; 4: vn_comm_available, validated Adam hyper-parameters (3: vn_config.widths[16], VN_KERNEL_LAYERED)
 
 int vn_create(const vn_config* cfg, vn_engine** out) {
   if (!cfg || !out) return fail(VN_EINVAL, "null argument");
@@ -1023,6 +1023,15 @@ int vn_residual_f64(vn_engine* h, const double* X, const double* diff, const dou
 
 // ---- tower gradient SUM over RCCL (TFModel.py:342-377) ------------------------------------
 int vn_comm_available(void) { return load_rccl(); }
+
+int vn_comm_version(int32_t* version_out) {
+  if (!version_out) return fail(VN_EINVAL, "null argument");
+  if (int rc = load_rccl()) return rc;
+  int v = 0;
+  RCCLCHK(g_rccl.GetVersion(&v));
+  *version_out = v;
+  return VN_OK;
+}
 
 int vn_comm_unique_id(void* id_out) {
   if (!id_out) return fail(VN_EINVAL, "null argument");

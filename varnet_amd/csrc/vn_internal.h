@@ -141,7 +141,7 @@ hipError_t vn_pointwise_residual_f64(const VnNet& net, const double* theta, cons
 
 // ---- layer-by-layer route for networks outside the kernels' range: vn_layered.hip ------------------
 // Activations of a chunk of rows in HBM, one GEMM per layer over the stacked (value, tangent [, derivative]) streams
-// (rocBLAS through dlopen), elementwise kernels in between.  All calls enqueue on `s`; errors come back as a message.
+// (the MFMA products of vn_gemm.hip), elementwise kernels in between.  All calls enqueue on `s`; errors come back as a message.
 struct VnLayered;
 int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errlen);
 void vn_layered_destroy(VnLayered* w);

@@ -12,9 +12,9 @@
 // one (S n) x H row-major matrix -- so every layer is ONE GEMM forward and TWO in the reverse pass, whatever S is
 // (S = 1: BC/IC rows and vn_forward; S = 2: interior rows; S = 1 + nd1 + dim: the strong residual with its first and
 // second derivative streams).  The GEMMs are the MFMA kernels of vn_gemm.hip (fp32 with the forward epilogue fused, fp64 for
-// the fp64 entry points); VN_LAYERED_ROCBLAS=1 runs the same products on rocBLAS instead (a cross-check: resolved with
-// dlopen at first use, atomics off), so libvarnet_hip.so neither links the library nor loads it otherwise.  Everything between
-// the GEMMs is hand-written below; all reductions have a fixed order, results are run-to-run reproducible.
+// the fp64 entry points): no vendor library is linked, loaded or named here (tests/test_layered_gpu.py checks the products
+// against library GEMMs from the outside).  Everything between the GEMMs is hand-written below; all reductions have a fixed
+// order, results are run-to-run reproducible.
 // Rows are processed in chunks sized to a fixed workspace.  The seeds need R_k of whole test functions first, so a gradient
 // evaluation is forward (all rows) -> seed kernel -> reverse (all rows): the forward KEEPS the activations of all rows in
 // HBM when they fit half of the free memory (6.4 M rows of a 3 x 256 net: 39 GB of the 288) and the reverse pass reads
@@ -24,9 +24,6 @@
 // when the stored activations do not fit, and serve the residual and fp64 entry points).
 #include "vn_internal.h"
 
-#include <dlfcn.h>
-#include <rocblas/rocblas.h>   // types and prototypes only: librocblas is dlopen'ed, never linked
-
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -34,21 +31,6 @@
 #include <vector>
 
 namespace {
-
-struct Blas {
-  void* dl = nullptr;
-  decltype(&rocblas_create_handle) create_handle = nullptr;
-  decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
-  decltype(&rocblas_set_stream) set_stream = nullptr;
-  decltype(&rocblas_set_atomics_mode) set_atomics_mode = nullptr;
-  decltype(&rocblas_sgemm) sgemm = nullptr;
-  decltype(&rocblas_sgemm_strided_batched) sgemm_strided_batched = nullptr;
-  decltype(&rocblas_dgemm) dgemm = nullptr;
-  decltype(&rocblas_sgemv) sgemv = nullptr;
-  decltype(&rocblas_dgemv) dgemv = nullptr;
-  decltype(&rocblas_status_to_string) status_to_string = nullptr;
-};
-Blas g_blas;
 
 int lfail(char* err, size_t n, const char* fmt, ...) {
   va_list ap;
@@ -58,74 +40,11 @@ int lfail(char* err, size_t n, const char* fmt, ...) {
   return 1;
 }
 
-int load_blas(char* err, size_t n) {
-  if (g_blas.dl) return 0;
-  const char* names[] = {getenv("VN_ROCBLAS_LIB"), "librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"};
-  void* dl = nullptr;
-  for (const char* nm : names) {
-    if (!nm || !*nm) continue;
-    dl = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-    if (dl) break;
-  }
-  if (!dl) return lfail(err, n, "rocBLAS not found (%s): set VN_ROCBLAS_LIB; it serves networks beyond %d layers / width %d",
-                        dlerror(), VN_KMAX_LAYERS, VN_KMAX_WIDTH);
-  Blas b;
-  b.dl = dl;
-#define VN_SYM(field, name)                                                     \
-  b.field = (decltype(b.field))dlsym(dl, name);                                 \
-  if (!b.field) { dlclose(dl); return lfail(err, n, "rocBLAS symbol %s missing", name); }
-  VN_SYM(create_handle, "rocblas_create_handle")
-  VN_SYM(destroy_handle, "rocblas_destroy_handle")
-  VN_SYM(set_stream, "rocblas_set_stream")
-  VN_SYM(set_atomics_mode, "rocblas_set_atomics_mode")
-  VN_SYM(sgemm, "rocblas_sgemm")
-  VN_SYM(sgemm_strided_batched, "rocblas_sgemm_strided_batched")
-  VN_SYM(dgemm, "rocblas_dgemm")
-  VN_SYM(sgemv, "rocblas_sgemv")
-  VN_SYM(dgemv, "rocblas_dgemv")
-  VN_SYM(status_to_string, "rocblas_status_to_string")
-#undef VN_SYM
-  g_blas = b;
-  return 0;
-}
-
-template <typename T> struct BlasT;
-template <> struct BlasT<float> {
-  static rocblas_status gemm(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* al,
-                             const float* A, int lda, const float* B, int ldb, const float* be, float* C, int ldc) {
-    return g_blas.sgemm(h, ta, tb, m, n, k, al, A, lda, B, ldb, be, C, ldc);
-  }
-  static rocblas_status gemv(rocblas_handle h, rocblas_operation t, int m, int n, const float* al, const float* A, int lda,
-                             const float* x, const float* be, float* y) {
-    return g_blas.sgemv(h, t, m, n, al, A, lda, x, 1, be, y, 1);
-  }
-};
-template <> struct BlasT<double> {
-  static rocblas_status gemm(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double* al,
-                             const double* A, int lda, const double* B, int ldb, const double* be, double* C, int ldc) {
-    return g_blas.dgemm(h, ta, tb, m, n, k, al, A, lda, B, ldb, be, C, ldc);
-  }
-  static rocblas_status gemv(rocblas_handle h, rocblas_operation t, int m, int n, const double* al, const double* A, int lda,
-                             const double* x, const double* be, double* y) {
-    return g_blas.dgemv(h, t, m, n, al, A, lda, x, 1, be, y, 1);
-  }
-};
-
 #define LHIP(expr)                                                                              \
   do {                                                                                          \
     hipError_t e_ = (expr);                                                                     \
     if (e_ != hipSuccess) return lfail(err, errlen, "%s: %s", #expr, hipGetErrorString(e_));    \
   } while (0)
-// rocBLAS probes its lazily loaded code objects with lookups that fail benignly ("Cannot find the function ...") and leave
-// the HIP runtime's sticky last-error set: it is cleared after every library call, or the next launch check of a kernel
-// of this file reports the library's stale error (seen as 'invalid argument' on the first 128-wide GEMM of a process).
-#define LBLAS(expr)                                                                             \
-  do {                                                                                          \
-    rocblas_status s_ = (expr);                                                                 \
-    (void)hipGetLastError();                                                                    \
-    if (s_ != rocblas_status_success) return lfail(err, errlen, "%s: %s", #expr, g_blas.status_to_string(s_)); \
-  } while (0)
-
 // VN_LAYERED_TRACE=1: stage markers on stderr with a stream sync in front of each (diagnosis of a fault: which stage)
 static bool g_trace = [] { const char* t = getenv("VN_LAYERED_TRACE"); return t && *t && *t != '0'; }();
 #define LTRACE(s_, ...)                                                        \
@@ -162,17 +81,6 @@ __global__ __launch_bounds__(EB) void k_pack_train(const float* __restrict__ X, 
   const int k = (int)(i % d_in);
   out[i] = X[i];
   if (S == 2) out[n * d_in + i] = (k < dim) ? G[r * dim + k] : 0.f;
-}
-
-// z (+ bias), zd  ->  a, ad in place
-__global__ __launch_bounds__(EB) void k_act_train(float* __restrict__ A, const float* __restrict__ bias, long n, int H, int S,
-                                                 int act) {
-  const long i = (long)blockIdx.x * EB + threadIdx.x;
-  if (i >= n * H) return;
-  const int c = (int)(i % H);
-  const float a = act_f<float>(A[i] + bias[c], act);
-  A[i] = a;
-  if (S == 2) A[n * H + i] *= act_s1<float>(a, act);
 }
 
 // adjoints of the last hidden layer: abar = ubar w_o^T, adbar = udbar w_o^T
@@ -411,9 +319,7 @@ inline unsigned blocks(long n) { return (unsigned)((n + EB - 1) / EB); }
 
 struct VnLayered {
   VnNet net{};
-  rocblas_handle handle = nullptr;  // created at first use: fp64 entry points, or every GEMM under VN_LAYERED_ROCBLAS=1
   int ncu = 256;
-  bool use_blas = false;            // VN_LAYERED_ROCBLAS=1 (diagnostic): library GEMMs for the fp32 passes instead of vn_gemm.hip
   long sumH = 0;           // sum of H[0..L]
   int hmax_all = 0;        // max of H[0..L]
   // one workspace, carved per call
@@ -482,53 +388,24 @@ int ensure_wt(VnLayered* w, size_t elems, char* err, size_t errlen) {
   return 0;
 }
 
-// rocBLAS is needed by the fp64 entry points (and by the fp32 passes only under VN_LAYERED_ROCBLAS=1): loaded and given
-// a handle at first use, so that a net trained in fp32 never loads the library.
-int ensure_blas(VnLayered* w, hipStream_t s, char* err, size_t errlen) {
-  if (!w->handle) {
-    if (int rc = load_blas(err, errlen)) return rc;
-    rocblas_status st = g_blas.create_handle(&w->handle);
-    (void)hipGetLastError();
-    if (st != rocblas_status_success) { w->handle = nullptr; return lfail(err, errlen, "rocblas_create_handle: %s", g_blas.status_to_string(st)); }
-    // no atomics: the weight-gradient GEMMs reduce over millions of rows and must give the same bits on every run
-    (void)g_blas.set_atomics_mode(w->handle, rocblas_atomics_not_allowed);
-  }
-  LBLAS(g_blas.set_stream(w->handle, s));
-  return 0;
-}
 #define LGEMM(expr)                                                                             \
   do {                                                                                          \
     int e_ = (expr);                                                                            \
     if (e_ != 0) return lfail(err, errlen, "%s: %s", #expr, hipGetErrorString((hipError_t)e_)); \
   } while (0)
 
-// dW (Hin x Hout, row-major) += A^T Zbar over M stacked rows.  The rows are cut into groups; one strided-batched GEMM
+// dW (Hin x Hout, row-major) += A^T Zbar over M stacked rows.  The rows are cut into groups; one launch of vn_gemm_tn_parts
 // gives a partial product per group (parallelism = groups x output tiles instead of output tiles), a fixed-order sum
 // adds them up.
 int wgrad_add(VnLayered* w, const float* A, const float* Zbar, long M, int Hin, int Hout, float* dW, hipStream_t s, char* err,
               size_t errlen) {
-  const long tiles = ((Hin + 127) / 128) * (long)((Hout + 127) / 128);
-  long rows = 8192;                                   // rows per group: about 1 000 workgroups for small layers ...
-  while (rows < M && tiles * ((M + rows - 1) / rows) > 2048) rows *= 2;   // ... and no more partials than needed for big ones
-  if (!w->use_blas) rows = vn_gemm_tn_rows(M, Hin, Hout, w->ncu);
+  const long rows = vn_gemm_tn_rows(M, Hin, Hout, w->ncu);     // rows per group that fill the chip evenly
   const int G = (int)(M / rows);                      // full groups; the ragged rest is one more GEMM
   const long rest = M - (long)G * rows;
   const int np = G + (rest > 0 ? 1 : 0);
   const long len = (long)Hin * Hout;
   if (int rc = ensure_part(w, (size_t)np * len, err, errlen)) return rc;
-  if (!w->use_blas) {
-    LGEMM(vn_gemm_tn_parts(A, Zbar, w->part, M, Hin, Hout, rows, s));          // np partial products, one launch
-  } else {
-    if (int rc = ensure_blas(w, s, err, errlen)) return rc;
-    const float one = 1.f, zero = 0.f;
-    // column-major: P_g'(Hout x Hin) = Zbar_g'(Hout x rows) A_g'(Hin x rows)^T
-    if (G > 0)
-      LBLAS(g_blas.sgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rows, &one,
-                                         Zbar, Hout, rows * Hout, A, Hin, rows * Hin, &zero, w->part, Hout, len, G));
-    if (rest > 0)
-      LBLAS(g_blas.sgemm(w->handle, rocblas_operation_none, rocblas_operation_transpose, Hout, Hin, (int)rest, &one,
-                         Zbar + (long)G * rows * Hout, Hout, A + (long)G * rows * Hin, Hin, &zero, w->part + (long)G * len, Hout));
-  }
+  LGEMM(vn_gemm_tn_parts(A, Zbar, w->part, M, Hin, Hout, rows, s));          // np partial products, one launch
   hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((len + 63) / 64)), dim3(64 * SUMG), 0, s, w->part, np, len, dW);
   LHIP(hipGetLastError());
   return 0;
@@ -539,50 +416,23 @@ template <typename T>
 long chunk_rows(long n, long per_row) {
   long c = (long)(WS_TARGET / ((size_t)per_row * sizeof(T)));
   if (c < 1024) c = 1024;
-  // the stacked GEMMs take S*c rows in a 32-bit rocblas_int
+  // the stacked GEMMs take S*c rows in a 32-bit int
   if (c > (1l << 26)) c = 1l << 26;
   return c < n ? (c & ~3l) : n;             // several chunks: a multiple of 4 rows, so that every chunk's matrices stay 16-byte aligned
 }
 
-// Z(M x Hout) = A(M x Hin) W(Hin x Hout), all row-major (fp32: vn_gemm.hip; fp64, or VN_LAYERED_ROCBLAS=1: the library, where
-// it is the column-major product  Z'(Hout x M) = W'(Hout x Hin) A'(Hin x M))
+// Z(M x Hout) = A(M x Hin) W(Hin x Hout), all row-major (vn_gemm.hip: fp32 and fp64 MFMA products)
 template <typename T>
 int gemm_fwd(VnLayered* w, long M, int Hin, int Hout, const T* A, const T* W, T* Z, hipStream_t s, char* err, size_t errlen) {
-  if constexpr (sizeof(T) == 4) {
-    if (!w->use_blas) {
-      LGEMM(vn_gemm_nn(A, W, Z, M, Hout, Hin, s));
-      return 0;
-    }
-  }
-  if constexpr (sizeof(T) == 8) {
-    if (!w->use_blas) {
-      LGEMM(vn_dgemm_nn(A, W, Z, M, Hout, Hin, s));
-      return 0;
-    }
-  }
-  if (int rc = ensure_blas(w, s, err, errlen)) return rc;
-  const T one = T(1), zero = T(0);
-  LBLAS(BlasT<T>::gemm(w->handle, rocblas_operation_none, rocblas_operation_none, Hout, (int)M, Hin, &one, W, Hout, A, Hin, &zero, Z, Hout));
+  if constexpr (sizeof(T) == 4) LGEMM(vn_gemm_nn(A, W, Z, M, Hout, Hin, s));
+  else LGEMM(vn_dgemm_nn(A, W, Z, M, Hout, Hin, s));
   return 0;
 }
 // y(M) = beta y + A(M x H) w
 template <typename T>
 int gemv_rows(VnLayered* w, long M, int H, const T* A, const T* x, T beta, T* y, hipStream_t s, char* err, size_t errlen) {
-  if constexpr (sizeof(T) == 4) {
-    if (!w->use_blas) {
-      LGEMM(vn_rowdot(A, x, y, M, H, beta, s));
-      return 0;
-    }
-  }
-  if constexpr (sizeof(T) == 8) {
-    if (!w->use_blas) {
-      LGEMM(vn_drowdot(A, x, y, M, H, beta, s));
-      return 0;
-    }
-  }
-  if (int rc = ensure_blas(w, s, err, errlen)) return rc;
-  const T one = T(1);
-  LBLAS(BlasT<T>::gemv(w->handle, rocblas_operation_transpose, H, (int)M, &one, A, H, x, &beta, y));
+  if constexpr (sizeof(T) == 4) LGEMM(vn_rowdot(A, x, y, M, H, beta, s));
+  else LGEMM(vn_drowdot(A, x, y, M, H, beta, s));
   return 0;
 }
 
@@ -592,8 +442,6 @@ int vn_layered_create(VnLayered** out, const VnNet& net, char* err, size_t errle
   *out = nullptr;
   VnLayered* w = new VnLayered();
   w->net = net;
-  const char* ub = getenv("VN_LAYERED_ROCBLAS");
-  w->use_blas = ub && *ub && *ub != '0';
   {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -620,7 +468,6 @@ void vn_layered_destroy(VnLayered* w) {
   if (!w) return;
   vn_wide_destroy(w->wide);
   if (w->wt) (void)hipFree(w->wt);
-  if (w->handle) (void)g_blas.destroy_handle(w->handle);      // (a handle exists only if the library was loaded)
   if (w->ws) (void)hipFree(w->ws);
   if (w->part) (void)hipFree(w->part);
   for (auto& k : w->kept) if (k.buf) (void)hipFree(k.buf);
@@ -636,14 +483,8 @@ int chunk_forward(VnLayered* w, const float* theta, const float* X, const float*
   hipLaunchKernelGGL(k_pack_train, dim3(blocks(c * net.d_in)), dim3(EB), 0, s, X, G, c, net.d_in, net.dim, S, act[0]);
   LHIP(hipGetLastError());
   for (int l = 1; l <= net.L; ++l) {
-    if (!w->use_blas) {
-      // product and layer epilogue in one kernel (vn_gemm.hip)
-      LGEMM(vn_gemm_fwd(act[l - 1], theta + net.woff[l], theta + net.boff[l], act[l], c, S, net.H[l], net.H[l - 1], net.actl[l], s));
-      continue;
-    }
-    if (int rc = gemm_fwd<float>(w, (long)S * c, net.H[l - 1], net.H[l], act[l - 1], theta + net.woff[l], act[l], s, err, errlen)) return rc;
-    hipLaunchKernelGGL(k_act_train, dim3(blocks(c * net.H[l])), dim3(EB), 0, s, act[l], theta + net.boff[l], c, net.H[l], S, net.actl[l]);
-    LHIP(hipGetLastError());
+    // product and layer epilogue in one kernel (vn_gemm.hip)
+    LGEMM(vn_gemm_fwd(act[l - 1], theta + net.woff[l], theta + net.boff[l], act[l], c, S, net.H[l], net.H[l - 1], net.actl[l], s));
   }
   return 0;
 }
@@ -753,7 +594,6 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
   if (kp) kp->valid = false;                        // theta moves after this step
   float *act[VN_MAX_LAYERS + 2], *adj[2];
   if (int rc = ensure_ws(w, (size_t)carve(w, c, S, true, act, adj, kept) * sizeof(float), err, errlen)) return rc;
-  const float one = 1.f, zero = 0.f;
   const int L = net.L, HL = net.H[L];
   long k = 0;
   for (long r0 = 0; r0 < seg.n; r0 += c, ++k) {
@@ -791,19 +631,13 @@ int vn_layered_backward(VnLayered* w, const float* theta, const VnRows& seg, flo
       LTRACE(s, "bwd layer %d colsum + wgrad done", l);
       if (l > 1) {
         // [abar; adbar]_{l-1} (M x Hin) = Zbar (M x Hout) W_l^T  ==  column-major (Hin x M) = W'(Hout x Hin)^T Zbar'(Hout x M)
-        if (!w->use_blas) {
-          // dA = Zb W^T as a plain product with the transposed weights (a few hundred KB, rewritten per call)
-          if (int rc = ensure_wt(w, (size_t)Hin * Hout, err, errlen)) return rc;
-          LGEMM(vn_transpose(theta + net.woff[l], w->wt, Hin, Hout, s));
-          LGEMM(vn_gemm_nn(cur, w->wt, nxt, M, Hin, Hout, s));
-          // (the reverse epilogue of layer l-1 fused into this product was built and measured: its loads of the stored
-          // (a | ad) in accumulator order cost what k_act_bwd costs -- 512,512: 2 128 us against 1 500 + 425 -- so it stays
-          // a separate, HBM-bound elementwise kernel)
-        } else {
-          if (int rc = ensure_blas(w, s, err, errlen)) return rc;
-          LBLAS(BlasT<float>::gemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, Hin, (int)M, Hout, &one,
-                                   theta + net.woff[l], Hout, cur, Hout, &zero, nxt, Hin));
-        }
+        // dA = Zb W^T as a plain product with the transposed weights (a few hundred KB, rewritten per call)
+        if (int rc = ensure_wt(w, (size_t)Hin * Hout, err, errlen)) return rc;
+        LGEMM(vn_transpose(theta + net.woff[l], w->wt, Hin, Hout, s));
+        LGEMM(vn_gemm_nn(cur, w->wt, nxt, M, Hin, Hout, s));
+        // (the reverse epilogue of layer l-1 fused into this product was built and measured: its loads of the stored
+        // (a | ad) in accumulator order cost what k_act_bwd costs -- 512,512: 2 128 us against 1 500 + 425 -- so it stays
+        // a separate, HBM-bound elementwise kernel)
         float* t = cur; cur = nxt; nxt = t;
       }
     }

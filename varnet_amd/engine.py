@@ -21,7 +21,7 @@ VN_MAX_DIN = 32
 VN_KMAX_LAYERS, VN_KMAX_WIDTH, VN_KMAX_DIN = 6, 64, 8
 VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED, VN_KERNEL_FUSED16, VN_KERNEL_LAYERED = 0, 1, 2, 3, 4
 VN_COMM_ID_BYTES = 128
-VN_ABI_VERSION = 4          # include/varnet_hip.h: load_library refuses a library that reports another number
+VN_ABI_VERSION = 5          # include/varnet_hip.h: load_library refuses a library that reports another number
 
 
 class VnConfig(C.Structure):
@@ -67,6 +67,7 @@ _SIGS = {
     'vn_residual': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_residual_f64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_comm_available': (C.c_int, []),
+    'vn_comm_version': (C.c_int, [C.POINTER(C.c_int32)]),
     'vn_comm_unique_id': (C.c_int, [C.c_void_p]),
     'vn_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'vn_comm_size': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -392,6 +393,12 @@ class VNEngine:
         return load_library().vn_comm_available() == 0
 
     @staticmethod
+    def comm_version():
+        """ncclGetVersion of the RCCL this process loaded (e.g. 22205), or None when it cannot be loaded."""
+        v = C.c_int32()
+        return int(v.value) if load_library().vn_comm_version(C.byref(v)) == 0 else None
+
+    @staticmethod
     def comm_unique_id():
         """128 opaque bytes (ncclUniqueId) made on ONE rank; ship them to every rank, then `comm_init`."""
         lib = load_library()
@@ -409,12 +416,17 @@ class VNEngine:
         self._ck(self.lib.vn_comm_init(self.h, int(rank), int(world), buf))
 
     def comm_init_from_torch(self, dist):
-        """Bootstrap through an initialised torch.distributed group.  Collective-safe: every rank walks through the SAME
-        sequence of collectives whatever fails where, so a rank without RCCL makes all ranks fall back instead of
-        leaving its peers in a broadcast or inside ncclCommInitRank.
-          1. every rank probes RCCL locally (no collective), MIN all-reduce of the flag;
-          2. only if all can load it: rank 0 makes the id inside try/except and ALWAYS broadcasts an (ok, id) pair;
-          3. all ranks call comm_init together, then agree (MIN) that it came up everywhere; else all destroy.
+        """Bootstrap through an initialised torch.distributed group.  Every rank walks through the SAME sequence of
+        collectives up to `comm_init`, and everything that can fail on ONE rank alone is checked before any rank enters
+        ncclCommInitRank (which has no timeout: a rank that never arrives leaves its peers inside it):
+          1. every rank probes locally, no collective: RCCL loads, the engine has no communicator yet, its GPU can be made
+             current; the (ok, device ordinal) pairs are all-gathered;
+          2. all ranks skip RCCL together if any probe failed, or if two ranks name the same GPU (RCCL refuses a device
+             that appears twice in a communicator: ranks sharing a card over gloo, VN_COMM=try);
+          3. rank 0 makes the id inside try/except and ALWAYS broadcasts an (ok, id) pair;
+          4. all ranks call comm_init together, then agree (MIN) that it came up everywhere; else all destroy.
+        What is NOT covered: a rank that dies, or whose ncclCommInitRank fails on its own, between 3 and 4 leaves its peers
+        in RCCL's bootstrap until RCCL gives up; the launcher (varnet_amd/launch.py, towers.py) ends the peers of a dead rank.
         Returns (True, '') when the communicator is up on every rank, (False, reason) when all ranks skipped it."""
         rank, world = dist.get_rank(), dist.get_world_size()
         t = self.torch
@@ -425,15 +437,26 @@ class VNEngine:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag.item()) == 1
 
-        why = ''
+        why, ordinal = '', -1
         try:
             mine = self.comm_available()
             if not mine:
                 why = self.lib.vn_last_error().decode()
+            elif self.comm_size()[0] != 1:
+                mine, why = False, 'this engine already has a communicator'
+            else:
+                ordinal = int(self.device.index)
+                t.cuda.set_device(ordinal)                   # what vn_comm_init's hipSetDevice would fail on
         except Exception as e:                       # noqa: BLE001  (a probe must not raise past the collective)
             mine, why = False, str(e)
-        if not all_ok(mine):
-            return False, why or 'RCCL is not loadable on another rank'
+        probes = [None] * world
+        dist.all_gather_object(probes, (bool(mine), ordinal, why))
+        bad = [(r, p[2]) for r, p in enumerate(probes) if not p[0]]
+        if bad:
+            return False, why or 'RCCL is not usable on rank %d: %s' % bad[0]
+        ordinals = [p[1] for p in probes]
+        if len(set(ordinals)) != world:
+            return False, 'ranks share a GPU (device ordinals %s): RCCL needs one device per rank' % ordinals
         box = [None]
         if rank == 0:
             try:

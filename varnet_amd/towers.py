@@ -35,9 +35,15 @@ def _tower_main(rank, world, port, conn, cls, args, kwargs, device, backend):
         import torch.distributed as dist
         # the GPU index is validated HERE, in the tower: the controller must not ask the runtime for a device count
         # (on ROCm that call can initialise HIP/HSA without torch noticing, and a fork must not inherit that)
-        if backend == 'nccl' or torch.cuda.is_available():        # (CPU-only rehearsals over gloo have no device to pick)
+        if backend == 'nccl':
             if device >= torch.cuda.device_count():
                 raise ValueError('requested processor GPU:%d is unavailable!' % device)      # TFModel.py:121-123
+            torch.cuda.set_device(device)
+        elif torch.cuda.is_available():
+            # rehearsal over another backend (VN_DIST_BACKEND=gloo): the towers share the cards there are, as bench.py's
+            # ranks do; a CPU-only rehearsal has no device to pick
+            device = device % torch.cuda.device_count()
+            os.environ['LOCAL_RANK'] = str(device)
             torch.cuda.set_device(device)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device))
@@ -45,8 +51,10 @@ def _tower_main(rank, world, port, conn, cls, args, kwargs, device, backend):
             dist.init_process_group(backend, rank=rank, world_size=world)
         vn = cls(*args, **kwargs)                       # inside a rank: takes its own entry of `processors`
         conn.send(('ready', None))
-    except Exception:
-        conn.send(('err', traceback.format_exc()))
+    except Exception as e:
+        # (tag, traceback text, exception type name, message): the controller re-raises argument errors under their
+        # own type, as the reference's single process would have raised them (TFModel.py:111-134)
+        conn.send(('err', traceback.format_exc(), type(e).__name__, str(e)))
         return
     while True:
         msg = conn.recv()
@@ -58,8 +66,8 @@ def _tower_main(rank, world, port, conn, cls, args, kwargs, device, backend):
             if name == 'simRes' and isinstance(r, dict):
                 r = {key: v for key, v in r.items() if key != 'grid'}
             conn.send(('ok', r if rank == 0 else None))
-        except Exception:
-            conn.send(('err', traceback.format_exc()))
+        except Exception as e:
+            conn.send(('err', traceback.format_exc(), type(e).__name__, str(e)))
     try:
         if getattr(vn, 'comm', 'none') == 'rccl':
             vn.engine.comm_destroy()
@@ -106,7 +114,7 @@ class TowerGroup:
         terminated (exact PIDs) and the error is raised."""
         pending = dict(enumerate(self.conns))
         sentinel = {p.sentinel: r for r, p in enumerate(self.procs)}
-        out, err = None, None
+        out, err, exc = None, None, RuntimeError
         while pending and err is None:
             ready = multiprocessing.connection.wait(list(pending.values()) + [s for s, r in sentinel.items() if r in pending])
             for obj in ready:
@@ -118,18 +126,21 @@ class TowerGroup:
                     continue
                 r = next(k for k, c in pending.items() if c is obj)
                 try:
-                    tag, val = obj.recv()
+                    msg = obj.recv()
                 except EOFError:
-                    tag, val = 'err', 'tower %d exited' % r
+                    msg = ('err', 'tower %d exited' % r)
+                tag, val = msg[0], msg[1]
                 del pending[r]
                 if tag == 'err':
                     err = 'tower %d failed:\n%s' % (r, val)
+                    if len(msg) >= 4 and msg[2] == 'ValueError':      # a rejected argument stays a ValueError (TFModel.py:124)
+                        exc, err = ValueError, '%s (tower %d)\n%s' % (msg[3], r, val)
                     break
                 if r == 0:
                     out = val
         if err is not None:
             self.close(kill=True)
-            raise RuntimeError(err)
+            raise exc(err)
         return out
 
     def call(self, name, *a, **k):
