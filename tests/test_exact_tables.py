@@ -1,18 +1,37 @@
 """
-The only reference-held numbers on the device path: the tabulated exact values (Mojtabi & Deville) that
-/root/reference/Operator_1Dt.py:113-128 and /root/reference/Operator_1DtMOR.py:117-150 keep for kappa = 0.01/pi and
-kappa = 0.005 (25 points each), and the reference's own acceptance metric l2Err(cEx, cApp) (Operator_1Dt.py:177-186,
-Operator_1DtMOR.py:214-224).  tests/golden/exact_tables.npz holds the arrays (oracle/gen_golden_tables.py).
+The reference-held known answers on the device path, and the chain  reference numbers -> oracle graph -> HIP engine:
 
-What is asserted on the GPU:
-  1. the HIP engine and the fp32 oracle (the CPU restatement of TFModel.py:515-714 + TF-1 Adam), trained for the same
-     fixed step budget from the same theta_0 on the Operator_1Dt set-up at kappa = 0.01/pi and on the Operator_1DtMOR
-     set-up, give the same field at the 25 tabulated points (FIELD_BAR), i.e. the same distance from the table;
-  2. a longer run of the HIP engine alone brings the trained field within a stated distance of the table (the
-     reference publishes no value of its own metric, so the distances are the ones measured here: TABLE_BAR_*).
+  * tabulated exact values (Mojtabi & Deville) for kappa = 0.01/pi and kappa = 0.005, 25 points each
+    (/root/reference/Operator_1Dt.py:113-128, /root/reference/Operator_1DtMOR.py:117-150) -> tests/golden/exact_tables.npz;
+  * the Fourier-series solution `cExact` of the 1D+t problem (/root/reference/Operator_1Dt.py:78-108; the parametrised copy
+    Operator_1DtMOR.py:77-110 that the MOR script evaluates at D = 0.1/pi, :226-229) -> tests/golden/cexact_1dt.npz
+    (oracle/gen_golden_cexact.py: the FunctionDefs cut out of the scripts with `ast` and run);
+  * the analytical solution `cExFun` of the 2D+t demo (/root/reference/Operator_2Dt.py:89-132) -> tests/golden/cexfun_2dt.npz;
+  * the reference's own acceptance metric l2Err(cEx, cApp) (Operator_1Dt.py:177-186, Operator_1DtMOR.py:214-234,
+    Operator_2Dt.py:174-183).
+
+What is asserted on the GPU (numbers -> gpurun_out/r4_exact_tables.json, copied to profiles/):
+  1. budget runs: the HIP engine and the fp32 oracle (the CPU restatement of TFModel.py:515-714 + TF-1 Adam), trained for the
+     same fixed step budget from the same theta_0, give the same field at the reference's points (FIELD_BAR);
+  2. CONVERGED runs with the scripts' own settings, the reference's metric against the reference-held answer at bars <= 0.2
+     that were written down BEFORE the test's first run, from the exploration runs committed as profiles/r4_explore_*.txt
+     (tools/explore_tables.py: the metric every 1000-2000 epochs along one run), and not raised afterwards;
+  3. discrimination: every known answer is matched by the network evaluated at ITS diffusivity several times better than
+     by the same network a decade away in kappa (see DISCRIMINATION below for what the two tables alone can and cannot tell);
+  4. the oracle leg at the converged theta*: fp64 oracle loss/gradient on mini-batches vs the engine's (1e-5 / 1e-4), oracle
+     forward at the reference's points vs `evaluate` (1e-6), and the ORACLE's own distance from the reference-held answer at
+     the same bars -- so the bars constrain the oracle graph, not only the HIP engine.
 Pairing: kappa = 0.01/pi <-> cExD3, kappa = 0.005 <-> cExD4; the reference's script swaps them
 (Operator_1DtMOR.py:216-224) -- not copied.
-The measured numbers go to gpurun_out/r3_exact_tables.json (copied to profiles/ by hand).
+
+DISCRIMINATION, stated honestly.  The two tables are 13 % apart in the metric (|d3 - d4| / |d3|), and almost all of that sits in
+the boundary layer x >= 0.98, which the [10,20,30] network does not resolve to that accuracy within 60 000 epochs of the script's
+settings (profiles/r4_explore_mor_60000.txt: correct pairing 0.09-0.13 / 0.04-0.16 from epoch 8000 on, the script's swapped pairing
+0.06-0.13 / 0.12-0.15 -- for kappa = 0.01/pi the smoother kappa = 0.005 table is often the CLOSER one, i.e. the trained boundary
+layer is too diffuse; the reference lets this run go to 500 000 epochs).  "Correct beats swapped on both" is therefore not a
+property the method has at any budget a test can afford, and it is not asserted.  What is asserted instead: away from the
+boundary layer (x <= 0.9) the network's kappa-sensitivity u(kappa_0) - u(kappa_1) is closer to the tables' difference d3 - d4
+than to zero; and each answer rejects the network evaluated a decade away in kappa by a factor >= 2.5.
 """
 import json
 import os
@@ -29,14 +48,24 @@ uf = UF()
 pi = np.pi
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'exact_tables.npz')
 
-# Measured (one MI355X, profiles/r3_exact_tables.json): field difference 3.1e-6 (Operator_1Dt, 3000 steps) and 8.1e-7
-# (Operator_1DtMOR, 240 steps); l2Err against the table 0.64599 on BOTH sides after 3000 steps, 0.326 after the 120 000-epoch
-# run of the script's own settings (0.159 on the points x <= 0.9, i.e. outside the boundary layer at x = 1 that a 20-unit
-# net on a 20 x 300 grid resolves last); Operator_1DtMOR 0.58 / 0.56 after 1500 of its epochs (loss 9.4e5 -> 1.6e5; the
-# reference lets it run to 500 000), longer runs in profiles/r3_exact_tables_long.txt.
-FIELD_BAR = 1e-4            # max |u_hip - u_oracle| at the tabulated points after the fixed budget (values are O(1))
-TABLE_BAR_1DT = 0.40        # l2Err(table, HIP field), Operator_1Dt set-up, 120 000 epochs
-TABLE_BAR_MOR = 0.65        # l2Err(table, HIP field), Operator_1DtMOR set-up, 1500 epochs, both diffusivities
+# ---- bars.  FIELD_BAR is a parity bar (HIP vs oracle).  The others are distances from reference-held answers in the reference's
+# own metric (1.0 = the zero function), every one <= 0.2, fixed before the tests' first run from the exploration runs
+# (profiles/r4_explore_*.txt); the measured values are in profiles/r4_exact_tables.json.
+FIELD_BAR = 1e-4            # max |u_hip - u_oracle| at the reference's points (values are O(1))
+# Operator_1DtMOR, the script's settings, 12 000 epochs (exploration: both tables 0.04-0.17 from epoch 7000 to 60000)
+MOR_EPOCHS = 12000
+MOR_TABLE_BAR = 0.20        # l2Err(table, field) for kappa = 0.01/pi (cExD3) and kappa = 0.005 (cExD4), all 25 points
+MOR_INNER_BAR = 0.08        # the same on the 12 points x <= 0.9, outside the boundary layer (exploration: 0.02-0.07 from epoch 8000)
+MOR_CEXACT_BAR = 0.05       # l2Err(cExact(D = 0.1/pi), field at kappa = 0.1/pi) on the script's 100 x 100 grid (exploration: 0.006-0.03)
+MOR_FAR_FACTOR = 2.5        # each answer rejects the network evaluated a decade away in kappa by this factor (exploration: 3.5-20)
+# BASELINE config 1 = Operator_1Dt at D = 0.1/pi with the 3x20 net, the script's settings, 100 000 epochs
+CFG1_EPOCHS = 100000
+CFG1_BAR = 0.05             # l2Err(fixData.cEx, evaluate()) (Operator_1Dt.py:177-186); exploration: 0.008-0.028 from epoch 20 000 to 300 000
+# Operator_2Dt problem, [40,20] x 40 grid (2.05 M training points), the script's net and weights, 20 000 epochs
+OP2_EPOCHS = 20000
+OP2_ALL_BAR = 0.20          # the script's metric over ALL 151 time nodes (Operator_2Dt.py:174-183); exploration: plateau 0.133-0.140 on the
+                            # [40,20] and on the script's own [80,40] grid alike (the t = 0 node is a discontinuous inlet profile)
+OP2_T_BAR = 0.12            # the same at t = T only (exploration: 0.092-0.099)
 
 
 def tables():
@@ -48,7 +77,7 @@ def record(key, value):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     try:
         os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, 'r3_exact_tables.json')
+        path = os.path.join(out, 'r4_exact_tables.json')
         data = json.load(open(path)) if os.path.exists(path) else {}
         data[key] = value
         json.dump(data, open(path, 'w'), indent=1, sort_keys=True)
@@ -114,27 +143,99 @@ def test_operator_1dt_tables_hip_vs_oracle():
     vn.engine.close()
 
 
+GOLD_CEX = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cexact_1dt.npz')
+
+
+def test_cexact_restatements_match_reference_outputs():
+    """The hand-written restatements of `cExact` used by the tests (tests/test_varnet_host.py) and by the demo
+    (examples/operator_1dt.py) against the outputs of the reference's own function (cut out of Operator_1Dt.py:78-108 and
+    run, oracle/gen_golden_cexact.py): scattered points incl. the initial line and both boundaries, and the 6 000-point
+    grid of the script's acceptance metric.  The MOR script's parametrised copy agrees with it at D = 0.1/pi."""
+    import importlib.util
+    from tests.test_varnet_host import cExact
+    g = np.load(GOLD_CEX)
+    np.testing.assert_allclose(g['params'], [1.0, 0.1 / pi, 2.0])
+    np.testing.assert_array_equal(g['c'], g['c_mor_D_0p1_over_pi'])
+    assert bool(g['mor_refuses_small_D'])                                  # Operator_1DtMOR.py:86-87
+    ui = g['uniform_input']
+    for name, fn in (('tests', cExact),):
+        np.testing.assert_allclose(fn(g['x'].copy(), g['t'].copy()), g['c'], rtol=1e-12, atol=1e-14, err_msg=name)
+        np.testing.assert_allclose(fn(ui[:, 0:1].copy(), ui[:, 1:2].copy()), g['c_uniform'], rtol=1e-12, atol=1e-14, err_msg=name)
+    spec = importlib.util.spec_from_file_location('ex_operator_1dt', os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'examples', 'operator_1dt.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    np.testing.assert_allclose(ex.cExact(g['x'].copy(), g['t'].copy()), g['c'], rtol=1e-12, atol=1e-14)
+    # the fixture's grid is the package's own uniform_input for discNum = 20, tDiscNum = 300 (built there from the formulas)
+    vn_ui = _config1_problem(engine=False)
+    np.testing.assert_allclose(vn_ui, ui, rtol=0, atol=1e-14)
+    on_ic = g['t'][:, 0] == 0
+    assert on_ic.sum() == 21 and np.allclose(g['c'][on_ic, 0], -np.sin(pi * g['x'][on_ic, 0]))
+
+
+def _config1_problem(engine=True):
+    """BASELINE config 1: Operator_1Dt.py:144-161 (D = 0.1/pi, cEx = cExact) with the 3 x 20 net."""
+    from tests.test_varnet_host import cExact
+    pde = ADPDE(Domain1D(), diff=0.1 / pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
+                IC=lambda x: -np.sin(pi * x), cEx=cExact)
+    if not engine:                                   # CPU tier: only the discretisation (no engine is created)
+        from varnet_amd.varnet import FIXData
+
+        class Shell:
+            pass
+        sh = VarNet.__new__(VarNet)
+        sh.PDE, sh.dim, sh.discNum, sh.bDiscNum, sh.tDiscNum, sh.MORdiscScheme = pde, 1, 20, None, 300, None
+        return FIXData(sh).uniform_input
+    return VarNet(pde, layerWidth=[20, 20, 20], discNum=20, bDiscNum=None, tDiscNum=300)
+
+
 @pytest.mark.gpu
-def test_operator_1dt_tables_long_run(tmp_path):
-    """Operator_1Dt.py:170 as the script runs it (residual-driven sampling, adjustWeight), bounded to 120 000 epochs,
-    then its own metric against its own table (Operator_1Dt.py:181-186)."""
-    inp, d3, _, _ = tables()
-    vn = _op1dt_advective()
+def test_config1_converged_run_against_cexact(tmp_path):
+    """BASELINE config 1 trained as the script trains it (Operator_1Dt.py:170: smpScheme='optimal', adjustWeight=True),
+    bounded to 100 000 epochs, then the script's acceptance metric l2Err(fixData.cEx, evaluate()) (:177-186) against the
+    reference-generated fixture of its own `cExact`; then the oracle leg at the converged theta*."""
+    g = np.load(GOLD_CEX)
+    vn = _config1_problem()
+    fd, eng = vn.fixData, vn.engine
+    assert fd.nT == 96000 and eng.P == 921
+    np.testing.assert_allclose(fd.cEx, g['c_uniform'], rtol=1e-12, atol=1e-14)      # the metric's cEx IS the reference's output
     np.random.seed(0)
-    res = vn.train(str(tmp_path), weight=[10., 10., 1.], smpScheme='optimal', adjustWeight=True, epochNum=120000,
-                   saveFreq=2000, verbose=False)
-    u = vn.evaluate(x=inp[:, 0:1], t=inp[:, 1:2])
-    e = float(uf.l2Err(d3, u))
-    interior = inp[:, 0] <= 0.9
-    e_in = float(uf.l2Err(d3[interior], u[interior]))
-    record('operator_1dt_kappa_0.01_over_pi_long', dict(epochs=len(res.lossAll), l2Err_table_hip=e,
-                                                         l2Err_table_hip_x_le_0p9=e_in,
-                                                         loss_first_last=[float(res.lossAll[0]), float(res.lossAll[-1])]))
-    print('1Dt tables, long run: l2Err %.5f (x <= 0.9: %.5f) after %d epochs' % (e, e_in, len(res.lossAll)))
-    assert e <= TABLE_BAR_1DT
-    vn.engine.close()
+    res = vn.train(str(tmp_path), weight=[10., 10., 1.], smpScheme='optimal', adjustWeight=True, epochNum=CFG1_EPOCHS,
+                   saveFreq=10000, verbose=False)
+    u = vn.evaluate()                                                                # Operator_1Dt.py:179
+    e_hip = float(uf.l2Err(g['c_uniform'], u))
+    # oracle leg at theta*
+    theta = eng.get_params().astype(np.float64)
+    u_o = og.forward(theta, 2, [20, 20, 20], torch.float64, fd.uniform_input)
+    e_orc = float(uf.l2Err(g['c_uniform'], u_o))
+    fdiff = float(np.max(np.abs(u - u_o)))
+    from tests.test_operator_parity_gpu import oracle_kwargs
+    td = vn._build_tdata()
+    td.select_mor(0)
+    w = np.array([3.0, 2.0, 5.0])
+    eng.set_weights(w)
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    gh = gb.cpu().numpy().astype(np.float64)
+    kw = oracle_kwargs(vn, td, w)
+    kw = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in kw.items()}
+    ref, gref = og.loss_and_grad(theta, 2, [20, 20, 20], torch.float64, **kw)
+    lerr = abs(gh[eng.P] - ref['loss']) / abs(ref['loss'])
+    gerr = float(np.max(np.abs(gh[:eng.P] - gref)) / np.max(np.abs(gref)))
+    record('config1_converged', dict(epochs=len(res.lossAll), l2Err_cExact_hip=e_hip, l2Err_cExact_oracle_at_theta_star=e_orc,
+                                     max_field_diff_hip_vs_oracle=fdiff, loss_rel_err_at_theta_star=float(lerr),
+                                     grad_rel_err_at_theta_star=gerr, loss_first_last=[float(res.lossAll[0]), float(res.lossAll[-1])],
+                                     training_sets_redrawn_at=list(res.inpIter), bar=CFG1_BAR))
+    print('config 1, %d epochs: l2Err(cExact) hip %.5f oracle %.5f, field diff %.1e, loss/grad err at theta* %.1e / %.1e'
+          % (len(res.lossAll), e_hip, e_orc, fdiff, lerr, gerr))
+    assert e_hip <= CFG1_BAR and e_orc <= CFG1_BAR
+    assert fdiff <= 2e-6                                    # fp32 forward vs fp64 oracle at the same parameters
+    assert lerr <= 1e-5 and gerr <= 1e-4
+    eng.close()
 
 
+# ---------------------------------------------------------------------------------------------------------
 # ---------------------------------------------------------------------------------------------------------
 def _mor_setup():
     """Operator_1DtMOR.py:163-196."""
@@ -218,23 +319,82 @@ def test_operator_1dtmor_tables_hip_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_operator_1dtmor_tables_long_run(tmp_path):
-    """Operator_1DtMOR.py:204 as the script runs it (uniform sampling, 20 shuffled mini-batches per kappa,
-    saveMORdata), bounded to 1500 epochs = 180 000 Adam steps; then Operator_1DtMOR.py:214-224 with the tables
-    paired with the diffusivity they were tabulated for."""
+def test_operator_1dtmor_converged_run_against_the_known_answers(tmp_path):
+    """Operator_1DtMOR.py:204 as the script runs it (uniform sampling, 20 shuffled mini-batches per kappa, saveMORdata),
+    bounded to 12 000 epochs = 1.44 M Adam steps (about a minute); then Operator_1DtMOR.py:214-229: the two tables, each
+    paired with the diffusivity it was tabulated for, and `cExact` at D = 0.1/pi on the script's 100 x 100 grid; the
+    discrimination checks of the module docstring; the oracle leg at theta*."""
     inp, d3, d4, kappa = tables()
+    g = np.load(GOLD_CEX)
+    grid, c_grid = g['mor_input'], g['c_mor_grid_D_0p1_over_pi']
+    k_far = 0.1 / pi
     vn = _mor_setup()
+    fd, eng = vn.fixData, vn.engine
     np.random.seed(0)
     res = vn.train(str(tmp_path), weight=[10., 10., 1.], smpScheme='uniform', saveMORdata=True, batchNum=20,
-                   shuffleData=True, epochNum=1500, saveFreq=500, verbose=False)
-    ev = lambda X, k: vn.evaluate(x=X[:, 0:1], t=X[:, 1:2], MORarg=[[k]])
-    e = _mor_errors(ev, inp, d3, d4, kappa)
-    swapped = [float(uf.l2Err(d4, ev(inp, kappa[0]))), float(uf.l2Err(d3, ev(inp, kappa[1])))]
-    record('operator_1dtmor_long', dict(epochs=len(res.lossAll), l2Err_table_hip=e, l2Err_with_the_scripts_swapped_pairing=swapped,
-                                         loss_first_last=[float(res.lossAll[0]), float(res.lossAll[-1])]))
-    print('MOR tables, long run: l2Err kappa=0.01/pi %.5f, kappa=0.005 %.5f (swapped pairing: %.5f %.5f)' % (e[0], e[1], swapped[0], swapped[1]))
-    assert max(e) <= TABLE_BAR_MOR
-    vn.engine.close()
+                   shuffleData=True, epochNum=MOR_EPOCHS, saveFreq=2000, verbose=False)
+    ev = lambda X, k: vn.evaluate(x=X[:, 0:1], t=X[:, 1:2], MORarg=[[k]])          # Operator_1DtMOR.py:217
+    theta = eng.get_params().astype(np.float64)
+    ev_o = lambda X, k: og.forward(theta, 3, [10, 20, 30], torch.float64, np.hstack([X, k * np.ones([X.shape[0], 1])]))
+    inner = inp[:, 0] <= 0.9
+    out = {}
+    for name, f in (('hip', ev), ('oracle_at_theta_star', ev_o)):
+        u0, u1, uf_ = f(inp, kappa[0]), f(inp, kappa[1]), f(inp, k_far)
+        out[name] = dict(
+            correct=[float(uf.l2Err(d3, u0)), float(uf.l2Err(d4, u1))],
+            scripts_swapped_pairing=[float(uf.l2Err(d4, u0)), float(uf.l2Err(d3, u1))],
+            inner_points=[float(uf.l2Err(d3[inner], u0[inner])), float(uf.l2Err(d4[inner], u1[inner]))],
+            tables_vs_net_a_decade_away=[float(uf.l2Err(d3, uf_)), float(uf.l2Err(d4, uf_))],
+            inner_sensitivity=float(uf.l2Err((d3 - d4)[inner], (u0 - u1)[inner])),
+            cexact_grid=float(uf.l2Err(c_grid, f(grid, k_far))),
+            cexact_grid_vs_net_at_kappa0=float(uf.l2Err(c_grid, f(grid, kappa[0]))))
+    fdiff = max(float(np.max(np.abs(ev(inp, k) - ev_o(inp, k)))) for k in (kappa[0], kappa[1], k_far))
+    fdiff = max(fdiff, float(np.max(np.abs(ev(grid, k_far) - ev_o(grid, k_far)))))
+    # oracle loss / gradient at theta* on one mini-batch of three of the six diffusivity batches (unshuffled feeds)
+    _silence(vn)
+    td = vn._build_tdata(batchNum=20)
+    w = np.array([3.0, 2.0, 5.0])
+    eng.set_weights(w)
+    gb = eng.bind_grad_buffer()
+    q, errs = fd.integNum, []
+    f64 = lambda t: t.cpu().numpy().astype(np.float64)
+    torch.set_num_threads(16)
+    for mb, bi in ((0, 0), (2, 7), (5, 19)):
+        td.select_mor(mb)
+        eng.grad(td.engine_batch(mb, bi))
+        torch.cuda.synchronize()
+        gh = gb.cpu().numpy().astype(np.float64)
+        d = td.mor[mb]
+        n0, n1 = td.block(bi)
+        n = (n1 - n0) * q
+        ref, gref = og.loss_and_grad(
+            theta, 3, [10, 20, 30], torch.float64, Input=f64(d['Input'][n0 * q:n1 * q]), gcoef=f64(d['gcoef'][n0 * q:n1 * q]),
+            source=None, N=np.tile(fd.N, n1 - n0).reshape(n, 1).astype(np.float32).astype(np.float64),
+            dNt=np.tile(fd.dNt, n1 - n0).reshape(n, 1).astype(np.float32).astype(np.float64), integW=None,
+            intShape=[n1 - n0, q], detJ=float(np.float32(fd.detJ)), detJvec=False, biInput=f64(d['biInput']),
+            biLabel=f64(d['biLabel']).reshape(-1, 1), bDof=fd.bDofsum, biDimVal=float(fd.biDimVal), w=w, dim=1,
+            time_dependent=True, is_source=False, integWflag=False)
+        errs.append((abs(gh[eng.P] - ref['loss']) / abs(ref['loss']), float(np.max(np.abs(gh[:eng.P] - gref)) / np.max(np.abs(gref)))))
+    out.update(epochs=len(res.lossAll), adam_steps=120 * len(res.lossAll), loss_first_last=[float(res.lossAll[0]), float(res.lossAll[-1])],
+               max_field_diff_hip_vs_oracle=fdiff, loss_grad_rel_err_at_theta_star=[[float(a), float(b)] for a, b in errs],
+               tables_relative_distance=float(uf.l2Err(d3, d4)),
+               bars=dict(table=MOR_TABLE_BAR, inner=MOR_INNER_BAR, cexact=MOR_CEXACT_BAR, far_factor=MOR_FAR_FACTOR))
+    record('operator_1dtmor_converged', out)
+    print('MOR converged run: %s' % json.dumps(out['hip']))
+    for name in ('hip', 'oracle_at_theta_star'):
+        o = out[name]
+        assert max(o['correct']) <= MOR_TABLE_BAR, (name, o)
+        assert max(o['inner_points']) <= MOR_INNER_BAR, (name, o)
+        assert o['cexact_grid'] <= MOR_CEXACT_BAR, (name, o)
+        # discrimination: every answer rejects the network evaluated a decade away in kappa ...
+        assert o['tables_vs_net_a_decade_away'][0] >= MOR_FAR_FACTOR * o['correct'][0], (name, o)
+        assert o['tables_vs_net_a_decade_away'][1] >= MOR_FAR_FACTOR * o['correct'][1], (name, o)
+        assert o['cexact_grid_vs_net_at_kappa0'] >= MOR_FAR_FACTOR * o['cexact_grid'], (name, o)
+        # ... and outside the boundary layer the kappa-sensitivity follows the tables' difference (1.0 = no sensitivity at all)
+        assert o['inner_sensitivity'] < 1.0, (name, o)
+    assert fdiff <= 2e-6
+    assert max(a for a, _ in errs) <= 1e-5 and max(b for _, b in errs) <= 1e-4, errs
+    eng.close()
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -242,7 +402,6 @@ def test_operator_1dtmor_tables_long_run(tmp_path):
 # known answer behind BASELINE config 3's problem.  tests/golden/cexfun_2dt.npz = outputs of the reference's own function
 # (oracle/gen_golden_cexfun.py); the metric is the script's: l2Err over ALL 151 time nodes (Operator_2Dt.py:174-183).
 GOLD2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cexfun_2dt.npz')
-TABLE_BAR_2DT = 0.40        # l2Err(cExFun, HIP field) over all 151 time nodes, down-scaled Operator_2Dt ([20,10] grid), 6000 epochs: measured 0.307
 
 
 def test_cexfun_restatement_matches_reference_outputs():
@@ -267,7 +426,7 @@ def _l2err_2dt(forward, g):
 
 
 @pytest.mark.gpu
-def test_operator_2dt_analytic_hip_vs_oracle_and_long_run(tmp_path):
+def test_operator_2dt_budget_run_hip_vs_oracle():
     from tests.test_operator_parity_gpu import run_both
     from tests.test_varnet_gpu import op2dt
     g = np.load(GOLD2)
@@ -276,13 +435,36 @@ def test_operator_2dt_analytic_hip_vs_oracle_and_long_run(tmp_path):
     e_g = _l2err_2dt(lambda X: vn.evaluate(x=X[:, :2], t=X[:, 2:3]), g)
     e_c = _l2err_2dt(lambda X: og.forward(th_c.astype(np.float64), 3, [10, 20], torch.float64, X), g)
     dev = float(np.max(np.abs(gl - cl) / np.abs(cl)))
+    record('operator_2dt_budget', dict(budget_steps=400, max_rel_loss_dev=dev, l2Err_cExFun_hip=e_g, l2Err_cExFun_oracle=e_c))
     assert dev <= 1e-2 and abs(e_g - e_c) <= 1e-4, (dev, e_g, e_c)
-    vn.engine.init_params(seed=0)
-    res = vn.train(str(tmp_path), weight=[5., 1., 1.], smpScheme='uniform', epochNum=6000, saveFreq=2000, verbose=False, lossLag=16)
-    e_long = _l2err_2dt(lambda X: vn.evaluate(x=X[:, :2], t=X[:, 2:3]), g)
-    record('operator_2dt_downscaled', dict(budget_steps=400, max_rel_loss_dev=dev, l2Err_cExFun_hip=e_g, l2Err_cExFun_oracle=e_c,
-                                            long_epochs=len(res.lossAll), l2Err_cExFun_hip_long=e_long,
-                                            loss_first_last=[float(res.lossAll[0]), float(res.lossAll[-1])]))
-    print('2Dt analytic: 400 steps l2Err hip %.5f oracle %.5f (loss dev %.1e); %d epochs: %.5f' % (e_g, e_c, dev, len(res.lossAll), e_long))
-    assert e_long <= TABLE_BAR_2DT
     vn.engine.close()
+
+
+@pytest.mark.gpu
+def test_operator_2dt_converged_run_against_the_analytical_solution(tmp_path):
+    """Operator_2Dt.py:136-167 (the script's net [10,20] and weights [5,1,1]) on a [40,20] x 40 grid = 2.05 M training points,
+    20 000 epochs; then the script's metric (:174-183) over all 151 time nodes against the reference-generated outputs of
+    `cExFun`, the same at t = T, and the oracle's own distance at theta*."""
+    from tests.test_varnet_gpu import op2dt
+    g = np.load(GOLD2)
+    vn = op2dt([10, 20], [40, 20], 20, 40)
+    eng = vn.engine
+    np.random.seed(0)
+    res = vn.train(str(tmp_path), weight=[5., 1., 1.], smpScheme='uniform', epochNum=OP2_EPOCHS, saveFreq=4000, verbose=False, lossLag=16)
+    x, T = g['x'], float(g['params'][0])
+    theta = eng.get_params().astype(np.float64)
+    fwd = {'hip': lambda X: vn.evaluate(x=X[:, :2], t=X[:, 2:3]),
+           'oracle_at_theta_star': lambda X: og.forward(theta, 3, [10, 20], torch.float64, X)}
+    out = {}
+    XT = np.hstack([x, T * np.ones([len(x), 1])])
+    for name, f in fwd.items():
+        out[name] = dict(all_time_nodes=_l2err_2dt(f, g), at_T=float(uf.l2Err(g['c_all'][:, -1:], f(XT))))
+    fdiff = float(np.max(np.abs(fwd['hip'](XT) - fwd['oracle_at_theta_star'](XT))))
+    out.update(epochs=len(res.lossAll), training_points=int(vn.fixData.nT), loss_first_last=[float(res.lossAll[0]), float(res.lossAll[-1])],
+               max_field_diff_hip_vs_oracle=fdiff, bars=dict(all_time_nodes=OP2_ALL_BAR, at_T=OP2_T_BAR))
+    record('operator_2dt_converged', out)
+    print('2Dt converged run: %s' % json.dumps(out))
+    for name in fwd:
+        assert out[name]['all_time_nodes'] <= OP2_ALL_BAR and out[name]['at_T'] <= OP2_T_BAR, (name, out[name])
+    assert fdiff <= 2e-6
+    eng.close()

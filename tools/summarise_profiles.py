@@ -4,53 +4,56 @@ import csv, collections, glob, json, os, shutil, sys
 tag, pre = sys.argv[1], sys.argv[2]
 src = 'gpurun_out/prof_%s' % tag
 os.makedirs('profiles', exist_ok=True)
-shutil.copy(src + '/bench.json', 'profiles/%s_bench_default.json' % pre)
-for extra, dst in (('bench_cfg2.json', '%s_bench_cfg2.json'), ('shard_perf.txt', '%s_shard_perf.txt'), ('mor_perf.txt', '%s_mor_perf.txt'),
-                   ('q216.txt', '%s_q216_perf.txt'), ('generic_w64.txt', '%s_generic_w64_perf.txt'), ('width60.txt', '%s_width60_perf.txt')):
-    if os.path.exists(src + '/' + extra):
-        shutil.copy(src + '/' + extra, 'profiles/' + dst % pre)
-for sub, dst in (('stats_q216', '%s_twopass_q216_kernel_stats.csv'), ('stats_generic', '%s_generic_w64_kernel_stats.csv')):
-    g = glob.glob(src + '/' + sub + '/**/s_kernel_stats.csv', recursive=True)
-    if g:
-        shutil.copy(g[0], 'profiles/' + dst % pre)
-tp = {}
-for f in glob.glob(src + '/tpmc_*/**/p_counter_collection.csv', recursive=True):
-    d = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        for kn in ('vn_fused16_kernel', 'vn_seed_kernel'):
-            if kn in r['Kernel_Name']:
-                d[kn][r['Counter_Name']].append(float(r['Counter_Value']))
-    for kn, dd in d.items():
-        for k, v in dd.items():
-            v = sorted(v)
-            # the fused kernel runs twice per step (forward-only, then reverse with seeds): report both halves
-            tp.setdefault(kn, {})[k] = {'min': v[0], 'median': v[len(v) // 2], 'max': v[-1], 'launches': len(v)}
-if tp:
-    tp['note'] = ('two-pass route at integNum 216 (tools/q216_perf.py: 30 000 test functions x 216 points, 5x50): per launch; '
-                  'vn_fused16_kernel is launched in forward-only mode (min column) and in reverse mode (max column) each step; '
-                  'MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / (GRBM_GUI_ACTIVE / 8)')
-    json.dump(tp, open('profiles/%s_pmc_twopass.json' % pre, 'w'), indent=1)
-gen = {}
-for f in glob.glob(src + '/gpmc_*/**/p_counter_collection.csv', recursive=True):
-    d = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if 'vn_generic_bwd_kernel' in r['Kernel_Name']:
-            d[r['Counter_Name']].append(float(r['Counter_Value']))
-    for k, v in d.items():
-        v = sorted(v); gen[k] = v[len(v) // 2]
-if gen:
-    cyc = gen.get('GRBM_GUI_ACTIVE', 0) / 8.0
-    gen['derived'] = {'shader_cycles_per_launch': cyc,
-                      'mfma_pipe_utilisation': gen.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024.0 / cyc if cyc else None,
-                      'lds_utilisation': gen.get('SQ_LDS_IDX_ACTIVE', 0) / 256.0 / cyc if cyc else None,
-                      'lds_conflict_share': gen.get('SQ_LDS_BANK_CONFLICT', 0) / max(gen.get('SQ_LDS_IDX_ACTIVE', 1), 1),
-                      'wait_any_share': gen.get('SQ_WAIT_ANY', 0) / max(gen.get('SQ_WAVE_CYCLES', 1), 1),
-                      'wait_inst_share': gen.get('SQ_WAIT_INST_ANY', 0) / max(gen.get('SQ_WAVE_CYCLES', 1), 1),
-                      'hbm_bytes_per_launch': (2 * gen.get('FETCH_SIZE', 0) + gen.get('WRITE_SIZE', 0)) * 1024.0}
-    gen['kernel'] = 'vn_generic_bwd_kernel, 3x64 net, config-3 sized inputs (tools/width_perf.py 64 3)'
-    json.dump(gen, open('profiles/%s_pmc_generic_bwd.json' % pre, 'w'), indent=1)
-st = glob.glob(src + '/stats/**/s_kernel_stats.csv', recursive=True)[0]
-shutil.copy(st, 'profiles/%s_fused16_kernel_stats.csv' % pre)
+full = not (len(sys.argv) > 3 and sys.argv[3] == 'cfg2')      # 'cfg2': only the config-2 counter passes (tools/collect_cfg2_pmc.sh)
+if full:
+    shutil.copy(src + '/bench.json', 'profiles/%s_bench_default.json' % pre)
+    for extra, dst in (('bench_cfg2.json', '%s_bench_cfg2.json'), ('shard_perf.txt', '%s_shard_perf.txt'), ('mor_perf.txt', '%s_mor_perf.txt'),
+                       ('q216.txt', '%s_q216_perf.txt'), ('generic_w64.txt', '%s_generic_w64_perf.txt'), ('width60.txt', '%s_width60_perf.txt')):
+        if os.path.exists(src + '/' + extra):
+            shutil.copy(src + '/' + extra, 'profiles/' + dst % pre)
+    for sub, dst in (('stats_q216', '%s_twopass_q216_kernel_stats.csv'), ('stats_generic', '%s_generic_w64_kernel_stats.csv')):
+        g = glob.glob(src + '/' + sub + '/**/s_kernel_stats.csv', recursive=True)
+        if g:
+            shutil.copy(g[0], 'profiles/' + dst % pre)
+    tp = {}
+    for f in glob.glob(src + '/tpmc_*/**/p_counter_collection.csv', recursive=True):
+        d = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            for kn in ('vn_fused16_kernel', 'vn_seed_kernel'):
+                if kn in r['Kernel_Name']:
+                    d[kn][r['Counter_Name']].append(float(r['Counter_Value']))
+        for kn, dd in d.items():
+            for k, v in dd.items():
+                v = sorted(v)
+                # the fused kernel runs twice per step (forward-only, then reverse with seeds): report both halves
+                tp.setdefault(kn, {})[k] = {'min': v[0], 'median': v[len(v) // 2], 'max': v[-1], 'launches': len(v)}
+    if tp:
+        tp['note'] = ('two-pass route at integNum 216 (tools/q216_perf.py: 30 000 test functions x 216 points, 5x50): per launch; '
+                      'vn_fused16_kernel is launched in forward-only mode (min column) and in reverse mode (max column) each step; '
+                      'MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 / (GRBM_GUI_ACTIVE / 8)')
+        json.dump(tp, open('profiles/%s_pmc_twopass.json' % pre, 'w'), indent=1)
+    gen = {}
+    for f in glob.glob(src + '/gpmc_*/**/p_counter_collection.csv', recursive=True):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if 'vn_generic_bwd_kernel' in r['Kernel_Name']:
+                d[r['Counter_Name']].append(float(r['Counter_Value']))
+        for k, v in d.items():
+            v = sorted(v); gen[k] = v[len(v) // 2]
+    if gen:
+        cyc = gen.get('GRBM_GUI_ACTIVE', 0) / 8.0
+        gen['derived'] = {'shader_cycles_per_launch': cyc,
+                          'mfma_pipe_utilisation': gen.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024.0 / cyc if cyc else None,
+                          'lds_utilisation': gen.get('SQ_LDS_IDX_ACTIVE', 0) / 256.0 / cyc if cyc else None,
+                          'lds_conflict_share': gen.get('SQ_LDS_BANK_CONFLICT', 0) / max(gen.get('SQ_LDS_IDX_ACTIVE', 1), 1),
+                          'wait_any_share': gen.get('SQ_WAIT_ANY', 0) / max(gen.get('SQ_WAVE_CYCLES', 1), 1),
+                          'wait_inst_share': gen.get('SQ_WAIT_INST_ANY', 0) / max(gen.get('SQ_WAVE_CYCLES', 1), 1),
+                          'hbm_bytes_per_launch': (2 * gen.get('FETCH_SIZE', 0) + gen.get('WRITE_SIZE', 0)) * 1024.0}
+        gen['kernel'] = 'vn_generic_bwd_kernel, 3x64 net, config-3 sized inputs (tools/width_perf.py 64 3)'
+        json.dump(gen, open('profiles/%s_pmc_generic_bwd.json' % pre, 'w'), indent=1)
+    st = glob.glob(src + '/stats/**/s_kernel_stats.csv', recursive=True)[0]
+    shutil.copy(st, 'profiles/%s_fused16_kernel_stats.csv' % pre)
+
 sys.path.insert(0, '.')
 import bench
 
@@ -88,12 +91,13 @@ def pmc_summary(prefix, config, workload, alg_bytes, command, copy_csv):
     return out
 
 
-out = pmc_summary('pmc_', 3, 'bench.py config 3 (6.4M points/step)', 128224000,
-                  'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 '
-                  '--no-cpu-baseline --no-dedup --no-extra', True)
-json.dump(out, open('profiles/%s_pmc_traffic.json' % pre, 'w'), indent=1)
-json.dump(out, open('profiles/' + bench.TRAFFIC_FILES[3], 'w'), indent=1)      # the file bench.py quotes `traffic` from
-print(json.dumps(out, indent=1))
+if full:
+    out = pmc_summary('pmc_', 3, 'bench.py config 3 (6.4M points/step)', 128224000,
+                      'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 '
+                      '--no-cpu-baseline --no-dedup --no-extra', True)
+    json.dump(out, open('profiles/%s_pmc_traffic.json' % pre, 'w'), indent=1)
+    json.dump(out, open('profiles/' + bench.TRAFFIC_FILES[3], 'w'), indent=1)      # the file bench.py quotes `traffic` from
+    print(json.dumps(out, indent=1))
 # config 2 (1D+t, 160 000 points, 4x50): Input [nT,2] + gcoef [nT,1] + BC/IC rows, f32
 out2 = pmc_summary('c2pmc_', 2, 'bench.py --config 2 (160k points/step)', 160000 * 3 * 4 + 450 * 3 * 4,
                    'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --config 2 --steps 50 '
