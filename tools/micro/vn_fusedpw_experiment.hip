@@ -1,3 +1,9 @@
+// EXPERIMENT, NOT PART OF THE PRODUCT LIBRARY (round 4, review item 4; result: profiles/r4_pw_perf.txt).
+// Built once, parity green, 17.5 % SLOWER than vn_fused16.hip on the bench workload (9.009 vs 7.667 ms): removed by the stop rule.
+// To rebuild it: copy this file to varnet_amd/csrc/vn_fusedpw.hip, add it to SRCS in the Makefile, declare
+// vn_fusedpw_supported / vn_fusedpw_tile / vn_fusedpw_launch in vn_internal.h and route vn_grad's fused launch to it
+// (tile = 64 points); tools/micro/pw_parity_cases.py and tools/micro/pw_perf.py are the checks that were run.
+//
 // Fused gfx950 kernel, ONE WAVE PER SIMD geometry ("pw": per-wave weight gradient).  Same algorithm and the same
 // forward / epilogue / input-gradient code as vn_fused16.hip (forward with one tangent, weak-form epilogue, full reverse
 // pass in one persistent launch); what differs is where the weight gradient is contracted:
