@@ -103,6 +103,34 @@ def static_traffic(kname, config, world):
                                             'sources %s... = this build)' % (rel, js.get('round'), js.get('kernel'), js['kernel_source_sha256'][:12]))
 
 
+def issue_model(kname, key):
+    """What bounds a kernel whose f32 MFMAs and f32 vector instructions share one datapath (gfx950: DESIGN.md 3.2) is matrix-pipe
+    cycles + vector-instruction issue cycles per SIMD, not the MFMA peak alone; for nets up to 32 wide the vector share is large
+    (elementwise work scales with H, matrix work with H^2).  The committed counter passes (profiles/pmc_issue.json, written by
+    tools/summarise_profiles.py) give both terms per launch; quoted ONLY for the kernel instantiation and kernel code they
+    were collected on.  frac_of_issue_bound = (matrix + vector cycles) / kernel cycles of the same profiled launches."""
+    f = os.path.join(ROOT, 'profiles', 'pmc_issue.json')
+    if not os.path.exists(f):
+        return {"available": False, "why": "profiles/pmc_issue.json absent"}
+    js = json.load(open(f)).get(key)
+    norm = lambda n: ''.join(str(n).split())
+    if not js:
+        return {"available": False, "why": "no counter pass for %s" % key}
+    if norm(js['kernel']) != norm(kname):
+        return {"available": False, "why": "counters were collected on %s, this run launches %s" % (js['kernel'], kname)}
+    if js['kernel_source_sha256'] != kernel_source_hash(kname):
+        return {"available": False, "why": "counter pass predates the current code of this kernel: re-run tools/collect_profiles.sh"}
+    return {"available": True, "matrix_cycles_per_simd": js['matrix_cycles_per_simd'],
+            "vector_instructions_per_simd": js['vector_instructions_per_simd'],
+            "cycles_per_vector_instruction": js['cycles_per_vector_instruction'],
+            "issue_bound_cycles": js['issue_bound_cycles'], "kernel_cycles_same_pass": js['kernel_cycles_same_pass'],
+            "frac_of_issue_bound": js['frac_of_issue_bound'], "matrix_pipe_busy": js['matrix_pipe_busy'],
+            "source": "profiles/pmc_issue.json[%s] (rocprofv3 --pmc passes of round %s on %s)" % (key, js.get('round'), js['kernel']),
+            "note": "f32 MFMA and f32 VALU share one datapath on gfx950: the bound of a launch is matrix-pipe cycles + 4 cycles per "
+                    "vector instruction (a lower bound: transcendentals cost 8), per SIMD; `frac` above prices the same launch "
+                    "against the MFMA peak alone"}
+
+
 def build_problem(cfg):
     from varnet_amd.domain import Domain1D, PolygonDomain2D
     from varnet_amd.adpde import ADPDE
@@ -282,7 +310,7 @@ def small_step_line(cfg, steps, warmup):
                         "achieved": flop / (kms * 1e-3) / 1e12 if kms else None,
                         "frac": flop / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if kms else None,
                         "whole_step_frac": flop / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                        "traffic_source": traffic_source}}
+                        "traffic_source": traffic_source, "issue_model": issue_model(kname, 'config%d' % cfg)}}
     eng.close()
     return out
 
@@ -304,11 +332,13 @@ def mor_epoch_line(epochs, warmup):
     for _ in range(warmup):
         epoch()
     torch.cuda.synchronize()
+    eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(epochs):
         epoch()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / epochs
+    kms, kl, kname = eng.profile_end()
     steps = fd.MORbatchNum * td.batchNum
     F_pt = 2 * (vn.inpDim * vn.layerWidth[0] + sum(a * b for a, b in zip(vn.layerWidth[:-1], vn.layerWidth[1:])) + vn.layerWidth[-1])
     nB = td.mor[0]['biInput'].shape[0]
@@ -317,8 +347,11 @@ def mor_epoch_line(epochs, warmup):
                       "training_points_per_step": int(fd.nT // td.batchNum), "bc_ic_points": int(nB)},
            "value": fd.nT * fd.MORbatchNum / dt, "unit": "training-points/s", "epochs": epochs, "warmup": warmup,
            "ms_per_epoch": dt * 1e3, "us_per_step": dt / steps * 1e6,
-           "roofline": {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "roofline": {"bound": "mfma", "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "kernel": kname, "kernel_ms": kms,
+                        "launches_timed": kl, "algorithmic_flop_per_launch": flop / steps,
+                        "frac": (flop / steps) / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if kms else None,
                         "whole_step_frac": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                        "issue_model": issue_model(kname, 'config5_minibatch'),
                         "note": "whole epoch incl. the host loop over mini-batches; a step is ~16 us of fixed cost (two dependent kernel "
                                 "boundaries: 7.6 us floor) plus 3 tiles per workgroup"}}
     eng.close()
@@ -490,6 +523,7 @@ def _main():
                          "traffic_source": traffic_source,
                          "kernel": kname, "kernel_ms": kms, "launches_timed": klaunches,
                          "algorithmic_flop_per_launch": flop_launch,
+                         "issue_model": issue_model(kname, 'config%d' % args.config) if world == 1 else None,
                          "note": "rank 0's launch: 6*F_pt per interior point + 3*F_pt per BC/IC point, F_pt=%d; "
                                  "HIP events on the engine stream" % F_pt},
         }

@@ -105,6 +105,11 @@ CASES = [
     (3, 2, [64],                 36,      21,  30,  10,  False, True,  False),   # one 64-wide layer: output bias per lane
     (3, 2, [64] * 6,             64,      12,  30,  10,  True,  False, False),   # six 64-wide layers: flush image over the weight images
     (3, 2, [60, 64, 51, 64, 56, 63], 36,  17,  12,  5,   False, True,  True),
+    # KS = 8 (widths 21..32): padding-only k-steps / row tiles are branched over on the layers' real widths, the bias row rides at the
+    # position of feature 31 unless the input side is exactly 32 wide (then thin_bias + the serial flush): ADVICE r3
+    (3, 2, [31, 32, 17],         64,      21,  30,  10,  False, False, False),
+    (2, 1, [17, 32, 32, 21],     16,      90,  33,  11,  True,  False, True),
+    (3, 1, [32, 32],             16,      40,  19,  7,   False, True,  False),
 ]
 
 

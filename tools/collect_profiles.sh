@@ -21,6 +21,13 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   t=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --kernel-trace -d $out/c2pmc_$t -o p --output-format csv -- python3 bench.py --config 2 --steps 50 --warmup 5 --no-cpu-baseline --no-dedup > $out/c2pmc_$t.log 2>&1
 done
+# issue-cycle model of the small-step kernels (bench.py extra.*.roofline.issue_model): matrix-pipe cycles and vector instructions
+# of config 1 (3x20, 96 k points) and of the config-5 mini-batch ([10,20,30], 96 k points); configs 2 and 3 use the passes above
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+  t=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace -d $out/c1pmc_$t -o p --output-format csv -- python3 bench.py --config 1 --steps 200 --warmup 20 --no-cpu-baseline --no-dedup > $out/c1pmc_$t.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace -d $out/c5pmc_$t -o p --output-format csv -- python3 tools/step_timeline.py run mor 100 > $out/c5pmc_$t.log 2>&1
+done
 # the other routes: two-pass fused (integNum 216) and the generic kernels (width 64)
 rocprofv3 --kernel-trace --stats -d $out/stats_q216 -o s --output-format csv -- python3 tools/q216_perf.py > $out/q216.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $out/stats_generic -o s --output-format csv -- python3 tools/width_perf.py 64 3 > $out/generic_w64.txt 2>&1

@@ -106,3 +106,54 @@ if out2:
     json.dump(out2, open('profiles/%s_pmc_traffic_cfg2.json' % pre, 'w'), indent=1)
     json.dump(out2, open('profiles/' + bench.TRAFFIC_FILES[2], 'w'), indent=1)
     print(json.dumps(out2, indent=1))
+
+
+# ---- issue-cycle model (review r3 item 3): what bounds a kernel whose f32 MFMAs and f32 vector instructions share one datapath is
+# matrix-pipe cycles + vector-instruction issue cycles per SIMD, not the MFMA peak alone.  Per launch, from the counter passes:
+#   matrix  = SQ_VALU_MFMA_BUSY_CYCLES / #SIMDs            vector = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / #SIMDs x 4 cycles
+#   (SQ_INSTS_VALU counts the MFMAs too; 4 cycles = issue cost of one wave's vector instruction, MI355X_MICROARCH.md cycle constants;
+#    transcendentals cost 8, so the bound is a lower one)    kernel = GRBM_GUI_ACTIVE / 8 of the same profiled launches
+def issue_entry(prefix, workload):
+    tot, kfull = {}, None
+    for f in glob.glob(src + '/' + prefix + '*/**/p_counter_collection.csv', recursive=True):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if 'vn_fused16_kernel' in r['Kernel_Name']:
+                d[r['Counter_Name']].append(float(r['Counter_Value']))
+                kn = r['Kernel_Name']
+                kfull = kn[kn.index('vn_fused16_kernel'):].split('(')[0].strip()
+        for k, v in d.items():
+            v = sorted(v[len(v) // 4:]); tot[k] = v[len(v) // 2]            # (the first quarter of the dispatches: warm-up)
+    need = ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA')
+    if any(k not in tot for k in need):
+        return None
+    nsimd = 4 * 256
+    matrix = tot['SQ_VALU_MFMA_BUSY_CYCLES'] / nsimd
+    vinst = (tot['SQ_INSTS_VALU'] - tot['SQ_INSTS_MFMA']) / nsimd
+    kernel = tot['GRBM_GUI_ACTIVE'] / 8.0
+    return {'kernel': kfull, 'kernel_source_sha256': bench.kernel_source_hash(kfull), 'workload': workload, 'round': pre,
+            'matrix_cycles_per_simd': matrix, 'vector_instructions_per_simd': vinst, 'cycles_per_vector_instruction': 4.0,
+            'vector_cycles_per_simd': 4.0 * vinst, 'issue_bound_cycles': matrix + 4.0 * vinst, 'kernel_cycles_same_pass': kernel,
+            'frac_of_issue_bound': (matrix + 4.0 * vinst) / kernel, 'matrix_pipe_busy': matrix / kernel,
+            'counters': {k: tot[k] for k in sorted(tot)}}
+
+
+issue = {}
+for key, prefix, wl in (('config3', 'pmc_', 'bench.py config 3 (6.4M points/step, 5x50)'),
+                        ('config2', 'c2pmc_', 'bench.py --config 2 (160 k points/step, 4x50)'),
+                        ('config1', 'c1pmc_', 'bench.py --config 1 (96 k points/step, 3x20)'),
+                        ('config5_minibatch', 'c5pmc_', 'tools/step_timeline.py run mor: one Adam step on a config-5 mini-batch (96 k points, [10,20,30])')):
+    e = issue_entry(prefix, wl)
+    if e:
+        issue[key] = e
+if issue:
+    old = {}
+    if os.path.exists('profiles/pmc_issue.json'):
+        old = json.load(open('profiles/pmc_issue.json'))
+    old.update(issue)
+    json.dump(old, open('profiles/pmc_issue.json', 'w'), indent=1)
+    json.dump(issue, open('profiles/%s_pmc_issue.json' % pre, 'w'), indent=1)
+    for k, e in issue.items():
+        print('issue model %-18s %-36s matrix %.0f + vector %.0f = %.0f of %.0f cycles per SIMD: %.3f' % (
+            k, e['kernel'], e['matrix_cycles_per_simd'], e['vector_cycles_per_simd'], e['issue_bound_cycles'], e['kernel_cycles_same_pass'],
+            e['frac_of_issue_bound']))

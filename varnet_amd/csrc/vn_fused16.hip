@@ -67,6 +67,18 @@ __host__ __device__ constexpr int vones(int KS) {
   return -1;
 }
 static_assert(vfeat(63) == 63 && vfeat(31) == 31 && vpos(7, 3) == 31, "position 4*KS-1 is feature 4*KS-1");
+// What the branches over padding-only k-steps / row tiles (KSKIP, live_k / live_m) rely on: k-step ks holds features 4ks..4ks+3 and
+// nothing else, row tile m (positions 16m..16m+15) holds features 16m..16m+15 and nothing else -- so "width H" bounds the live
+// k-steps by ceil(H/4) and the live row tiles by ceil(H/16).  A change of vpos / vfeat that breaks this must not compile.
+__host__ __device__ constexpr bool layout_ties_ksteps_and_tiles_to_features() {
+  for (int ks = 0; ks < 16; ++ks)
+    for (int g = 0; g < 4; ++g)
+      if (vks(vpos(ks, g)) != ks || vfeat(vpos(ks, g)) != 4 * ks + g) return false;
+  for (int pos = 0; pos < 64; ++pos)
+    if (vfeat(pos) < 16 * (pos >> 4) || vfeat(pos) >= 16 * (pos >> 4) + 16 || vpos(vks(pos), (pos >> 2) & 3) != pos) return false;
+  return true;
+}
+static_assert(layout_ties_ksteps_and_tiles_to_features(), "KSKIP: k-step = feature >> 2, row tile = feature >> 4");
 __host__ __device__ constexpr int mtiles(int KS) { return (KS + 3) / 4; }
 #ifndef VN_MERGED_ROUNDS
 #define VN_MERGED_ROUNDS 1
