@@ -335,7 +335,7 @@ int run_twopass(vn_engine* h, const Batch& b, float* gradbuf) {
 int run_dedup(vn_engine* h, const Batch& b, bool with_grad, float* lossVec, float* gradbuf) {
   const int dim = h->cfg.dim, q = h->cfg.integ_num, grid = h->ncu, P = h->net.P;
   const long nT = b.n_k * q;
-  const int sblk = (int)((b.n_k + 255) / 256);
+  const int sblk = (int)((b.n_k + VN_DEDUP_TFB - 1) / VN_DEDUP_TFB);
   float* lp = h->dd_losspart;                       // [dim*grid + sblk][3]
   VnFusedArgs f{};
   f.net = h->net; f.theta = h->theta; f.X = b.Xu; f.G = nullptr; f.src = nullptr;
@@ -764,7 +764,7 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     h->dd_capU = U;
   }
   if (!h->dd_partial) HIPCHK(hipMalloc((void**)&h->dd_partial, (size_t)3 * h->ncu * h->net.P * sizeof(float)));
-  const long need_lp = ((long)3 * h->ncu + (b.n_k + 255) / 256) * 3;
+  const long need_lp = ((long)3 * h->ncu + (b.n_k + VN_DEDUP_TFB - 1) / VN_DEDUP_TFB) * 3;
   if (need_lp > h->dd_cap_lp) {
     if (h->dd_losspart) (void)hipFree(h->dd_losspart);
     h->dd_losspart = nullptr;

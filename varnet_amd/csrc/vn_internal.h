@@ -122,6 +122,7 @@ struct VnDedupArgs {
   float* part;                               // [grid*3] block partials (var, 0, 0)
   float* seed_u; float* seed_g;              // [U], [U, dim] gathered seeds
 };
+constexpr int VN_DEDUP_TFB = 32;            // test functions per workgroup of the seed kernel = per loss partial (grid = ceil(n_k / 32))
 hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s);
 hipError_t vn_dedup_gather_launch(const VnDedupArgs& a, hipStream_t s);
 
