@@ -30,13 +30,16 @@ for widths, d_in, dim, q in (([50] * 5, 3, 2, 64), ([50] * 4, 2, 1, 16), ([10, 2
 # with a -DVN_FIXSTAMPS build (VARNET_HIP_LIB=.../libvarnet_hip_fix.so): where the empty launch's cycles go
 import os
 if 'fix' in os.environ.get('VARNET_HIP_LIB', ''):
-    e = VNEngine(2, 3, [50] * 5, True, 64)
-    e.init_params(0); e.set_fe_table(np.ones(64), np.ones(64))
-    X = torch.rand(1, 3, device='cuda'); G = torch.randn(1, 2, device='cuda')
-    e.set_interior(0, X[:0], G[:0], None, n_k=0, detJ=1e-3); e.set_bic(None, None, 0, 1.0); e.set_weights([1, 1, 1])
-    for _ in range(3): e.train_step(0)
-    torch.cuda.synchronize()
-    st = e.debug_stamps()
-    d = [st[i + 1] - st[i] for i in range(4)]
-    print('empty 5x50 launch, workgroup 0 (s_memtime ticks at 100 MHz -> us): prologue %.2f  loop %.2f  flush %.2f  store %.2f'
-          % tuple(x / 100.0 for x in d))
+    for widths, d_in, dim, q in (([50] * 5, 3, 2, 64), ([10, 20, 30], 3, 1, 16), ([20] * 3, 2, 1, 16)):
+        e = VNEngine(dim, d_in, widths, True, q)
+        e.init_params(0); e.set_fe_table(np.ones(q), np.ones(q))
+        X = torch.rand(1, d_in, device='cuda'); G = torch.randn(1, dim, device='cuda')
+        e.set_interior(0, X[:0], G[:0], None, n_k=0, detJ=1e-3); e.set_bic(None, None, 0, 1.0); e.set_weights([1, 1, 1])
+        for _ in range(3): e.train_step(0)
+        torch.cuda.synchronize()
+        st = e.debug_stamps()
+        d = [st[i + 1] - st[i] for i in range(4)]
+        # s_memtime counts shader cycles (MI355X_MICROARCH.md): 2.4 GHz nominal
+        print('empty %s launch, workgroup 0 wave 0 (s_memtime cycles; us at 2.4 GHz): prologue %d (%.2f)  set-up %d (%.2f)  flush %d (%.2f)  store + loss partials %d (%.2f)'
+              % ((widths,) + tuple(v for x in d for v in (x, x / 2400.0))))
+        e.close()
