@@ -395,14 +395,23 @@ def _main():
     if args.gpus > 1 and 'RANK' not in os.environ:
         # `python bench.py --gpus N`: start the N ranks ourselves, as fresh children, BEFORE anything in this
         # process touches the GPU (this parent never imports torch); rank 0 prints the JSON line.
-        from varnet_amd.launch import spawn_ranks
-        rc = spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        from varnet_amd import launch
+        rc = launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
         if rc != 0:       # the failing rank has printed its own {"error": ...} line if it got as far as Python
-            print(json.dumps({"error": "a rank of the %d-rank launch exited with status %d (its peers were ended)" % (args.gpus, rc),
-                              "n_gpus": args.gpus}), flush=True)
+            rep = launch.last_report or {}
+            print(json.dumps({"error": "a rank of the %d-rank launch exited with status %d (its peers were ended): %s"
+                                       % (args.gpus, rc, rep.get('reason')),
+                              "n_gpus": args.gpus, "last_stage": rep.get('last_stage'), "exit_status": rep.get('exit_status'),
+                              "alive_when_ended": rep.get('alive')}), flush=True)
         raise SystemExit(rc)
 
+    from varnet_amd.launch import mark_stage, rank_watchdog, IMPORTS_DONE
+    mark_stage('start')
     import torch
+    mark_stage(IMPORTS_DONE)
+    # N > 1 under somebody else's launcher (torch.distributed.run): the rank ends itself with a one-line diagnosis
+    # (its last stage) instead of sitting in a bootstrap until the caller's limit kills it silently
+    disarm = rank_watchdog(what='bench rank') if args.gpus > 1 else (lambda: None)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -421,12 +430,17 @@ def _main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=float(os.environ.get('VN_PG_TIMEOUT_S', '120')))     # torch's default is 10 minutes
+        mark_stage('pg_init')
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local), timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
 
+    mark_stage('build_problem')
     vn, wname = build_problem(args.config)        # joins the engine's RCCL communicator when world > 1
+    mark_stage('data')
     fd, eng = vn.fixData, vn.engine
     tdata = vn._build_tdata()                     # shards by rank when world > 1
     tdata.select_mor(0)
@@ -454,6 +468,7 @@ def _main():
             ar_ev.append((e0, e1))
             eng.apply()
 
+    mark_stage('warmup')
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -461,6 +476,7 @@ def _main():
         dist.barrier()
     torch.cuda.synchronize()
     ar_ev.clear()
+    mark_stage('timed')
     eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -470,6 +486,7 @@ def _main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    mark_stage('report')
     comm_ms = None
     if world > 1:
         comm_ms = eng.profile_comm()[0] if in_engine else float(np.mean([a.elapsed_time(b) for a, b in ar_ev]))
@@ -575,10 +592,13 @@ def _main():
                             "config5_mor_epoch": mor_epoch_line(5, 2)}
         print(json.dumps(out), flush=True)
     if world > 1:
+        mark_stage('teardown')
         dist.barrier()
         if vn.comm == 'rccl':
             eng.comm_destroy()
         dist.destroy_process_group()
+    mark_stage('done')
+    disarm()
 
 
 if __name__ == '__main__':

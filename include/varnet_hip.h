@@ -97,8 +97,9 @@ const char* vn_last_error(void);
 int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_kernel_path, vn_profile_comm;
                                 * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, layer_act, VN_KERNEL_LAYERED;
                                 * 4: vn_comm_available, Adam hyper-parameters validated (no silent NaN from a zeroed config);
-                                * 5: vn_comm_version */
-#define VN_ABI_VERSION 5     /* what this header describes: a binding must refuse a library that reports another number */
+                                * 5: vn_comm_version;
+                                * 6: vn_forward_grad */
+#define VN_ABI_VERSION 6     /* what this header describes: a binding must refuse a library that reports another number */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
 int vn_create(const vn_config* cfg, vn_engine** out);
@@ -185,6 +186,10 @@ int vn_eval_loss(vn_engine* h, int32_t batch, double out[4], float* lossVec_dev)
 /* runSession(['model']) (VarNetUtility.py:1123-1128,1142; VarNet.py:1930): u = model(X). */
 int vn_forward(vn_engine* h, const float* X_dev, int64_t n, float* u_dev);
 int vn_forward_f64(vn_engine* h, const double* X_dev, int64_t n, double* u_dev);
+/* NNModel.modelGrad's tf.gradients(model(Input), Input) (TFModel.py:536-541): u = model(X) [n] and
+ * g = d u / d X[:, :dim] [n, dim] in one pass (value forward + value-adjoint sweep to the inputs, 2 F_pt per point).
+ * Networks the 8-wave fused kernel serves (vn_kernel_path == VN_KERNEL_FUSED16), dim <= 3; VN_EUNSUPPORTED otherwise. */
+int vn_forward_grad(vn_engine* h, const float* X_dev, int64_t n, float* u_dev, float* g_dev);
 /* runSession(['model','residual']) (VarNetUtility.py:1130-1142; TFModel.py:743-754):
  * res = -u_t + diff*Lap(u) - (vel - diff_dx).grad(u) + source.  diff [n], vel [n,dim],
  * source [n] or NULL, diff_dx [n,dim] or NULL.  fp32 and fp64 forms. */

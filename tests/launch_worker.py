@@ -1,0 +1,92 @@
+"""Rank bodies for the CPU-tier launcher / bootstrap tests (tests/test_bench_cpu.py); started by varnet_amd.launch.spawn_ranks.
+
+    launch_worker.py stuck          every rank joins a gloo group; rank 1 then sleeps forever in stage `comm_init`, rank 0 waits
+                                    for it in a collective: what a wedged ncclCommInitRank looks like from outside
+    launch_worker.py watchdog       one rank under rank_watchdog(1 s) that never finishes
+    launch_worker.py bootstrap KIND VNEngine.comm_init_from_torch over gloo on a stand-in engine whose probes are scripted:
+                                    KIND = distinct  the ranks share ORDINAL 0 but sit on different hosts / devices
+                                    KIND = same      both ranks name the same (host, device)
+                                    prints {"rank":, "ok":, "why":} per rank
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from varnet_amd.launch import IMPORTS_DONE, mark_stage, rank_watchdog  # noqa: E402
+
+mode = sys.argv[1]
+rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+mark_stage('start')
+
+if mode == 'watchdog':
+    rank_watchdog(1.0, what='test rank')
+    mark_stage('comm_init')
+    time.sleep(600)
+    sys.exit(0)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+mark_stage(IMPORTS_DONE)
+mark_stage('pg_init')
+dist.init_process_group('gloo', rank=rank, world_size=world)
+
+if mode == 'stuck':
+    mark_stage('probe')
+    mark_stage('id_bcast')
+    mark_stage('comm_init')
+    if rank == 1:
+        time.sleep(600)
+    dist.barrier()
+    sys.exit(0)
+
+if mode == 'bootstrap':
+    from varnet_amd.engine import VNEngine
+    kind = sys.argv[2]
+
+    class Dev:
+        index = 0                                     # every rank sees its card as cuda:0 (per-rank visibility mask)
+
+    class Lib:
+        @staticmethod
+        def vn_last_error():
+            return b''
+
+    class StandIn:
+        """the attributes comm_init_from_torch touches, scripted"""
+        torch, device, lib = torch, Dev(), Lib()
+        inited = None
+        shared_gpus = staticmethod(VNEngine.shared_gpus)
+
+        def comm_available(self):
+            return True
+
+        def comm_size(self):
+            return (1, 0)
+
+        def _make_current(self, ordinal):
+            assert ordinal == 0
+
+        def _gpu_identity(self, ordinal):
+            return ('node%d' % rank, 'uuid:GPU-%04d' % rank) if kind == 'distinct' else ('node0', 'uuid:GPU-0000')
+
+        def comm_unique_id(self):
+            return bytes(range(128))
+
+        def comm_init(self, r, w, uid):
+            assert uid == bytes(range(128))
+            self.inited = (r, w)
+
+        def comm_destroy(self):
+            self.inited = None
+
+    eng = StandIn()
+    ok, why = VNEngine.comm_init_from_torch(eng, dist)
+    print(json.dumps({"rank": rank, "ok": bool(ok), "why": why, "inited": eng.inited, "last_stage": mark_stage.last}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
+
+raise SystemExit('unknown mode ' + mode)

@@ -41,6 +41,76 @@ def test_self_launch_reports_a_failed_rank():
     assert any('exited with status' in js['error'] and js.get('n_gpus') == 2 for js in lines)
 
 
+WORKER = os.path.join(ROOT, 'tests', 'launch_worker.py')
+
+
+def test_launch_deadline_says_where_every_rank_was(capfd):
+    """a first N > 1 run that wedges in the communicator bootstrap must not be killed at somebody else's
+    limit having printed nothing.  Rank 1 sleeps forever in stage `comm_init`, rank 0 waits for it in a collective: within the
+    launcher's deadline the parent ends both BY PID, prints ONE JSON line (who was alive, every rank's last stage) and
+    returns 124."""
+    import time
+    sys.path.insert(0, ROOT)
+    from varnet_amd import launch
+    t0 = time.time()
+    rc = launch.spawn_ranks([WORKER, 'stuck'], 2, deadline_s=4.0, import_grace_s=60.0)
+    dt = time.time() - t0
+    assert rc == 124 and dt < 100
+    out = capfd.readouterr().out
+    lines = [json.loads(ln) for ln in out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    js = lines[0]
+    assert 'deadline' in js['error'] and js['alive'] == [0, 1] and js['ranks'] == 2
+    assert js['last_stage'] == {'0': 'comm_init', '1': 'comm_init'}
+    assert js['s_in_last_stage']['1'] >= 3.5
+    assert launch.last_report['reason'].startswith('launch deadline')
+
+
+def test_launch_reports_the_stage_of_a_rank_that_died():
+    sys.path.insert(0, ROOT)
+    from varnet_amd import launch
+    rc = launch.spawn_ranks(['-c', 'import os, sys; sys.path.insert(0, %r); from varnet_amd.launch import mark_stage; '
+                             'mark_stage("pg_init"); sys.exit(7 if os.environ["RANK"] == "1" else 0)' % ROOT], 2, deadline_s=30.0)
+    assert rc == 7
+    rep = launch.last_report
+    assert rep['reason'] == 'rank 1 exited with status 7' and rep['last_stage']['1'] == 'pg_init' and rep['exit_status']['1'] == 7
+
+
+def test_rank_watchdog_ends_a_rank_with_its_last_stage():
+    """the same deadline for a rank started by another launcher (torch.distributed.run): the rank's own one-line diagnosis"""
+    r = subprocess.run([sys.executable, WORKER, 'watchdog'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124
+    js = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert js['last_stage'] == 'comm_init' and 'deadline' in js['error'] and js['rank'] == 0
+
+
+@pytest.mark.parametrize('kind,expect_ok', [('distinct', True), ('same', False)])
+def test_comm_bootstrap_compares_physical_gpus_not_ordinals(kind, expect_ok, capfd):
+    """with per-rank visibility masks (SLURM --gpus-per-task) or several nodes, distinct physical GPUs share
+    device ordinal 0.  The bootstrap must bring RCCL up there (compare (host, uuid)), and refuse only exact duplicates -- on
+    every rank alike.  Runs VNEngine.comm_init_from_torch over gloo on a stand-in engine with scripted probes."""
+    sys.path.insert(0, ROOT)
+    from varnet_amd import launch
+    rc = launch.spawn_ranks([WORKER, 'bootstrap', kind], 2, deadline_s=120.0)
+    assert rc == 0
+    lines = [json.loads(ln) for ln in capfd.readouterr().out.splitlines() if ln.startswith('{')]
+    assert sorted(js['rank'] for js in lines) == [0, 1]
+    for js in lines:
+        assert js['ok'] is expect_ok
+        if expect_ok:
+            assert js['inited'] == [js['rank'], 2] and js['last_stage'] == 'comm_agree'
+        else:
+            assert js['inited'] is None and 'share a physical GPU' in js['why'] and js['last_stage'] == 'probe'
+
+
+def test_shared_gpus_flags_exact_duplicates_only():
+    sys.path.insert(0, ROOT)
+    from varnet_amd.engine import VNEngine
+    assert VNEngine.shared_gpus([('a', 'uuid:1'), ('b', 'uuid:1'), ('a', 'uuid:2')]) == []          # same uuid string on two hosts
+    assert VNEngine.shared_gpus([('a', 'uuid:1'), ('a', 'uuid:2'), ('a', 'uuid:1')]) == [(0, 2)]
+    assert VNEngine.shared_gpus([['a', 'x'], ['a', 'x']]) == [(0, 1)]                                # all_gather_object hands lists back
+
+
 def test_static_traffic_is_refused_for_another_kernel_or_config():
     sys.path.insert(0, ROOT)
     import bench

@@ -426,6 +426,13 @@ def _csr(uid, U):
     (3, 2, [50, 50, 50, 50, 50], 64, 40,  500,  77, 40,  True,  False),
     (3, 2, [32, 17],             32, 33,  300,  10, 4,   False, True),
     (3, 1, [10, 20, 30],         16, 64,  400,  19, 7,   True,  False),      # MOR-style extra input
+    # the seed kernel's reduction paths: integNum not a multiple of 16 -> level 2 re-reads the row values; ragged
+    # chunks (q = 36: 7 test functions per 256-row chunk, 32-function blocks walk chunks of 7,7,7,7,4); n_k not a multiple of 32
+    (2, 1, [20, 20],             4,   77,  90,   12, 5,   False, False),      # integPnum 1 in 1D+t
+    (3, 2, [20, 20, 20],         8,   45,  120,  9,  4,   True,  True),       # integPnum 1 in 2D+t
+    (2, 1, [50, 50, 50],         36,  53,  700,  31, 11,  True,  True),       # integPnum 3 in 1D+t
+    (2, 1, [24, 31],             100, 37,  900,  8,  8,   False, True),       # integPnum 5 in 1D+t; no IC rows
+    (4, 3, [50, 50, 50, 50],     64,  21,  333,  40, 22,  True,  False),      # dim 3 (+ time): three coordinates in one sweep
 ])
 def test_dedup_formulation_parity(case):
     """De-duplicated formulation (one network evaluation per unique quadrature point): same loss
@@ -484,6 +491,57 @@ def test_dedup_formulation_parity(case):
     eng.grad(0)
     torch.cuda.synchronize()
     assert np.array_equal(gb.cpu().numpy(), g_rows)
+    eng.close()
+
+
+@pytest.mark.parametrize('d_in,dim,widths,act,n', [
+    (2, 1, [20, 20, 20], 'sigmoid', 1000),          # <3,5>: edge rows with 4 features
+    (3, 2, [50, 50, 50, 50, 50], 'sigmoid', 4099),  # <5,13>: the bench network; n not a multiple of 16
+    (3, 2, [50, 50, 50, 50, 50], 'tanh', 777),
+    (3, 1, [10, 20, 30], 'sigmoid', 515),           # <3,8>: padding k-steps / row tiles branched over; extra (MOR) input
+    (4, 3, [64, 64, 64], 'tanh', 2048),             # <3,16>: full tiles, three coordinates + time
+    (3, 2, [50], 'sigmoid', 130),                   # one hidden layer: no hidden-to-hidden sweep
+    (4, 3, [33, 50, 41, 17, 50, 50, 50, 50], 'sigmoid', 300),   # <8,13>: most stored activations
+    (2, 1, [64, 51, 64, 60, 55, 64], 'sigmoid', 97),            # <6,16>
+    (3, 2, [7, 5], 'tanh', 15),                     # fewer points than one wave chunk
+])
+def test_forward_grad_parity(d_in, dim, widths, act, n):
+    """vn_forward_grad (vn_pgrad16.hip: value forward + value-adjoint sweep to the inputs, the reference's
+    tf.gradients(model(Input), Input), TFModel.py:536-541) against the fp64 oracle's model_grad."""
+    from varnet_amd.engine import VNEngine
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1.5, 1.5, (n, d_in)).astype(np.float32)
+    eng = VNEngine(dim, d_in, widths, True, 16, activationFun=act)
+    eng.init_params(seed=9)
+    flat = eng.get_params()
+    # glorot weights give a flat field; scale them up so that the derivatives are not tiny
+    flat = (flat * 2.5).astype(np.float32)
+    flat[-1] = 0.3
+    eng.set_params(flat)
+    u, g = eng.forward_grad(X)
+    u2 = eng.forward(X)
+    torch.cuda.synchronize()
+    params = og.unflatten(flat.astype(np.float64), d_in, widths, torch.float64)
+    Xt = torch.tensor(X.astype(np.float64), requires_grad=True)
+    Val, dM_dx, _, _ = og.model_grad(params, Xt, dim, activation=act)
+    uref, gref = Val.detach().numpy().reshape(-1), dM_dx.detach().numpy()
+    eu = np.max(np.abs(u.cpu().numpy() - uref)) / np.max(np.abs(uref))
+    eg = np.max(np.abs(g.cpu().numpy() - gref)) / np.max(np.abs(gref))
+    ERRORS['forward_grad %s %s' % (widths, act)] = {'u': float(eu), 'grad': float(eg)}
+    assert eu <= 2e-6 and eg <= 1e-5, (eu, eg)
+    assert np.max(np.abs(u.cpu().numpy() - u2.cpu().numpy())) <= 2e-6 * np.max(np.abs(uref))      # vn_forward: the same values
+    u3, g3 = eng.forward_grad(X)
+    torch.cuda.synchronize()
+    assert torch.equal(u, u3) and torch.equal(g, g3)
+    eng.close()
+
+
+def test_forward_grad_refuses_networks_outside_the_fused_family():
+    from varnet_amd.engine import VNEngine, VNError
+    eng = VNEngine(2, 3, [128, 128], True, 16)
+    eng.init_params(seed=1)
+    with pytest.raises(VNError):
+        eng.forward_grad(np.zeros((4, 3), dtype=np.float32))
     eng.close()
 
 

@@ -28,10 +28,15 @@ DISCRIMINATION, stated honestly.  The two tables are 13 % apart in the metric (|
 the boundary layer x >= 0.98, which the [10,20,30] network does not resolve to that accuracy within 60 000 epochs of the script's
 settings (profiles/r4_explore_mor_60000.txt: correct pairing 0.09-0.13 / 0.04-0.16 from epoch 8000 on, the script's swapped pairing
 0.06-0.13 / 0.12-0.15 -- for kappa = 0.01/pi the smoother kappa = 0.005 table is often the CLOSER one, i.e. the trained boundary
-layer is too diffuse; the reference lets this run go to 500 000 epochs).  "Correct beats swapped on both" is therefore not a
-property the method has at any budget a test can afford, and it is not asserted.  What is asserted instead: away from the
+layer is too diffuse; the reference lets this run go to 500 000 epochs).  Round 5 settled it with ONE run to 120 000 epochs
+(14.4 M Adam steps, 614 s; profiles/r5_explore_mor_120000.txt): for kappa = 0.005 the correct table wins from epoch ~62 000 on and by
+3 x at the end (0.042 against 0.129); for kappa = 0.01/pi the smoother kappa = 0.005 table stays the closer one to the end (correct 0.103,
+swapped 0.085) while the points x <= 0.9 converge to 0.013 / 0.010 -- the network's boundary layer at the larger Peclet number is still
+too diffuse.  "Correct beats swapped on both" is therefore not a property the method has at any budget a test can afford, and it is
+not asserted (tests/long_tables.py, not collected, asserts the half that holds).  What is asserted instead: away from the
 boundary layer (x <= 0.9) the network's kappa-sensitivity u(kappa_0) - u(kappa_1) is closer to the tables' difference d3 - d4
-than to zero; and each answer rejects the network evaluated a decade away in kappa by a factor >= 2.5.
+than to zero BY A MARGIN (<= 0.9 where 1.0 means no sensitivity at all; 0.79 at this test's 12 000 epochs, <= 0.69 from epoch 18 000
+on); and each answer rejects the network evaluated a decade away in kappa by a factor >= 2.5.
 """
 import json
 import os
@@ -60,6 +65,9 @@ MOR_TABLE_BAR = 0.20        # l2Err(table, field) for kappa = 0.01/pi (cExD3) an
 MOR_INNER_BAR = 0.08        # the same on the 12 points x <= 0.9, outside the boundary layer (exploration: 0.02-0.07 from epoch 8000)
 MOR_CEXACT_BAR = 0.05       # l2Err(cExact(D = 0.1/pi), field at kappa = 0.1/pi) on the script's 100 x 100 grid (exploration: 0.006-0.03)
 MOR_FAR_FACTOR = 2.5        # each answer rejects the network evaluated a decade away in kappa by this factor (exploration: 3.5-20)
+MOR_SENS_BAR = 0.9          # l2Err((d3 - d4), u(kappa0) - u(kappa1)) on the points x <= 0.9; 1.0 = no kappa-sensitivity at all.  Exploration
+                            # (profiles/r4_explore_mor_60000.txt, profiles/r5_explore_mor_120000.txt): 0.79-0.84 at epochs 10 000-14 000,
+                            # 0.48-0.69 from epoch 18 000 to 120 000
 # BASELINE config 1 = Operator_1Dt at D = 0.1/pi with the 3x20 net, the script's settings, 100 000 epochs
 CFG1_EPOCHS = 100000
 CFG1_BAR = 0.05             # l2Err(fixData.cEx, evaluate()) (Operator_1Dt.py:177-186); exploration: 0.008-0.028 from epoch 20 000 to 300 000
@@ -401,7 +409,7 @@ def test_operator_1dtmor_converged_run_against_the_known_answers(tmp_path):
                                                      loss_bar=float(lb), loss_err_of_the_fp32_restatement_itself=float(lc))
                                                 for a, b, c, e, lb, lc in errs],
                tables_relative_distance=float(uf.l2Err(d3, d4)),
-               bars=dict(table=MOR_TABLE_BAR, inner=MOR_INNER_BAR, cexact=MOR_CEXACT_BAR, far_factor=MOR_FAR_FACTOR))
+               bars=dict(table=MOR_TABLE_BAR, inner=MOR_INNER_BAR, cexact=MOR_CEXACT_BAR, far_factor=MOR_FAR_FACTOR, inner_sensitivity=MOR_SENS_BAR))
     record('operator_1dtmor_converged', out)
     print('MOR converged run: %s' % json.dumps(out['hip']))
     for name in ('hip', 'oracle_at_theta_star'):
@@ -414,7 +422,7 @@ def test_operator_1dtmor_converged_run_against_the_known_answers(tmp_path):
         assert o['tables_vs_net_a_decade_away'][1] >= MOR_FAR_FACTOR * o['correct'][1], (name, o)
         assert o['cexact_grid_vs_net_at_kappa0'] >= MOR_FAR_FACTOR * o['cexact_grid'], (name, o)
         # ... and outside the boundary layer the kappa-sensitivity follows the tables' difference (1.0 = no sensitivity at all)
-        assert o['inner_sensitivity'] < 1.0, (name, o)
+        assert o['inner_sensitivity'] <= MOR_SENS_BAR, (name, o)
     assert fdiff <= FWD_BAR
     assert all(e[0] <= e[4] and e[1] <= e[2] for e in errs), errs
     eng.close()

@@ -1,6 +1,6 @@
 """Exploration behind tests/test_exact_tables.py (round 4): how many epochs of the reference's own settings bring the trained
 field to the reference-held known answers, sampled along ONE run (the hook rides on VarNet.residual, which the training loop
-calls every saveFreq epochs).  Output -> gpurun_out/r4_explore_<case>.txt
+calls every saveFreq epochs).  Output -> gpurun_out/$VN_ROUND_explore_<case>.txt (VN_ROUND defaults to r5)
 
     python tools/explore_tables.py mor [epochs] | cfg1 [epochs] [scheme] | 2dt nx ny nb nt [epochs]
 """
@@ -18,7 +18,8 @@ from tests.test_exact_tables import _mor_setup, tables, uf  # noqa: E402
 pi = np.pi
 case = sys.argv[1]
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-out = open(os.path.join(ROOT, 'gpurun_out', 'r4_explore_%s.txt' % '_'.join(sys.argv[1:]).replace(' ', '').replace('[', '').replace(']', '').replace(',', 'x')), 'w')
+_tag = '_'.join(sys.argv[1:]).replace(' ', '').replace('[', '').replace(']', '').replace(',', 'x')
+out = open(os.path.join(ROOT, 'gpurun_out', '%s_explore_%s.txt' % (os.environ.get('VN_ROUND', 'r5'), _tag)), 'w')
 
 
 def say(s):

@@ -114,6 +114,7 @@ struct vn_engine {
   float *dd_uv = nullptr, *dd_ug = nullptr, *dd_su = nullptr, *dd_sg = nullptr, *dd_partial = nullptr,
         *dd_losspart = nullptr;
   long dd_capU = 0, dd_cap_lp = 0;
+  int pgrad_wgs = 1;           // workgroups per CU of vn_pgrad16 (diagnostic: $VN_PGRAD_WGS)
 
   // tower gradient SUM over RCCL (vn_comm_init); nullptr = single process or host-side collective
   ncclComm_t comm = nullptr;
@@ -329,61 +330,48 @@ int run_twopass(vn_engine* h, const Batch& b, float* gradbuf) {
   return VN_OK;
 }
 
-// One gradient evaluation in the de-duplicated formulation (vn_dedup.hip header): forward at the
-// unique points for each spatial direction, weak-form assembly over rows, seed gather, one reverse
-// pass per direction.  with_grad = false stops after the loss (vn_eval_loss).
-int run_dedup(vn_engine* h, const Batch& b, bool with_grad, float* lossVec, float* gradbuf) {
+// One gradient evaluation in the de-duplicated formulation (vn_dedup.hip header), 8 F_pt per unique point:
+//   1. (u, du/dx_d) at the unique points: value forward + value-adjoint sweep to the inputs     (2 F_pt, vn_pgrad16.hip)
+//   2. weak-form assembly over (test function, quadrature point) rows -> R_k, loss, per-row seeds
+//   3. seed gather per unique point: su = d loss / d u, sg[d] = d loss / d u_{x_d}
+//   4. ONE reverse launch of the fused kernel (recomputes the forward): the directional derivative is linear in its
+//      direction, sum_d sg_d * d(u_{x_d})/d theta = d(sg . grad u)/d theta with sg held fixed, so the per-point direction
+//      G = sg with tangent seed 1 and value seed su gives the whole gradient; BC/IC tiles ride along       (6 F_pt)
+int run_dedup(vn_engine* h, const Batch& b, float* gradbuf) {
   const int dim = h->cfg.dim, q = h->cfg.integ_num, grid = h->ncu, P = h->net.P;
-  const long nT = b.n_k * q;
   const int sblk = (int)((b.n_k + VN_DEDUP_TFB - 1) / VN_DEDUP_TFB);
-  float* lp = h->dd_losspart;                       // [dim*grid + sblk][3]
-  VnFusedArgs f{};
-  f.net = h->net; f.theta = h->theta; f.X = b.Xu; f.G = nullptr; f.src = nullptr;
-  f.nT = b.U; f.n_k = 0; f.integ_num = q;
-  f.feN = h->feN; f.fedNt = h->fedNt; f.feW = nullptr; f.detJv = nullptr; f.detJ = 0.f;
-  f.time_dependent = h->cfg.time_dependent; f.lossVec = nullptr;
-  f.Xb = bi_x(h, b); f.label = bi_y(h, b); f.nB = 0; f.bDof = h->bDof; f.biDimVal = (float)h->biDimVal;
-  f.w0 = (float)h->w[0]; f.w1 = (float)h->w[1]; f.w2 = (float)h->w[2];
-  f.partial = h->dd_partial; f.losspart = lp; f.stamps = nullptr;
-  f.ostride = dim;
-  // 1. (u, du/dx_d) at the unique points
-  for (int d = 0; d < dim; ++d) {
-    f.mode = 1; f.dir = d; f.out_u = (d == 0) ? h->dd_uv : nullptr; f.out_ud = h->dd_ug + d;
-    HIPCHK(vn_fused16_launch(f, grid, h->stream));
+  float* lp = h->dd_losspart;                       // [grid + sblk][3]
+  // vn_profile_*: HIP events around the formulation's whole kernel sequence (steps 1-4; the reduction stays outside as
+  // in the row-wise step)
+  const bool rec = h->prof_on && h->prof_n < PROF_CAP;
+  if (rec) {
+    if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
+    HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
   }
-  // 2. weak-form assembly over (test function, quadrature point) rows
+  HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, h->dd_uv, h->dd_ug, grid * h->pgrad_wgs, h->stream));
   VnDedupArgs a{};
   a.uv = h->dd_uv; a.ug = h->dd_ug; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
   a.gcoef = b.gcoef; a.source = h->cfg.has_source ? b.source : nullptr;
   a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
   a.detJv = b.detJv; a.detJ = (float)b.detJ; a.n_k = b.n_k; a.U = b.U; a.q = q; a.dim = dim;
   a.time_dependent = h->cfg.time_dependent; a.w2 = (float)h->w[2];
-  a.srow = with_grad ? h->u : nullptr; a.lossVec = lossVec; a.part = lp + (long)dim * grid * 3;
+  a.srow = h->u; a.lossVec = nullptr; a.part = lp + (long)grid * 3;
   a.seed_u = h->dd_su; a.seed_g = h->dd_sg;
-  (void)nT;
   HIPCHK(vn_dedup_seed_launch(a, sblk, h->stream));
-  if (!with_grad) {
-    // boundary / initial loss: forward of the BC rows through the generic kernel + seed epilogue
-    return VN_OK;
-  }
   HIPCHK(vn_dedup_gather_launch(a, h->stream));
-  // 3. reverse pass per direction (BC/IC tiles ride along in the first one)
-  for (int d = 0; d < dim; ++d) {
-    f.mode = 2; f.dir = d; f.out_u = nullptr; f.out_ud = nullptr;
-    f.seed_u = (d == 0) ? h->dd_su : nullptr; f.seed_ud = h->dd_sg + d;
-    f.nB = (d == 0) ? h->nB : 0;
-    f.partial = h->dd_partial + (long)d * grid * P;
-    f.losspart = lp + (long)d * grid * 3;
-    const bool rec = h->prof_on && h->prof_n < PROF_CAP && d == 0;
-    if (rec) {
-      if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
-      HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
-    }
-    HIPCHK(vn_fused16_launch(f, grid, h->stream));
-    if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
-  }
-  HIPCHK(vn_reduce_launch(h->dd_partial, dim * grid, P, lp, dim * grid + sblk, h->bDof, h->nB, f.w0, f.w1, f.w2,
-                          gradbuf, h->stream, h->fuse));
+  VnFusedArgs f{};
+  f.net = h->net; f.theta = h->theta; f.X = b.Xu; f.G = h->dd_sg; f.src = nullptr;
+  f.nT = b.U; f.n_k = 0; f.integ_num = q;
+  f.feN = h->feN; f.fedNt = h->fedNt; f.feW = nullptr; f.detJv = nullptr; f.detJ = 0.f;
+  f.time_dependent = h->cfg.time_dependent; f.lossVec = nullptr;
+  f.Xb = bi_x(h, b); f.label = bi_y(h, b); f.nB = h->nB; f.bDof = h->bDof; f.biDimVal = (float)h->biDimVal;
+  f.w0 = (float)h->w[0]; f.w1 = (float)h->w[1]; f.w2 = (float)h->w[2];
+  f.partial = h->dd_partial; f.losspart = lp; f.stamps = nullptr;
+  f.mode = 2; f.dir = -1; f.ostride = 1; f.out_u = nullptr; f.out_ud = nullptr;
+  f.seed_u = h->dd_su; f.seed_ud = nullptr;          // tangent seed 1
+  HIPCHK(vn_fused16_launch(f, grid, h->stream));
+  if (rec) { HIPCHK(hipEventRecord(h->ev1[h->prof_n], h->stream)); h->prof_n++; }
+  HIPCHK(vn_reduce_launch(h->dd_partial, grid, P, lp, grid + sblk, h->bDof, h->nB, f.w0, f.w1, f.w2, gradbuf, h->stream, h->fuse));
   return VN_OK;
 }
 
@@ -451,7 +439,7 @@ int load_rccl() {
 extern "C" {
 
 const char* vn_last_error(void) { return g_err.c_str(); }
-int vn_abi_version(void) { return VN_ABI_VERSION; }   // 5: vn_comm_version; 4: vn_comm_available, validated Adam hyper-parameters (3: vn_config.widths[16], VN_KERNEL_LAYERED)
+int vn_abi_version(void) { return VN_ABI_VERSION; }   // 6: vn_forward_grad; 5: vn_comm_version; 4: vn_comm_available, validated Adam hyper-parameters (3: vn_config.widths[16], VN_KERNEL_LAYERED)
 
 int vn_create(const vn_config* cfg, vn_engine** out) {
   if (!cfg || !out) return fail(VN_EINVAL, "null argument");
@@ -554,6 +542,7 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
   h->two_pass = !h->use_fused && tp_ok && (cfg->kernel == VN_KERNEL_FUSED16 || cfg->kernel == VN_KERNEL_AUTO);
   h->fused_only = deep_fused;
   { const char* fg = getenv("VN_FULL_GRID"); h->full_grid = fg && *fg && *fg != '0'; }
+  { const char* pw = getenv("VN_PGRAD_WGS"); if (pw && *pw >= '1' && *pw <= '4') h->pgrad_wgs = *pw - '0'; }
   if (h->use_fused || h->two_pass) {
     // (the forward-only mode of the 8-wave kernel writes its per-workgroup loss partials here too: vn_forward and
     // vn_eval_loss of a two-pass engine must not find it NULL)
@@ -763,8 +752,8 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     }
     h->dd_capU = U;
   }
-  if (!h->dd_partial) HIPCHK(hipMalloc((void**)&h->dd_partial, (size_t)3 * h->ncu * h->net.P * sizeof(float)));
-  const long need_lp = ((long)3 * h->ncu + (b.n_k + VN_DEDUP_TFB - 1) / VN_DEDUP_TFB) * 3;
+  if (!h->dd_partial) HIPCHK(hipMalloc((void**)&h->dd_partial, (size_t)h->ncu * h->net.P * sizeof(float)));
+  const long need_lp = ((long)h->ncu + (b.n_k + VN_DEDUP_TFB - 1) / VN_DEDUP_TFB) * 3;
   if (need_lp > h->dd_cap_lp) {
     if (h->dd_losspart) (void)hipFree(h->dd_losspart);
     h->dd_losspart = nullptr;
@@ -818,7 +807,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
   if (int rc = check_batch(h, batch)) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   const Batch& b = h->batches[batch];
-  if (b.Xu && h->use_fused16) return run_dedup(h, b, true, nullptr, h->gradbuf);
+  if (b.Xu && h->use_fused16) return run_dedup(h, b, h->gradbuf);
   if (h->two_pass) return run_twopass(h, b, h->gradbuf);
   if (h->use_fused) {
     VnFusedArgs a{};
@@ -973,6 +962,16 @@ int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
   VnRows s0{}, s1{};
   s0.X = X; s0.G = nullptr; s0.u = u; s0.ud = nullptr; s0.n = n;
   HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));
+  return VN_OK;
+}
+
+int vn_forward_grad(vn_engine* h, const float* X, int64_t n, float* u, float* g) {
+  if (!h || (n > 0 && (!X || !u || !g))) return fail(VN_EINVAL, "null argument");
+  (void)hipGetLastError();   // a stale last-error of another library on this thread is not ours to report
+  if (!h->use_fused16 && !h->two_pass) return fail(VN_EUNSUPPORTED, "vn_forward_grad needs a network of the 8-wave fused kernel");
+  if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "vn_forward_grad supports dim <= 3");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, g, h->ncu * h->pgrad_wgs, h->stream));
   return VN_OK;
 }
 

@@ -35,77 +35,52 @@ __global__ __launch_bounds__(256) void vn_dedup_seed_kernel(VnDedupArgs a) {
   const long k0 = (long)blockIdx.x * VN_DEDUP_TFB;
   const long k1 = (k0 + VN_DEDUP_TFB < a.n_k) ? k0 + VN_DEDUP_TFB : a.n_k;
   float lv = 0.f;
-  if (q <= 256) {
-    const int tpc = 256 / q;                           // test functions per chunk
-    const int tf = tid / q, p = tid - tf * q;
-    const bool act = tf < tpc;
-    for (long kc = k0; kc < k1; kc += tpc) {
-      const long k = kc + tf;
-      const bool live = act && k < k1;
-      const long r = k * q + p;
-      float t = 0.f;
-      if (live) {
-        const long j = a.uid[r];
-        for (int d = 0; d < dim; ++d) t += a.ug[j * dim + d] * a.gcoef[r * dim + d];   // TFModel.py:653-654
-        if (a.time_dependent) t -= a.uv[j] * a.fedNt[p];                              // :655
-        if (a.source) t -= a.source[r] * a.feN[p];                                    // :657
-        if (a.feW) t *= a.feW[p];                                                     // :660
-      }
-      sval[tid] = t;
-      __syncthreads();
-      // level 1: the first row of every 16-row group of a test function sums its group; level 2: row 0 sums the groups
-      if (live && (p & 15) == 0) {
-        const int n = (q - p < 16) ? q - p : 16;
-        float g = 0.f;
-        for (int i = 0; i < n; ++i) g += sval[tid + i];
-        sgrp[tid >> 4] = g;                            // tid = tf*q + p: groups of different test functions never share tid >> 4
-      }                                                //  only when q is a multiple of 16; otherwise level 2 re-reads sval (below)
-      __syncthreads();
-      if (live && p == 0) {
-        float R = 0.f;
-        if ((q & 15) == 0) {
-          for (int i = 0; i < q / 16; ++i) R += sgrp[(tid >> 4) + i];
-        } else {
-          for (int i = 0; i < q; ++i) R += sval[tid + i];
-        }
-        const float dj = a.detJv ? a.detJv[k] : a.detJ;
-        const float l = dj * R * R;
-        lv += l;
-        if (a.lossVec) a.lossVec[k] = l;
-        sR[tf] = 2.f * a.w2 * dj * R;
-      }
-      __syncthreads();
-      if (live && a.srow) {
-        const float s0 = sR[tf];
-        a.srow[r] = a.feW ? s0 * a.feW[p] : s0;
-      }
-      // (the next chunk's stores to sval / sgrp / sR come behind its own first barrier for sgrp and sR; sval is rewritten at
-      // once, but every read of this chunk's sval happened before the barrier above)
+  // q <= 128 here: the formulation needs the 8-wave fused kernel, whose tile holds whole test functions (vn_set_dedup)
+  const int tpc = 256 / q;                           // test functions per chunk
+  const int tf = tid / q, p = tid - tf * q;
+  const bool act = tf < tpc;
+  for (long kc = k0; kc < k1; kc += tpc) {
+    const long k = kc + tf;
+    const bool live = act && k < k1;
+    const long r = k * q + p;
+    float t = 0.f;
+    if (live) {
+      const long j = a.uid[r];
+      for (int d = 0; d < dim; ++d) t += a.ug[j * dim + d] * a.gcoef[r * dim + d];   // TFModel.py:653-654
+      if (a.time_dependent) t -= a.uv[j] * a.fedNt[p];                              // :655
+      if (a.source) t -= a.source[r] * a.feN[p];                                    // :657
+      if (a.feW) t *= a.feW[p];                                                     // :660
     }
-  } else {
-    // integ_num beyond a block: one test function per thread (not a shape the package produces)
-    const long k = k0 + tid;
-    if (tid < VN_DEDUP_TFB && k < a.n_k) {
-      const long base = k * q;
+    sval[tid] = t;
+    __syncthreads();
+    // level 1: the first row of every 16-row group of a test function sums its group; level 2: row 0 sums the groups
+    if ((q & 15) == 0 && live && (p & 15) == 0) {
+      const int n = (q - p < 16) ? q - p : 16;
+      float g = 0.f;
+      for (int i = 0; i < n; ++i) g += sval[tid + i];
+      sgrp[tid >> 4] = g;                            // tid = tf*q + p, q a multiple of 16: groups of different test functions
+    }                                                // never share tid >> 4; any other q: level 2 re-reads sval (below)
+    __syncthreads();
+    if (live && p == 0) {
       float R = 0.f;
-      for (int p = 0; p < q; ++p) {
-        const long r = base + p;
-        const long j = a.uid[r];
-        float t = 0.f;
-        for (int d = 0; d < dim; ++d) t += a.ug[j * dim + d] * a.gcoef[r * dim + d];
-        if (a.time_dependent) t -= a.uv[j] * a.fedNt[p];
-        if (a.source) t -= a.source[r] * a.feN[p];
-        if (a.feW) t *= a.feW[p];
-        R += t;
+      if ((q & 15) == 0) {
+        for (int i = 0; i < q / 16; ++i) R += sgrp[(tid >> 4) + i];
+      } else {
+        for (int i = 0; i < q; ++i) R += sval[tid + i];
       }
       const float dj = a.detJv ? a.detJv[k] : a.detJ;
-      lv = dj * R * R;
-      if (a.lossVec) a.lossVec[k] = lv;
-      if (a.srow) {
-        const float s0 = 2.f * a.w2 * dj * R;
-        for (int p = 0; p < q; ++p) a.srow[base + p] = a.feW ? s0 * a.feW[p] : s0;
-      }
+      const float l = dj * R * R;
+      lv += l;
+      if (a.lossVec) a.lossVec[k] = l;
+      sR[tf] = 2.f * a.w2 * dj * R;
     }
+    __syncthreads();
+    if (live && a.srow) {
+      const float s0 = sR[tf];
+      a.srow[r] = a.feW ? s0 * a.feW[p] : s0;
+    }
+    // (the next chunk's stores to sval / sgrp / sR come behind its own first barrier for sgrp and sR; sval is rewritten at
+    // once, but every read of this chunk's sval happened before the barrier above)
   }
   const float s = block_sum256(lv, red);
   if (threadIdx.x == 0) {

@@ -95,7 +95,7 @@ struct VnFusedArgs {
   int dir;                      // tangent direction e_dir (modes 1, 2)
   int ostride;                  // element stride of out_ud / seed_ud
   float* out_u; float* out_ud;  // mode 1 outputs
-  const float* seed_u; const float* seed_ud;   // mode 2 seeds (seed_u may be nullptr = 0)
+  const float* seed_u; const float* seed_ud;   // mode 2 seeds (seed_u nullptr = 0; seed_ud nullptr = 1: the direction G carries them)
 };
 bool vn_fused_supported(const VnNet& net, int integ_num);
 size_t vn_fused_lds_bytes(const VnNet& net);
@@ -106,6 +106,12 @@ bool vn_fused16_net_supported(const VnNet& net);   // network instantiated (any 
 size_t vn_fused16_lds_bytes(const VnNet& net);
 int vn_fused16_ks(const VnNet& net);               // k-steps per hidden layer of the instantiation that serves `net` (0: none)
 hipError_t vn_fused16_launch(const VnFusedArgs& a, int grid, hipStream_t s);
+
+// ---- value + input gradient at points in one pass (vn_pgrad16.hip): value forward + value-adjoint sweep to the inputs,
+// 2 F_pt per point (TFModel.py:536-541); every network vn_fused16_net_supported accepts, dim <= 3.
+// out_u[n], out_g[n, net.dim]; ncu = workgroups the launch may use.
+hipError_t vn_pgrad16_launch(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g,
+                             int ncu, hipStream_t s);
 
 // ---- de-duplicated weak-form assembly (vn_dedup.hip) -----------------------------------------
 struct VnDedupArgs {

@@ -21,7 +21,7 @@ VN_MAX_DIN = 32
 VN_KMAX_LAYERS, VN_KMAX_WIDTH, VN_KMAX_DIN = 6, 64, 8
 VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED, VN_KERNEL_FUSED16, VN_KERNEL_LAYERED = 0, 1, 2, 3, 4
 VN_COMM_ID_BYTES = 128
-VN_ABI_VERSION = 5          # include/varnet_hip.h: load_library refuses a library that reports another number
+VN_ABI_VERSION = 6          # include/varnet_hip.h: load_library refuses a library that reports another number
 
 
 class VnConfig(C.Structure):
@@ -63,6 +63,7 @@ _SIGS = {
     'vn_train_epoch': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_void_p]),
     'vn_eval_loss': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
     'vn_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'vn_forward_grad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_forward_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'vn_residual': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_residual_f64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
@@ -364,6 +365,14 @@ class VNEngine:
         self._ck(self.lib.vn_forward(self.h, _ptr(X), X.shape[0], _ptr(u)))
         return u
 
+    def forward_grad(self, X):
+        """(u [n], du/dx [n, dim]) at X: tf.gradients(model(Input), Input) of TFModel.py:536-541, one pass."""
+        X = self.dev(X)
+        u = self.torch.empty(X.shape[0], dtype=self.torch.float32, device=self.device)
+        g = self.torch.empty((X.shape[0], self.dim), dtype=self.torch.float32, device=self.device)
+        self._ck(self.lib.vn_forward_grad(self.h, _ptr(X), X.shape[0], _ptr(u), _ptr(g)))
+        return u, g
+
     def forward_f64(self, X):
         t = self.torch
         X = self.dev(X, t.float64)
@@ -415,19 +424,55 @@ class VNEngine:
         buf = C.create_string_buffer(bytes(unique_id), VN_COMM_ID_BYTES)
         self._ck(self.lib.vn_comm_init(self.h, int(rank), int(world), buf))
 
+    def _gpu_identity(self, ordinal):
+        """What distinguishes one physical GPU from another across ranks: (host name, device UUID | PCI address).  A device
+        ORDINAL is only unique within one node and one visibility mask: with per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES
+        (SLURM --gpus-per-task: every rank sees its card as cuda:0) or with several nodes, distinct GPUs share an ordinal."""
+        import socket
+        p = self.torch.cuda.get_device_properties(ordinal)
+        ident = getattr(p, 'uuid', None)
+        if ident is not None:
+            ident = 'uuid:%s' % ident
+        else:
+            bus = [getattr(p, a, None) for a in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')]
+            if all(b is not None for b in bus):
+                ident = 'pci:%04x:%02x:%02x' % tuple(bus)
+            else:       # nothing physical to read: the ordinal qualified by the visibility mask it is an index into
+                ident = 'ordinal:%d|%s|%s' % (ordinal, os.environ.get('HIP_VISIBLE_DEVICES', ''), os.environ.get('ROCR_VISIBLE_DEVICES', ''))
+        return (socket.gethostname(), ident)
+
+    def _make_current(self, ordinal):
+        self.torch.cuda.set_device(ordinal)          # what vn_comm_init's hipSetDevice would fail on
+
+    @staticmethod
+    def shared_gpus(identities):
+        """Ranks that name the SAME physical GPU (exact duplicates of the (host, device) pair): [(rank, rank), ...]."""
+        seen, dup = {}, []
+        for r, ident in enumerate(identities):
+            ident = tuple(ident) if isinstance(ident, (list, tuple)) else ident
+            if ident in seen:
+                dup.append((seen[ident], r))
+            else:
+                seen[ident] = r
+        return dup
+
     def comm_init_from_torch(self, dist):
         """Bootstrap through an initialised torch.distributed group.  Every rank walks through the SAME sequence of
         collectives up to `comm_init`, and everything that can fail on ONE rank alone is checked before any rank enters
         ncclCommInitRank (which has no timeout: a rank that never arrives leaves its peers inside it):
           1. every rank probes locally, no collective: RCCL loads, the engine has no communicator yet, its GPU can be made
-             current; the (ok, device ordinal) pairs are all-gathered;
-          2. all ranks skip RCCL together if any probe failed, or if two ranks name the same GPU (RCCL refuses a device
-             that appears twice in a communicator: ranks sharing a card over gloo, VN_COMM=try);
+             current; the (ok, physical GPU identity) pairs are all-gathered;
+          2. all ranks skip RCCL together if any probe failed, or if two ranks name the same PHYSICAL GPU -- the same
+             (host name, device UUID / PCI address), not the same ordinal: ordinals repeat across nodes and across per-rank
+             visibility masks (RCCL refuses a device that appears twice in a communicator: ranks sharing a card over gloo,
+             VN_COMM=try);
           3. rank 0 makes the id inside try/except and ALWAYS broadcasts an (ok, id) pair;
           4. all ranks call comm_init together, then agree (MIN) that it came up everywhere; else all destroy.
         What is NOT covered: a rank that dies, or whose ncclCommInitRank fails on its own, between 3 and 4 leaves its peers
-        in RCCL's bootstrap until RCCL gives up; the launcher (varnet_amd/launch.py, towers.py) ends the peers of a dead rank.
+        in RCCL's bootstrap until RCCL gives up; the launcher (varnet_amd/launch.py: deadline + stage breadcrumbs, towers.py)
+        ends the peers of a dead rank and says where every rank last was.
         Returns (True, '') when the communicator is up on every rank, (False, reason) when all ranks skipped it."""
+        from .launch import mark_stage
         rank, world = dist.get_rank(), dist.get_world_size()
         t = self.torch
         dev = self.device if dist.get_backend() == 'nccl' else 'cpu'
@@ -437,7 +482,8 @@ class VNEngine:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return int(flag.item()) == 1
 
-        why, ordinal = '', -1
+        mark_stage('probe')
+        why, ident = '', None
         try:
             mine = self.comm_available()
             if not mine:
@@ -446,17 +492,20 @@ class VNEngine:
                 mine, why = False, 'this engine already has a communicator'
             else:
                 ordinal = int(self.device.index)
-                t.cuda.set_device(ordinal)                   # what vn_comm_init's hipSetDevice would fail on
+                self._make_current(ordinal)
+                ident = self._gpu_identity(ordinal)
         except Exception as e:                       # noqa: BLE001  (a probe must not raise past the collective)
             mine, why = False, str(e)
         probes = [None] * world
-        dist.all_gather_object(probes, (bool(mine), ordinal, why))
+        dist.all_gather_object(probes, (bool(mine), ident, why))
         bad = [(r, p[2]) for r, p in enumerate(probes) if not p[0]]
         if bad:
             return False, why or 'RCCL is not usable on rank %d: %s' % bad[0]
-        ordinals = [p[1] for p in probes]
-        if len(set(ordinals)) != world:
-            return False, 'ranks share a GPU (device ordinals %s): RCCL needs one device per rank' % ordinals
+        dup = self.shared_gpus([p[1] for p in probes])
+        if dup:
+            return False, ('ranks %s share a physical GPU %s: RCCL needs one device per rank'
+                           % (' and '.join(str(r) for r in dup[0]), probes[dup[0][0]][1]))
+        mark_stage('id_bcast')
         box = [None]
         if rank == 0:
             try:
@@ -467,11 +516,13 @@ class VNEngine:
         ok0, payload = box[0]
         if not ok0:
             return False, 'rank 0 could not create the RCCL id: %s' % payload
+        mark_stage('comm_init')
         up, why = True, ''
         try:
             self.comm_init(rank, world, payload)
         except Exception as e:                       # noqa: BLE001
             up, why = False, str(e)
+        mark_stage('comm_agree')
         if all_ok(up):
             return True, ''
         if up:

@@ -9,13 +9,28 @@ the smallest launcher for that: it sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_
 and starts the ranks as fresh children.  It never touches the GPU itself (no torch import), so it is
 safe to call from a parent that has not initialised HIP -- `bench.py --gpus N` uses it to launch itself.
 `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 script.py` is equivalent.
+
+A first multi-GPU run that wedges must leave a diagnosis, not a kill at somebody else's limit:
+  * every rank appends STAGE BREADCRUMBS (`mark_stage`) to its own file ($VN_STAGE_FILE, set here per rank);
+  * `spawn_ranks` has an overall DEADLINE ($VN_LAUNCH_DEADLINE_S, default 240 s, counted from the moment every rank
+    has finished its imports -- a fresh box spends 1-2 minutes paging PyTorch in -- or from start + $VN_LAUNCH_IMPORT_GRACE_S,
+    default 180 s, whichever comes first).  When it expires the parent ends its children BY PID (terminate, then kill),
+    prints ONE JSON line -- which ranks were alive, each rank's last stage -- and returns 124.  A process that has
+    touched the GPU is ended and reported, never re-executed;
+  * `rank_watchdog` gives the same deadline to a rank started by another launcher (torch.distributed.run): a daemon
+    thread that prints the rank's own JSON line and ends the process.
 """
+import json
 import os
 import signal
 import socket
 import subprocess
 import sys
+import tempfile
+import threading
 import time
+
+IMPORTS_DONE = 'imports_done'          # the stage that starts the deadline clock
 
 
 def free_port():
@@ -26,22 +41,108 @@ def free_port():
     return p
 
 
-def spawn_ranks(argv, nproc, env_extra=None, poll_s=0.2):
+def mark_stage(name):
+    """Append a breadcrumb `<unix time> <name>` to this rank's stage file (no-op without $VN_STAGE_FILE); also kept in
+    `mark_stage.last` for `rank_watchdog`."""
+    mark_stage.last = name
+    f = os.environ.get('VN_STAGE_FILE')
+    if not f:
+        return
+    try:
+        with open(f, 'a') as fh:
+            fh.write('%.3f %s\n' % (time.time(), name))
+    except OSError:
+        pass
+
+
+mark_stage.last = None
+
+
+def read_stages(path):
+    """[(time, stage), ...] of one rank's breadcrumb file ([] if it never wrote one)."""
+    out = []
+    try:
+        for ln in open(path):
+            t, _, s = ln.strip().partition(' ')
+            if s:
+                out.append((float(t), s))
+    except (OSError, ValueError):
+        pass
+    return out
+
+
+def rank_watchdog(deadline_s=None, what='rank'):
+    """For a rank somebody else launched (torch.distributed.run): after `deadline_s` ($VN_RANK_DEADLINE_S, default 300 s)
+    print ONE JSON line with this rank's last stage and end the process with status 124 (os._exit: the main thread may sit
+    in a collective that never returns).  Returns a function that disarms it."""
+    if deadline_s is None:
+        deadline_s = float(os.environ.get('VN_RANK_DEADLINE_S', '300'))
+    done = threading.Event()
+
+    def run():
+        if done.wait(deadline_s):
+            return
+        print(json.dumps({"error": "%s deadline of %.0f s expired" % (what, deadline_s), "rank": int(os.environ.get('RANK', '0')),
+                          "world": int(os.environ.get('WORLD_SIZE', '1')), "last_stage": mark_stage.last}), flush=True)
+        os._exit(124)
+    threading.Thread(target=run, daemon=True).start()
+    return done.set
+
+
+def _end(procs, grace_s=10.0):
+    """terminate, then kill, the exact PIDs we started"""
+    for q in procs:
+        if q.poll() is None:
+            q.terminate()
+    t_end = time.time() + grace_s
+    for q in procs:
+        try:
+            q.wait(max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            q.kill()
+            q.wait()
+
+
+last_report = None      # diagnosis of the last spawn_ranks call (dict): stages per rank, exit codes, what ended it
+
+
+def spawn_ranks(argv, nproc, env_extra=None, poll_s=0.2, deadline_s=None, import_grace_s=None):
     """Run `sys.executable argv...` as `nproc` ranks; returns the first non-zero exit status (0 if all
-    succeed).  When one rank fails the others are ended (exact PIDs), so a dead rank cannot leave its
-    peers blocked in a collective."""
+    succeed, 124 if the deadline expired).  When one rank fails the others are ended (exact PIDs), so a dead rank cannot
+    leave its peers blocked in a collective; when the deadline expires all are ended and ONE JSON line says who was
+    alive and where every rank last was.  `last_report` keeps the same diagnosis for the caller."""
+    global last_report
+    last_report = None
+    if deadline_s is None:
+        deadline_s = float(os.environ.get('VN_LAUNCH_DEADLINE_S', '240'))
+    if import_grace_s is None:
+        import_grace_s = float(os.environ.get('VN_LAUNCH_IMPORT_GRACE_S', '180'))
     port = free_port()
-    procs = []
+    procs, stage_files = [], []
+    stage_dir = tempfile.mkdtemp(prefix='vn_stages_')
     for r in range(nproc):
         env = dict(os.environ)
+        sf = os.path.join(stage_dir, 'rank%d.stage' % r)
+        stage_files.append(sf)
         env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(nproc), 'LOCAL_WORLD_SIZE': str(nproc),
-                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'VN_STAGE_FILE': sf})
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // nproc)))
         if env_extra:
             env.update(env_extra)
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env))
-    status = 0
+    t_start = time.time()
+    t_clock = None                       # when the deadline clock started
+    status, ended_by = 0, None
+    exit_codes = {}
+
+    def report(reason):
+        stages = [read_stages(f) for f in stage_files]
+        return {"reason": reason, "ranks": nproc, "deadline_s": deadline_s, "elapsed_s": round(time.time() - t_start, 1),
+                "alive": [r for r, p in enumerate(procs) if p.poll() is None],
+                "exit_status": {str(r): rc for r, rc in sorted(exit_codes.items())},
+                "last_stage": {str(r): (st[-1][1] if st else None) for r, st in enumerate(stages)},
+                "s_in_last_stage": {str(r): (round(time.time() - st[-1][0], 1) if st else None) for r, st in enumerate(stages)}}
     try:
         live = list(procs)
         while live:
@@ -50,24 +151,45 @@ def spawn_ranks(argv, nproc, env_extra=None, poll_s=0.2):
                 if rc is None:
                     continue
                 live.remove(p)
+                exit_codes[procs.index(p)] = rc
                 if rc != 0 and status == 0:
-                    status = rc
-                    for q in live:                       # do not leave the peers blocked in a collective
-                        q.terminate()
-                    deadline = time.time() + 10
-                    for q in live:
-                        try:
-                            q.wait(max(0.1, deadline - time.time()))
-                        except subprocess.TimeoutExpired:
-                            q.kill()
+                    status, ended_by = rc, 'rank %d exited with status %d' % (procs.index(p), rc)
+                    last_report = report(ended_by)
+                    _end(live)                           # do not leave the peers blocked in a collective
                     live = []
                     break
+            if not live:
+                break
+            now = time.time()
+            if t_clock is None:
+                if now - t_start >= import_grace_s or all(any(s == IMPORTS_DONE for _, s in read_stages(f)) for f in stage_files):
+                    t_clock = now
+            elif now - t_clock >= deadline_s:
+                status, ended_by = 124, 'launch deadline of %.0f s expired' % deadline_s
+                last_report = report(ended_by)
+                _end(live)
+                live = []
+                js = dict(last_report)
+                js["error"] = "%s: the ranks still alive were ended by PID" % ended_by
+                print(json.dumps(js), flush=True)
+                break
             time.sleep(poll_s)
     except KeyboardInterrupt:
         for p in procs:
             if p.poll() is None:
                 p.send_signal(signal.SIGINT)
         status = 130
+    if last_report is None or status == 0:
+        last_report = report(ended_by or 'all ranks exited with status 0')
+    for f in stage_files:
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    try:
+        os.rmdir(stage_dir)
+    except OSError:
+        pass
     return status
 
 
