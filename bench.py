@@ -33,10 +33,15 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
 
 
-# which translation units determine the code of a profiled kernel (the instantiation's name starts with the key)
-KERNEL_SOURCES = {'vn_fused16_kernel': ('varnet_amd/csrc/vn_fused16.hip', 'varnet_amd/csrc/vn_internal.h')}
+# which files determine the code of a profiled kernel (the instantiation's name starts with the key): its translation unit, every
+# header that unit includes, and the compile flags of the Makefile (-fno-slp-vectorize and friends decide the code too)
+_F16 = ('varnet_amd/csrc/vn_fused16.hip', 'varnet_amd/csrc/vn_fused16_common.h', 'varnet_amd/csrc/vn_internal.h', 'include/varnet_hip.h')
+KERNEL_SOURCES = {'vn_fused16_kernel': _F16,
+                  'vn_pgrad16_kernel': ('varnet_amd/csrc/vn_pgrad16.hip',) + _F16[1:],
+                  'vn_dedup_': ('varnet_amd/csrc/vn_dedup.hip',) + _F16[2:]}
 # counter files bench.py may quote `roofline.traffic` from, by --config (tools/collect_profiles.sh + tools/summarise_profiles.py)
 TRAFFIC_FILES = {3: 'pmc_traffic.json', 2: 'pmc_traffic_cfg2.json'}
+DEDUP_TRAFFIC_FILE = 'pmc_traffic_dedup.json'
 
 
 def strip_comments(src):
@@ -64,9 +69,21 @@ def strip_comments(src):
     return ' '.join(''.join(out).split())
 
 
+def effective_cxxflags():
+    """The compile flags of varnet_amd/csrc/Makefile as a plain `make` resolves them (ARCH = gfx950, EXTRA empty)."""
+    import re
+    mk = open(os.path.join(ROOT, 'varnet_amd', 'csrc', 'Makefile')).read()
+    var = {'ARCH': 'gfx950', 'EXTRA': ''}
+    m = re.search(r'^CXXFLAGS\s*=\s*(.*)$', mk, re.M)
+    flags = m.group(1) if m else ''
+    flags = re.sub(r'\$\((\w+)\)', lambda mm: var.get(mm.group(1), ''), flags)
+    return ' '.join(flags.split())
+
+
 def kernel_source_hash(kernel='vn_fused16_kernel'):
-    """sha256 over the comment-stripped, white-space-normalised translation units that determine `kernel`'s code: ties a
-    committed counter file to the code it measured.  Edits to other kernels' files, comments and layout do not move it."""
+    """sha256 over what determines `kernel`'s code: the comment-stripped, white-space-normalised translation unit and headers
+    (KERNEL_SOURCES) and the Makefile's effective compile flags.  Ties a committed counter file to the code it measured; edits to
+    other kernels' files, comments and layout do not move it."""
     import hashlib
     key = [k for k in KERNEL_SOURCES if str(kernel).startswith(k)]
     if not key:
@@ -75,6 +92,7 @@ def kernel_source_hash(kernel='vn_fused16_kernel'):
     for f in KERNEL_SOURCES[key[0]]:
         h.update(f.encode())
         h.update(strip_comments(open(os.path.join(ROOT, f)).read()).encode())
+    h.update(('CXXFLAGS ' + effective_cxxflags()).encode())
     return h.hexdigest()
 
 
@@ -103,7 +121,24 @@ def static_traffic(kname, config, world):
                                             'sources %s... = this build)' % (rel, js.get('round'), js.get('kernel'), js['kernel_source_sha256'][:12]))
 
 
-def issue_model(kname, key):
+def dedup_traffic(config):
+    """HBM bytes per step of the de-duplicated formulation's four kernels (committed counter passes, profiles/pmc_traffic_dedup.json),
+    quoted only when every kernel's file still hashes to what the counters were collected on.  (traffic or None, source string)"""
+    rel = 'profiles/' + DEDUP_TRAFFIC_FILE
+    f = os.path.join(ROOT, rel)
+    if not os.path.exists(f):
+        return None, 'none: %s absent' % rel
+    js = json.load(open(f))
+    if js.get('config') != config:
+        return None, 'none: %s holds the config-%s launches' % (rel, js.get('config'))
+    for k in js.get('kernels', []):
+        if k.get('kernel_source_sha256') != kernel_source_hash(k['kernel']):
+            return None, 'none: %s predates the current code of %s: re-run tools/collect_profiles.sh' % (rel, k['kernel'].split('<')[0])
+    return js.get('hbm_bytes_per_step'), '%s (static: rocprofv3 --pmc passes of round %s; per kernel: %s)' % (
+        rel, js.get('round'), ', '.join('%s %.1f MB' % (k['kernel'].split('<')[0].split('(')[0], k['hbm_bytes_per_launch'] / 1e6) for k in js['kernels']))
+
+
+def issue_model(kname, key, cal=None):
     """What bounds a kernel whose f32 MFMAs and f32 vector instructions share one datapath (gfx950: DESIGN.md 3.2) is matrix-pipe
     cycles + vector-instruction issue cycles per SIMD, not the MFMA peak alone; for nets up to 32 wide the vector share is large
     (elementwise work scales with H, matrix work with H^2).  The committed counter passes (profiles/pmc_issue.json, written by
@@ -125,11 +160,19 @@ def issue_model(kname, key):
             "vector_instructions_per_simd": js['vector_instructions_per_simd'],
             "cycles_per_vector_instruction": js['cycles_per_vector_instruction'],
             "issue_bound_cycles": js['issue_bound_cycles'], "kernel_cycles_same_pass": js['kernel_cycles_same_pass'],
-            "frac_of_issue_bound": js['frac_of_issue_bound'], "matrix_pipe_busy": js['matrix_pipe_busy'],
+            "frac_of_issue_bound": js['frac_of_issue_bound'],
+            # the bound depends on what a vector instruction costs on the shared datapath: 4 cycles is the guide's ONE-wave issue
+            # cost, the kernels run two waves per SIMD, where independent v_fma_f32 measure ~2.7 (tools/micro/overlap2.hip;
+            # re-measured live: roofline.calibration) -- so the fraction is a RANGE, its low end the honest one
+            "frac_of_issue_bound_range": [(js['matrix_cycles_per_simd'] + c * js['vector_instructions_per_simd']) / js['kernel_cycles_same_pass']
+                                          for c in ((cal or {}).get('cycles_per_vector_instruction_2_waves_per_simd') or 2.7, 4.0)],
+            "cycles_per_vector_instruction_range": [(cal or {}).get('cycles_per_vector_instruction_2_waves_per_simd') or 2.7, 4.0],
+            "matrix_pipe_busy": js['matrix_pipe_busy'],
             "source": "profiles/pmc_issue.json[%s] (rocprofv3 --pmc passes of round %s on %s)" % (key, js.get('round'), js['kernel']),
-            "note": "f32 MFMA and f32 VALU share one datapath on gfx950: the bound of a launch is matrix-pipe cycles + 4 cycles per "
-                    "vector instruction (a lower bound: transcendentals cost 8), per SIMD; `frac` above prices the same launch "
-                    "against the MFMA peak alone"}
+            "note": "f32 MFMA and f32 VALU share one datapath on gfx950: the bound of a launch is matrix-pipe cycles + c cycles per "
+                    "vector instruction per SIMD, c between the measured two-waves-per-SIMD issue cost (~2.7) and the guide's "
+                    "one-wave 4 (transcendentals cost more); frac_of_issue_bound uses c = 4, frac_of_issue_bound_range = [c measured, 4]; "
+                    "`frac` above prices the same launch against the MFMA peak alone"}
 
 
 def build_problem(cfg):
@@ -267,7 +310,10 @@ def cpu_baseline(vn, tdata, budget_s=25.0):
         gl.append(float(lg.item()))
     gl = np.array(gl)
     dev = np.abs(gl - losses) / np.abs(losses)
-    return {"value": rows / dt, "unit": "training-points/s", "cores": cores, "kind": "port",
+    full = None
+    if os.environ.get('VN_CPU_FULL', '1') != '0':
+        full = cpu_full_size(vn, tdata, kw, theta0, cores)
+    return {"value": rows / dt, "unit": "training-points/s", "cores": cores, "kind": "port", "full_size": full,
             "value_1_thread": rows / dt1,
             "physical_cores_lscpu": phys, "cores_usable_by_this_job": usable,
             "timed_steps": n_timed, "warmup_steps": warm, "ms_per_step": dt * 1e3,
@@ -281,7 +327,125 @@ def cpu_baseline(vn, tdata, budget_s=25.0):
                       % (n_s, fd.nt, rows, nB, n_timed, warm, cores, phys, usable)}
 
 
-def small_step_line(cfg, steps, warmup):
+def dedup_leg(vn, tdata, eng, step_fn, steps, warmup, nT_total, nB, F_pt, loss_of, config=None):
+    """The de-duplicated formulation on the workload just timed (SURVEY.md 8d "honest accounting"): separately reported,
+    never `value`.  Per unique quadrature point 8 F_pt: value + input gradient in one pass (2 F_pt, vn_pgrad16), weak-form
+    assembly over rows and seed gather (HBM-bound), ONE reverse launch of the fused kernel with the per-point direction
+    (6 F_pt incl. the recomputed forward).  Its own roofline: the formulation's FLOPs over the HIP-event time of its kernel
+    sequence (vn_profile_* brackets steps 1-4 of run_dedup on the engine stream)."""
+    import torch
+    U = tdata.enable_dedup()
+    if not U:
+        return None
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    eng.profile_begin()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    dtd = time.perf_counter() - t1
+    kms, kl, kname = eng.profile_end()
+    loss_dd = loss_of()
+    tdata.disable_dedup()                          # what runs after this leg is the row-wise formulation again
+    flop_dd = 8.0 * F_pt * U + 3.0 * F_pt * nB
+    traffic, traffic_source = dedup_traffic(config)
+    return {
+        "value": nT_total * steps / dtd, "unit": "training-points/s (reference units: rows per step / time)",
+        "ms_per_step": dtd / steps * 1e3, "steps": steps, "unique_points": int(U),
+        "rows_per_unique_point": nT_total / max(U, 1), "loss_after": loss_dd,
+        "roofline": {"bound": "mfma", "achieved": flop_dd / (kms * 1e-3) / 1e12 if kms else None, "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": flop_dd / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if kms else None,
+                     "whole_step_frac": flop_dd / (dtd / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                     "kernels": ["vn_pgrad16_kernel (u and du/dx_d at the unique points: value forward + value-adjoint sweep, 2 F_pt)",
+                                 "vn_dedup_seed_kernel (rows: weak-form integrand, R_k, loss, per-row seeds; HBM-bound)",
+                                 "vn_dedup_gather_kernel (unique points: CSR sum of their rows' seeds; HBM-bound)",
+                                 "%s, reverse mode with the per-point direction sg and tangent seed 1 (6 F_pt, BC/IC tiles ride along)" % kname],
+                     "kernel_sequence_ms": kms, "launches_timed": kl, "formulation_flop_per_step": flop_dd,
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "note": "FLOPs of the formulation that ran (8 F_pt per unique point + 3 F_pt per BC/IC point), not of the row-wise "
+                             "one; per-kernel times: profiles/r5_dedup_kernel_stats.csv"},
+        "note": "separate speed-up, not the headline: each unique quadrature point is evaluated once instead of once per "
+                "(test function, point) row; same loss and gradient up to fp32 rounding "
+                "(tests/test_engine_gpu.py::test_dedup_formulation_parity)"}
+
+
+def cpu_full_size(vn, tdata, kw_sample, theta0, cores, budget_s=45.0):
+    """SURVEY.md 8(d) "same inputs / seed / step count": the oracle on the FULL workload (all test functions, all BC/IC points),
+    1 warm-up + 3 timed Adam steps at the granted thread count -- the sample's per-point rate checked at full size, not
+    extrapolated.  One autograd graph over 6.4 M rows would hold ~60 tensors of 1.3 GB; the set is therefore fed as the
+    reference feeds towers: T contiguous blocks of whole test functions, gradients SUMMED (TFModel.py:370), BC/IC weights / T
+    (VarNetUtility.py:819-857, 900-901) -- the same arithmetic the reference runs with processors=[...] * T.  The HIP engine
+    takes the same steps on the full batch from the same theta_0; the per-step losses are compared."""
+    import torch
+    from oracle import tf1_graph as og
+    fd, eng = vn.fixData, vn.engine
+    q, nt = fd.integNum, fd.nt
+    d = tdata.mor[0]
+    # block size: 2 000 test functions (128 k rows), the sample's -- the host's per-point rate is 2.3 x lower on 10 blocks of 640 k
+    # rows (tensors of 128 MB each: DRAM-bound; 2.28e5 points/s, 28 s per step on the round-5 box) than on blocks that stay in
+    # cache, and the faster way to run the same arithmetic is the fairer baseline
+    T = int(os.environ.get('VN_CPU_FULL_TOWERS', max(1, int(np.ceil(nt / 2000.0)))))
+    blk = -(-nt // T)
+    feeds = []
+    for t in range(T):
+        k0, k1 = t * blk, min(nt, (t + 1) * blk)
+        if k1 <= k0:
+            continue
+        r0, r1 = k0 * q, k1 * q
+        kw = dict(kw_sample)
+        kw.update(Input=d['Input'][r0:r1].cpu().numpy(), gcoef=d['gcoef'][r0:r1].cpu().numpy(),
+                  source=None if d['source'] is None else d['source'][r0:r1].cpu().numpy().reshape(r1 - r0, 1),
+                  N=np.tile(fd.N, k1 - k0).reshape(r1 - r0, 1).astype(np.float32),
+                  dNt=np.tile(fd.dNt, k1 - k0).reshape(r1 - r0, 1).astype(np.float32), intShape=[k1 - k0, q])
+        feeds.append(kw)
+    T = len(feeds)
+    w = np.array([1.0 / T, 1.0 / T, 1.0])
+    torch.set_num_threads(cores)
+
+    def one_step(theta, adam):
+        loss, g = 0.0, 0.0
+        for kw in feeds:
+            kw['w'] = w
+            res, gt = og.loss_and_grad(theta, vn.inpDim, vn.layerWidth, torch.float32, **kw)
+            loss += res['loss']
+            g = g + gt
+        return adam.step(theta, g), loss
+
+    theta = theta0.copy()
+    adam = og.TF1Adam(theta.size, lr=vn.learning_rate, dtype=np.float32)
+    losses, times = [], []
+    n_timed = 3
+    i = 0
+    while i < 1 + n_timed:
+        t0 = time.perf_counter()
+        theta, l = one_step(theta, adam)
+        times.append(time.perf_counter() - t0)
+        losses.append(l)
+        if i == 0 and times[0] * 3 > budget_s:          # slow host: keep the run bounded, say so
+            n_timed = max(1, int(budget_s / times[0]))
+        i += 1
+    dt = float(np.mean(times[1:]))
+    # the same steps on the HIP engine: full batch 0, same theta_0, weights [1, 1, 1]
+    eng.set_weights(np.array([1.0, 1.0, 1.0]))
+    eng.init_params(seed=0)
+    lg = torch.zeros(1, dtype=torch.float32, device=eng.device)
+    gl = []
+    for _ in range(len(losses)):
+        eng.train_step(0, lg)
+        gl.append(float(lg.item()))
+    dev = np.abs(np.array(gl) - np.array(losses)) / np.abs(np.array(losses))
+    rows = nt * q
+    return {"value": rows / dt, "unit": "training-points/s", "cores": cores, "ms_per_step": dt * 1e3, "timed_steps": int(len(times) - 1),
+            "warmup_steps": 1, "towers": T, "rows_per_step": int(rows), "loss_traj_max_rel_dev": float(dev.max()),
+            "loss_first_last_cpu": [float(losses[0]), float(losses[-1])], "loss_first_last_gpu": [float(gl[0]), float(gl[-1])],
+            "sample": "ALL %d test functions (%d points) + all BC/IC points per step, fed as %d tower blocks of <= %d test functions whose "
+                      "gradients are summed (TFModel.py:370; BC/IC weights / %d): %d timed Adam step(s) after 1 warm-up at %d threads"
+                      % (nt, rows, T, blk, T, len(times) - 1, cores)}
+
+
+def small_step_line(cfg, steps, warmup, cal=None, with_dedup=False):
     """One more workload in the same process, reported under `extra`: BASELINE config 2 (1D+t, 4x50, 160 k points), a step
     of ~0.16 ms where per-step fixed cost, not the tile loop, decides.  Same timing rules as the headline (inputs resident,
     K steps between synchronisations, whole-step time; the kernel's own time from HIP events on the engine stream)."""
@@ -313,12 +477,16 @@ def small_step_line(cfg, steps, warmup):
                         "achieved": flop / (kms * 1e-3) / 1e12 if kms else None,
                         "frac": flop / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if kms else None,
                         "whole_step_frac": flop / (dt / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                        "traffic_source": traffic_source, "issue_model": issue_model(kname, 'config%d' % cfg)}}
+                        "traffic_source": traffic_source, "issue_model": issue_model(kname, 'config%d' % cfg, cal)}}
+    if with_dedup:
+        gb = eng.bind_grad_buffer()
+        out["dedup"] = dedup_leg(vn, tdata, eng, lambda: eng.train_epoch([0], None), steps, warmup, fd.nT, nB, F_pt,
+                                 lambda: float(gb[eng.P].item()))
     eng.close()
     return out
 
 
-def mor_epoch_line(epochs, warmup):
+def mor_epoch_line(epochs, warmup, cal=None):
     """BASELINE config 5 under `extra`: one epoch = 6 diffusivities x 20 mini-batches, each mini-batch its own Adam step
     (VarNetUtility.py:1021-1047: batch loop inside the MOR loop), driven like VarNet.train drives it."""
     import torch
@@ -360,7 +528,7 @@ def mor_epoch_line(epochs, warmup):
                         "launches_timed": kl, "algorithmic_flop_per_launch": flop / steps,
                         "frac": (flop / steps) / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if kms else None,
                         "whole_step_frac": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                        "issue_model": issue_model(kname, 'config5_minibatch'),
+                        "issue_model": issue_model(kname, 'config5_minibatch', cal),
                         "note": "whole epoch incl. the host loop over mini-batches; a step is ~16 us of fixed cost (two dependent kernel "
                                 "boundaries: 7.6 us floor) plus 3 tiles per workgroup"}}
     eng.close()
@@ -389,7 +557,7 @@ def _main():
     ap.add_argument('--config', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dedup', action='store_true', help='skip the extra de-duplicated-formulation timing')
-    ap.add_argument('--no-extra', action='store_true', help='skip the extra small-step workloads (configs 1, 2, 5)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the calibration launches, the 2-s sustained window and the extra small-step workloads (configs 1, 2, 5)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -503,25 +671,27 @@ def _main():
     else:
         n_ranks = 1
 
+    F_pt = 2 * (vn.inpDim * vn.layerWidth[0] + sum(a * b for a, b in zip(vn.layerWidth[:-1], vn.layerWidth[1:])) + vn.layerWidth[-1])
+    cal, sustained, dd = None, None, None
+    if world == 1 and not args.no_extra:
+        # what this GPU sustains on the two instruction streams the kernel is priced against (vn_calib.hip, ~30 ms)
+        cal = eng.calibrate()
+        # ---- the same workload for >= 2 s in ONE timed window: does the 20-step rate hold under seconds of load?
+        n_sus = int(max(args.steps, min(2000, np.ceil(2.2 / max(dt / args.steps, 1e-6)))))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        eng.train_epoch([0] * n_sus, None)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t2
+        sustained = {"steps": n_sus, "window_s": dts, "ms_per_step": dts / n_sus * 1e3, "value": nT_total * n_sus / dts,
+                     "unit": "training-points/s", "ratio_to_the_%d_step_value" % args.steps: (dt / args.steps) / (dts / n_sus),
+                     "note": "one timed window, one host call (vn_train_epoch), synchronised at both ends"}
     # ---- extra, separately reported: de-duplicated formulation (one network evaluation per unique
     # quadrature point; SURVEY.md 8d "honest accounting").  Never mixed into `value`.
-    dd = None
     if not args.no_dedup and world == 1:          # the scaling runs time the headline formulation only
-        U_local = tdata.enable_dedup()
-        if U_local:
-            for _ in range(args.warmup):
-                step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            dtd = time.perf_counter() - t1
-            dd = (dtd, int(U_local), float(gb[P].item()))
+        dd = dedup_leg(vn, tdata, eng, step, args.steps, args.warmup, nT_total, nB, F_pt, lambda: float(gb[P].item()), args.config)
 
     if rank == 0:
-        F_pt = 2 * (vn.inpDim * vn.layerWidth[0] + sum(a * b for a, b in zip(vn.layerWidth[:-1], vn.layerWidth[1:]))
-                    + vn.layerWidth[-1])
         flop_of = lambda rows: 6.0 * F_pt * rows + 3.0 * F_pt * nB
         flop_launch = flop_of(rows_local)
         achieved = flop_launch / (kms * 1e-3) / 1e12 if kms > 0 else None
@@ -545,11 +715,16 @@ def _main():
                        "optimizer": "TF1-Adam lr=1e-3", "sharding": "contiguous test-function blocks per rank, SUM all-reduce of %d floats" % (P + 4),
                        "test_functions_per_sec": fd.nt * args.steps / dt, "loss_after": loss_after},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+                         "frac": (achieved / PEAK_FP32_MFMA_TFLOPS) if achieved else None,
+                         # the datasheet peak beside what a loop of independent v_mfma_f32_16x16x4_f32 sustains on this box, two
+                         # waves per SIMD on all 1 024 SIMDs, measured in this process (vn_debug_calibrate)
+                         "peak_measured": cal["mfma_f32_tflops"] if cal else None,
+                         "frac_of_peak_measured": (achieved / cal["mfma_f32_tflops"]) if (cal and achieved) else None,
+                         "calibration": cal, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "kernel": kname, "kernel_ms": kms, "launches_timed": klaunches,
                          "algorithmic_flop_per_launch": flop_launch,
-                         "issue_model": issue_model(kname, 'config%d' % args.config) if world == 1 else None,
+                         "issue_model": issue_model(kname, 'config%d' % args.config, cal) if world == 1 else None,
                          "note": "rank 0's launch: 6*F_pt per interior point + 3*F_pt per BC/IC point, F_pt=%d; "
                                  "HIP events on the engine stream" % F_pt},
         }
@@ -571,25 +746,17 @@ def _main():
             if backend != 'nccl':
                 out["rehearsal"] = "ranks share %d GPU(s) over %s: a plumbing check, not a scaling number" % (ndev, backend)
         if dd is not None:
-            dtd, U_tot, loss_dd = dd
-            # formulation actually run: per unique point dim forward passes (2 F_pt) + dim reverse passes (6 F_pt)
-            flop_dd = 8.0 * vn.dim * F_pt * U_tot + 3.0 * F_pt * nB
-            out["dedup"] = {
-                "value": nT_total * args.steps / dtd, "unit": "training-points/s (reference units: rows per step / time)",
-                "ms_per_step": dtd / args.steps * 1e3, "unique_points": U_tot,
-                "rows_per_unique_point": nT_total / max(U_tot, 1), "loss_after": loss_dd,
-                "achieved_TFLOPs_of_formulation_run": flop_dd / (dtd / args.steps) / 1e12,
-                "note": "separate speed-up, not the headline: each unique quadrature point is evaluated once "
-                        "(value + input gradient, one tangent pass per spatial dimension) instead of once per "
-                        "(test function, point) row; same loss and gradient up to fp32 rounding "
-                        "(tests/test_engine_gpu.py::test_dedup_formulation_parity)"}
+            out["dedup"] = dd
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vn, tdata)
         if world == 1 and args.config == 3 and not args.no_extra:
             eng.close()
-            out["extra"] = {"config2_small_step": small_step_line(2, 400, 40),
-                            "config1_small_step": small_step_line(1, 1000, 100),
-                            "config5_mor_epoch": mor_epoch_line(5, 2)}
+            out["extra"] = {"sustained": sustained,
+                            "config2_small_step": small_step_line(2, 400, 40, cal, with_dedup=not args.no_dedup),
+                            "config1_small_step": small_step_line(1, 1000, 100, cal),
+                            "config5_mor_epoch": mor_epoch_line(5, 2, cal)}
+        elif sustained is not None:
+            out["extra"] = {"sustained": sustained}
         print(json.dumps(out), flush=True)
     if world > 1:
         mark_stage('teardown')

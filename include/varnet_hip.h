@@ -98,7 +98,7 @@ int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_ker
                                 * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, layer_act, VN_KERNEL_LAYERED;
                                 * 4: vn_comm_available, Adam hyper-parameters validated (no silent NaN from a zeroed config);
                                 * 5: vn_comm_version;
-                                * 6: vn_forward_grad */
+                                * 6: vn_forward_grad, vn_debug_calibrate */
 #define VN_ABI_VERSION 6     /* what this header describes: a binding must refuse a library that reports another number */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
@@ -244,6 +244,13 @@ int vn_kernel_path(const vn_engine* h, int32_t* kernel_out, int32_t* two_pass_ou
  * object.  vn_profile_end synchronises. */
 int vn_profile_begin(vn_engine* h);
 int vn_profile_end(vn_engine* h, double* mean_ms, int64_t* launches, char* name, int32_t name_len);
+
+/* Measurement aid (bench.py `roofline.peak_measured`, `issue_model`), ~30 ms, synchronises: what this GPU sustains on
+ * the two instruction streams the fused kernels are priced against, two waves per SIMD on every SIMD.
+ * out[0] fp32 MFMA TFLOP/s (v_mfma_f32_16x16x4_f32 loop; datasheet 157.3), out[1] ms of that launch,
+ * out[2] cycles per independent v_fma_f32 per SIMD (at the clock out[3]), out[3] GHz implied by 32 cycles per MFMA,
+ * out[4] ms of the vector launch. */
+int vn_debug_calibrate(vn_engine* h, double out[5]);
 
 /* Diagnostic builds (-DVN_STAMPS) only: per-phase s_memtime cycle sums of workgroup 0 of the last
  * fused launch (zeros otherwise).  Never part of a timed or shipped build. */

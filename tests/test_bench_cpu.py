@@ -126,8 +126,8 @@ def test_static_traffic_is_refused_for_another_kernel_or_config():
 
 def test_committed_counter_files_match_the_tree():
     """the driver's bench line lost `roofline.traffic` to a commit made after the counter pass.  The
-    committed counter files must carry the hash of the CURRENT code of the kernel they profiled (comment-stripped
-    vn_fused16.hip + vn_internal.h): a kernel edit without a re-run of tools/collect_profiles.sh +
+    committed counter files must carry the hash of the CURRENT code of the kernel they profiled (comment-stripped translation
+    unit + every header it includes + the Makefile's compile flags): a kernel edit without a re-run of tools/collect_profiles.sh +
     tools/summarise_profiles.py fails here, in the CPU tier, before the driver's run can print traffic: null."""
     sys.path.insert(0, ROOT)
     import bench
@@ -140,6 +140,16 @@ def test_committed_counter_files_match_the_tree():
             '%s predates the kernel code in the tree: re-run tools/collect_profiles.sh + tools/summarise_profiles.py' % name
         t, src = bench.static_traffic(js['kernel'], cfg, 1)
         assert t == js['hbm_bytes_per_launch'] and t > 0 and src.startswith('profiles/' + name)
+    # the de-duplicated formulation's four kernels (round 5): every one of them against its own sources
+    path = os.path.join(ROOT, 'profiles', bench.DEDUP_TRAFFIC_FILE)
+    assert os.path.exists(path), 'no counter file for the de-duplicated formulation: run tools/collect_profiles.sh'
+    js = json.load(open(path))
+    assert [k['kernel'].split('<')[0] for k in js['kernels']] == ['vn_pgrad16_kernel', 'vn_dedup_seed_kernel', 'vn_dedup_gather_kernel', 'vn_fused16_kernel']
+    for k in js['kernels']:
+        assert k['kernel_source_sha256'] == bench.kernel_source_hash(k['kernel']), '%s predates the code of %s' % (bench.DEDUP_TRAFFIC_FILE, k['kernel'])
+    t, src = bench.dedup_traffic(3)
+    assert t == js['hbm_bytes_per_step'] and t > 0
+    assert bench.dedup_traffic(2)[0] is None
 
 
 def test_kernel_hash_ignores_comments_and_layout_only():
@@ -152,3 +162,7 @@ def test_kernel_hash_ignores_comments_and_layout_only():
     assert '// not a comment' in bench.strip_comments(a)
     assert bench.kernel_source_hash('vn_fused16_kernel<5, 13, false>') == bench.kernel_source_hash('vn_fused16_kernel')
     assert bench.kernel_source_hash('some_other_kernel') is None
+    # the headers every object depends on and the compile flags decide the code too
+    assert 'include/varnet_hip.h' in bench.KERNEL_SOURCES['vn_fused16_kernel'] and 'varnet_amd/csrc/vn_fused16_common.h' in bench.KERNEL_SOURCES['vn_fused16_kernel']
+    assert '-fno-slp-vectorize' in bench.effective_cxxflags() and '--offload-arch=gfx950' in bench.effective_cxxflags()
+    assert len({bench.kernel_source_hash(k) for k in ('vn_fused16_kernel', 'vn_pgrad16_kernel', 'vn_dedup_seed_kernel')}) == 3

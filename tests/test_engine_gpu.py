@@ -431,7 +431,7 @@ def _csr(uid, U):
     (2, 1, [20, 20],             4,   77,  90,   12, 5,   False, False),      # integPnum 1 in 1D+t
     (3, 2, [20, 20, 20],         8,   45,  120,  9,  4,   True,  True),       # integPnum 1 in 2D+t
     (2, 1, [50, 50, 50],         36,  53,  700,  31, 11,  True,  True),       # integPnum 3 in 1D+t
-    (2, 1, [24, 31],             100, 37,  900,  8,  8,   False, True),       # integPnum 5 in 1D+t; no IC rows
+    (2, 1, [24, 31],             100, 37,  900,  8,  5,   False, True),       # integPnum 5 in 1D+t
     (4, 3, [50, 50, 50, 50],     64,  21,  333,  40, 22,  True,  False),      # dim 3 (+ time): three coordinates in one sweep
 ])
 def test_dedup_formulation_parity(case):

@@ -171,6 +171,18 @@ def test_config2_fullsize(cfg2):
     assert np.max(np.abs(ga[:P] + gb_[:P] - g1[:P])) <= 2e-5 * np.max(np.abs(g1[:P]))
     assert abs(ga[P] + gb_[P] - g1[P]) <= 2e-5 * abs(g1[P])
     eng.set_weights([3.0, 2.0, 5.0])
+    # the de-duplicated formulation at config-2 size (bench.py extra.config2_small_step.dedup): 41 004 unique points for 160 000
+    # rows (3.9 rows per point; dim = 1: 8 F_pt per unique point against 6 F_pt per row), same loss and gradient as the row-wise
+    # launch and as the independent generic kernels, bitwise reproducible, and switching it off restores the row-wise bits
+    U = td.enable_dedup()
+    assert U == 41004
+    gd, gd2 = _grad(eng), _grad(eng)
+    assert np.array_equal(gd, gd2)
+    assert np.max(np.abs(gd[:P] - g1[:P])) <= 1e-4 * np.max(np.abs(g1[:P]))
+    assert np.max(np.abs(gd[:P] - gg[:P])) <= 2e-4 * np.max(np.abs(gg[:P]))
+    assert np.allclose(gd[P:P + 4], g1[P:P + 4], rtol=1e-5)
+    td.disable_dedup()
+    assert np.array_equal(_grad(eng), g1)
 
 
 # ---- BASELINE config 5 at the Operator_1DtMOR sizes -----------------------------------------------------

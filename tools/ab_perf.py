@@ -21,6 +21,13 @@ N1, dN1 = rng.uniform(0, 1, q), rng.standard_normal(q)
 engs = []
 for nm in names:
     path = os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), 'libvarnet_hip_%s.so' % nm)
+    import ctypes
+    engine.VN_ABI_VERSION = ctypes.CDLL(path).vn_abi_version()      # an older build may report an older ABI; the entry points used here have not changed
+    engine._lib = None
+    _probe = ctypes.CDLL(path)
+    _all = getattr(engine, '_SIGS_ALL', None) or dict(engine._SIGS)
+    engine._SIGS_ALL = _all
+    engine._SIGS.clear(); engine._SIGS.update({k: v for k, v in _all.items() if hasattr(_probe, k)})   # older builds lack newer entry points
     engine._lib = engine.load_library(path)
     e = engine.VNEngine(dim, d_in, widths, True, q, kernel=kernel)
     e.init_params(0); e.set_fe_table(N1, dN1); e.set_interior(0, Input, gcoef, None, n_k=n_k, detJ=1e-6)

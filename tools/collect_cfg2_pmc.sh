@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: only the config-2 counter passes of tools/collect_profiles.sh (a kernel edit needs the full script).
-tag=${1:-r4}
+tag=${1:-r5}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd $root

@@ -53,9 +53,28 @@ if full:
         json.dump(gen, open('profiles/%s_pmc_generic_bwd.json' % pre, 'w'), indent=1)
     st = glob.glob(src + '/stats/**/s_kernel_stats.csv', recursive=True)[0]
     shutil.copy(st, 'profiles/%s_fused16_kernel_stats.csv' % pre)
+    g = glob.glob(src + '/stats_dedup/**/s_kernel_stats.csv', recursive=True)
+    if g:
+        shutil.copy(g[0], 'profiles/%s_dedup_kernel_stats.csv' % pre)
 
 sys.path.insert(0, '.')
 import bench
+
+# the hash that goes into a counter file is the one taken AT COLLECTION TIME (tools/collect_profiles.sh writes it before its
+# first pass); a tree that has moved since then must not have its new code blessed by old counters
+COLLECTED = {}
+if os.path.exists(src + '/kernel_source_sha256.json'):
+    COLLECTED = json.load(open(src + '/kernel_source_sha256.json'))
+    moved = [k for k, v in COLLECTED.items() if bench.kernel_source_hash(k) != v]
+    if moved:
+        raise SystemExit('the sources of %s changed after %s was collected: re-run tools/collect_profiles.sh, then summarise' % (moved, src))
+else:
+    print('WARNING: %s/kernel_source_sha256.json absent (collected by an older script): hashing the tree as it is now' % src)
+
+
+def collected_hash(kernel):
+    key = [k for k in bench.KERNEL_SOURCES if str(kernel).startswith(k)]
+    return COLLECTED.get(key[0]) if key and COLLECTED else bench.kernel_source_hash(kernel)
 
 
 def pmc_summary(prefix, config, workload, alg_bytes, command, copy_csv):
@@ -75,7 +94,7 @@ def pmc_summary(prefix, config, workload, alg_bytes, command, copy_csv):
     if 'FETCH_SIZE' not in tot or 'WRITE_SIZE' not in tot:
         return None
     out = {
-        'kernel': kfull, 'kernel_source_sha256': bench.kernel_source_hash(kfull), 'config': config, 'workload': workload,
+        'kernel': kfull, 'kernel_source_sha256': collected_hash(kfull), 'config': config, 'workload': workload,
         'FETCH_SIZE_KB_per_launch': tot['FETCH_SIZE'], 'WRITE_SIZE_KB_per_launch': tot['WRITE_SIZE'],
         'correction': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE taken as is',
         'hbm_bytes_per_launch': (2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0,
@@ -108,6 +127,50 @@ if out2:
     print(json.dumps(out2, indent=1))
 
 
+# ---- de-duplicated formulation: HBM traffic and matrix-pipe use of its four kernels, per launch (one launch of each per step).
+# The bench process runs the row-wise leg first, so the fused kernel's dispatches BEHIND the first vn_pgrad16 dispatch are the
+# formulation's reverse launches.
+def dedup_summary():
+    DD = ('vn_pgrad16_kernel', 'vn_dedup_seed_kernel', 'vn_dedup_gather_kernel', 'vn_fused16_kernel')
+    per, names = collections.defaultdict(lambda: collections.defaultdict(list)), {}
+    for f in glob.glob(src + '/ddpmc_*/**/p_counter_collection.csv', recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        first = min([int(r['Dispatch_Id']) for r in rows if 'vn_pgrad16_kernel' in r['Kernel_Name']] or [1 << 60])
+        for r in rows:
+            for kn in DD:
+                if kn in r['Kernel_Name'] and (kn != 'vn_fused16_kernel' or int(r['Dispatch_Id']) > first):
+                    per[kn][r['Counter_Name']].append(float(r['Counter_Value']))
+                    full = r['Kernel_Name']
+                    names[kn] = full[full.index(kn):].split('(')[0].strip()
+    if any('FETCH_SIZE' not in per[kn] or 'WRITE_SIZE' not in per[kn] for kn in DD):
+        return None
+    med = lambda v: sorted(v)[len(v) // 2]
+    ks = []
+    for kn in DD:
+        t = {k: med(v) for k, v in per[kn].items()}
+        e = {'kernel': names[kn], 'kernel_source_sha256': collected_hash(names[kn]), 'FETCH_SIZE_KB_per_launch': t['FETCH_SIZE'],
+             'WRITE_SIZE_KB_per_launch': t['WRITE_SIZE'], 'hbm_bytes_per_launch': (2 * t['FETCH_SIZE'] + t['WRITE_SIZE']) * 1024.0,
+             'launches_profiled': len(per[kn]['FETCH_SIZE'])}
+        if 'GRBM_GUI_ACTIVE' in t and t['GRBM_GUI_ACTIVE'] > 0:
+            e['shader_cycles_per_launch'] = t['GRBM_GUI_ACTIVE'] / 8.0
+            e['mfma_pipe_utilisation'] = t.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / 1024.0 / (t['GRBM_GUI_ACTIVE'] / 8.0)
+        ks.append(e)
+    return {'config': 3, 'round': pre, 'kernels': ks, 'hbm_bytes_per_step': sum(k['hbm_bytes_per_launch'] for k in ks),
+            'correction': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE taken as is',
+            'command': 'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 '
+                       '--no-cpu-baseline --no-extra',
+            'note': 'one launch of each kernel per de-duplicated step; vn_fused16_kernel = its reverse-mode launches (dispatches behind the first '
+                    'vn_pgrad16 dispatch)'}
+
+
+if full:
+    outd = dedup_summary()
+    if outd:
+        json.dump(outd, open('profiles/%s_pmc_traffic_dedup.json' % pre, 'w'), indent=1)
+        json.dump(outd, open('profiles/' + bench.DEDUP_TRAFFIC_FILE, 'w'), indent=1)
+        print(json.dumps(outd, indent=1))
+
+
 # ---- issue-cycle model (review r3 item 3): what bounds a kernel whose f32 MFMAs and f32 vector instructions share one datapath is
 # matrix-pipe cycles + vector-instruction issue cycles per SIMD, not the MFMA peak alone.  Per launch, from the counter passes:
 #   matrix  = SQ_VALU_MFMA_BUSY_CYCLES / #SIMDs            vector = (SQ_INSTS_VALU - SQ_INSTS_MFMA) / #SIMDs x 4 cycles
@@ -131,7 +194,7 @@ def issue_entry(prefix, workload):
     matrix = tot['SQ_VALU_MFMA_BUSY_CYCLES'] / nsimd
     vinst = (tot['SQ_INSTS_VALU'] - tot['SQ_INSTS_MFMA']) / nsimd
     kernel = tot['GRBM_GUI_ACTIVE'] / 8.0
-    return {'kernel': kfull, 'kernel_source_sha256': bench.kernel_source_hash(kfull), 'workload': workload, 'round': pre,
+    return {'kernel': kfull, 'kernel_source_sha256': collected_hash(kfull), 'workload': workload, 'round': pre,
             'matrix_cycles_per_simd': matrix, 'vector_instructions_per_simd': vinst, 'cycles_per_vector_instruction': 4.0,
             'vector_cycles_per_simd': 4.0 * vinst, 'issue_bound_cycles': matrix + 4.0 * vinst, 'kernel_cycles_same_pass': kernel,
             'frac_of_issue_bound': (matrix + 4.0 * vinst) / kernel, 'matrix_pipe_busy': matrix / kernel,

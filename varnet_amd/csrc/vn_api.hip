@@ -114,7 +114,7 @@ struct vn_engine {
   float *dd_uv = nullptr, *dd_ug = nullptr, *dd_su = nullptr, *dd_sg = nullptr, *dd_partial = nullptr,
         *dd_losspart = nullptr;
   long dd_capU = 0, dd_cap_lp = 0;
-  int pgrad_wgs = 1;           // workgroups per CU of vn_pgrad16 (diagnostic: $VN_PGRAD_WGS)
+  int pgrad_wgs = 0;           // workgroups per CU of vn_pgrad16: 0 = what fits, at most 2 (diagnostic override: $VN_PGRAD_WGS = 1..4)
 
   // tower gradient SUM over RCCL (vn_comm_init); nullptr = single process or host-side collective
   ncclComm_t comm = nullptr;
@@ -348,7 +348,7 @@ int run_dedup(vn_engine* h, const Batch& b, float* gradbuf) {
     if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
     HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
   }
-  HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, h->dd_uv, h->dd_ug, grid * h->pgrad_wgs, h->stream));
+  HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, h->dd_uv, h->dd_ug, grid, h->pgrad_wgs, h->stream));
   VnDedupArgs a{};
   a.uv = h->dd_uv; a.ug = h->dd_ug; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
   a.gcoef = b.gcoef; a.source = h->cfg.has_source ? b.source : nullptr;
@@ -971,7 +971,7 @@ int vn_forward_grad(vn_engine* h, const float* X, int64_t n, float* u, float* g)
   if (!h->use_fused16 && !h->two_pass) return fail(VN_EUNSUPPORTED, "vn_forward_grad needs a network of the 8-wave fused kernel");
   if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "vn_forward_grad supports dim <= 3");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, g, h->ncu * h->pgrad_wgs, h->stream));
+  HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, g, h->ncu, h->pgrad_wgs, h->stream));
   return VN_OK;
 }
 
@@ -1119,6 +1119,14 @@ int vn_kernel_path(const vn_engine* h, int32_t* kernel, int32_t* two_pass) {
   if (!h || !kernel) return fail(VN_EINVAL, "null argument");
   *kernel = h->layered ? VN_KERNEL_LAYERED : h->use_fused16 ? VN_KERNEL_FUSED16 : h->use_fused ? VN_KERNEL_FUSED : h->two_pass ? VN_KERNEL_FUSED16 : VN_KERNEL_GENERIC;
   if (two_pass) *two_pass = h->two_pass ? 1 : 0;
+  return VN_OK;
+}
+
+int vn_debug_calibrate(vn_engine* h, double out[5]) {
+  if (!h || !out) return fail(VN_EINVAL, "null argument");
+  (void)hipGetLastError();
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(vn_calibrate(h->ncu, h->stream, out));
   return VN_OK;
 }
 

@@ -109,9 +109,12 @@ hipError_t vn_fused16_launch(const VnFusedArgs& a, int grid, hipStream_t s);
 
 // ---- value + input gradient at points in one pass (vn_pgrad16.hip): value forward + value-adjoint sweep to the inputs,
 // 2 F_pt per point (TFModel.py:536-541); every network vn_fused16_net_supported accepts, dim <= 3.
-// out_u[n], out_g[n, net.dim]; ncu = workgroups the launch may use.
+// out_u[n], out_g[n, net.dim]; ncu = CUs of the device; wgs_per_cu = 0: as many resident workgroups per CU as fit, at most 2.
 hipError_t vn_pgrad16_launch(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g,
-                             int ncu, hipStream_t s);
+                             int ncu, int wgs_per_cu, hipStream_t s);
+
+// ---- measurement aid (vn_calib.hip): sustained fp32 MFMA rate and fp32 vector issue cost of this GPU; out[5], see there
+hipError_t vn_calibrate(int ncu, hipStream_t s, double out[5]);
 
 // ---- de-duplicated weak-form assembly (vn_dedup.hip) -----------------------------------------
 struct VnDedupArgs {

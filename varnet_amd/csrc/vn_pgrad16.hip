@@ -308,11 +308,12 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_pgrad16_kern
 }
 
 template <int L, int KS, bool TANH>
-hipError_t launch_one(const VnPgradArgsD& a, int grid, hipStream_t s) {
+hipError_t launch_one(const VnPgradArgsD& a, int ncu, int wgs_per_cu, hipStream_t s) {
   const size_t bytes = (size_t)PLay<L, KS>::TOTAL * sizeof(float);
   // the attribute is per device and sticky: set it once per device (bit mask; engines on different devices may be
   // driven from different threads)
   static std::atomic<unsigned long long> attr_done{0};
+  static std::atomic<int> occ{0};                    // workgroups of this instantiation a CU holds (registers, LDS)
   int dev = 0;
   (void)hipGetDevice(&dev);
   const unsigned long long bit = 1ull << (dev & 63);
@@ -320,8 +321,21 @@ hipError_t launch_one(const VnPgradArgsD& a, int grid, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)vn_pgrad16_kernel<L, KS, TANH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
+    int nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)vn_pgrad16_kernel<L, KS, TANH>, NTHREADS, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      nb = 1;
+    }
+    occ.store(nb < 1 ? 1 : nb, std::memory_order_relaxed);
     attr_done.fetch_or(bit, std::memory_order_release);
   }
+  // Waves are independent here (no workgroup barrier in the chunk loop), so a second resident workgroup per CU -- where
+  // the instantiation's registers (<= 128) and weight images (<= 80 KB) allow it -- hides more of the LDS / transcendental
+  // latencies under the partner's MFMAs: 395 -> 382 us on the bench network (profiles/r5_dedup_ab.txt).
+  int per_cu = wgs_per_cu > 0 ? wgs_per_cu : (occ.load(std::memory_order_relaxed) >= 2 ? 2 : 1);
+  const long wgs = ((a.n + CW - 1) / CW + NW - 1) / NW;
+  const long cap = (long)ncu * per_cu;
+  const int grid = (int)(wgs < cap ? wgs : cap);
   hipLaunchKernelGGL((vn_pgrad16_kernel<L, KS, TANH>), dim3(grid), dim3(NTHREADS), bytes, s, a);
   return hipGetLastError();
 }
@@ -336,17 +350,15 @@ hipError_t launch_one(const VnPgradArgsD& a, int grid, hipStream_t s) {
   X(1, 16) X(2, 16) X(3, 16) X(4, 16) X(5, 16) X(6, 16)
 
 hipError_t vn_pgrad16_launch(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g,
-                             int ncu, hipStream_t s) {
+                             int ncu, int wgs_per_cu, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   if (net.dim > 3 || net.d_in > 4 * KS0) return hipErrorInvalidValue;
   VnPgradArgsD a;
   a.net = net; a.theta = theta; a.X = X; a.n = n; a.out_u = out_u; a.out_g = out_g;
-  const long wgs = ((n + CW - 1) / CW + NW - 1) / NW;
-  const int grid = (int)(wgs < ncu ? wgs : ncu);
   const int ks = vn_fused16_ks(net);
 #define X(LL, KK)                                                                              \
   if (net.L == LL && ks == KK)                                                                  \
-    return net.act == VN_ACT_TANH ? launch_one<LL, KK, true>(a, grid, s) : launch_one<LL, KK, false>(a, grid, s);
+    return net.act == VN_ACT_TANH ? launch_one<LL, KK, true>(a, ncu, wgs_per_cu, s) : launch_one<LL, KK, false>(a, ncu, wgs_per_cu, s);
   VN_PGRAD16_CASES(X)
 #undef X
   return hipErrorInvalidValue;

@@ -64,6 +64,7 @@ _SIGS = {
     'vn_eval_loss': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.c_void_p]),
     'vn_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'vn_forward_grad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'vn_debug_calibrate': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     'vn_forward_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'vn_residual': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
     'vn_residual_f64': (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p, C.c_void_p]),
@@ -549,6 +550,13 @@ class VNEngine:
     def dedup_supported(self):
         k, tp = self.kernel_path()
         return k == VN_KERNEL_FUSED16 and not tp
+
+    def calibrate(self):
+        """Sustained fp32 MFMA rate and fp32 vector issue cost of this GPU (vn_calib.hip): dict for bench.py."""
+        out = (C.c_double * 5)()
+        self._ck(self.lib.vn_debug_calibrate(self.h, out))
+        return {"mfma_f32_tflops": out[0], "mfma_launch_ms": out[1], "cycles_per_vector_instruction_2_waves_per_simd": out[2],
+                "clock_ghz_implied_by_the_mfma_loop": out[3], "valu_launch_ms": out[4]}
 
     def debug_stamps(self):
         out = (C.c_uint64 * 8)()

@@ -649,6 +649,17 @@ class ManageTrainData:
         self.dedup_on = True
         return total
 
+    def disable_dedup(self):
+        """Back to the row-wise formulation for every registered batch (`vn_set_dedup` with no points)."""
+        if not getattr(self, 'dedup_on', False):
+            return
+        for mb in range(len(self.mor)):
+            for bi in range(self.batchNum):
+                n0, n1 = self.block(bi)
+                if n1 > n0:
+                    self.vn.engine.set_dedup(self.engine_batch(mb, bi))
+        self.dedup_on = False
+
     def select_mor(self, mb):
         d = self.mor[mb]
         self.vn.engine.set_bic(d['biInput'], d['biLabel'], self.bDofsum, self.biDimVal)
