@@ -2,8 +2,9 @@
 Randomised cross-check of the independent GPU routes on the same inputs, WITH the oracle in the loop (test
 infrastructure: lives under tests/ because it uses oracle/).
 
-Routes: the AUTO kernel choice (8-wave fused / two-pass / layer-by-layer), the generic kernels, and both forms of the
-layer-by-layer route (tile kernels of vn_wide.hip = route 4, GEMM form = 40), whichever can run a case.  Cases: random
+Routes: the AUTO kernel choice (8-wave fused / two-pass / layer-by-layer), the generic kernels, both forms of the
+layer-by-layer route (tile kernels of vn_wide.hip = route 4, GEMM form = 40), and -- round 5 -- the de-duplicated formulation
+(route 30: vn_pgrad16 + vn_dedup.hip + one reverse launch) on inputs whose rows share points, whichever can run a case.  Cases: random
 depth, widths (uniform and ragged; one in five beyond the fused kernels' range: up to 9 layers, 300 wide), sigmoid /
 tanh, d_in, dim, integNum 4..1296, source / integW / detJvec / per-row tables, one tile to several tiles per workgroup.
 
@@ -112,6 +113,26 @@ def run_case(c, with_oracle=True):
     n_k = c['n_k'] if (c['big'] and in_range) else min(c['n_k'], 40)     # keep the HBM route's cases small
     c = dict(c, n_k=n_k)
     d = synth(1000 + case, d_in, dim, widths, q, n_k, c['nB'], c['bDof'], src, iw, djv)
+    # Round 5: the de-duplicated formulation as one more route (code 30) wherever it applies -- the 8-wave fused kernel, uniform
+    # supports -- on inputs whose rows really share points: the first U rows become the unique points and every row draws one of
+    # them (all routes see the same expanded rows).  integNum 4, 8, 36 and ragged chunk tails reach vn_dedup_seed_kernel's
+    # other reduction paths here.
+    dd = None
+    if not djv and not c['rows'] and dim <= 3:
+        probe = make_engine(d_in, dim, widths, q, src, iw, 0, act)
+        if probe.dedup_supported():
+            r5 = np.random.default_rng(5000 + case)
+            n = n_k * q
+            U = max(1, n // int(r5.integers(1, 9)))
+            uid = r5.integers(0, U, n).astype(np.int32)
+            uid[:U] = np.arange(U)                      # every unique point is used
+            r5.shuffle(uid)
+            Xu = d['Input'][:U].copy()
+            d['Input'] = Xu[uid]
+            rowptr = np.zeros(U + 1, dtype=np.int32)
+            rowptr[1:] = np.cumsum(np.bincount(uid, minlength=U))
+            dd = (Xu, uid, rowptr, np.argsort(uid, kind='stable').astype(np.int32))
+        probe.close()
     grads, routes, flat = [], [], None
     for kernel in kernels:
         eng = make_engine(d_in, dim, widths, q, src, iw, kernel, act)
@@ -128,6 +149,12 @@ def run_case(c, with_oracle=True):
         torch.cuda.synchronize()
         grads.append(gb.cpu().numpy().astype(np.float64))
         routes.append(40 if kernel == 40 else eng.kernel_path()[0])
+        if kernel == 0 and dd is not None:
+            eng.set_dedup(0, *dd)
+            eng.grad(0)
+            torch.cuda.synchronize()
+            grads.append(gb.cpu().numpy().astype(np.float64))
+            routes.append(30)
         eng.close()
     P = grads[0].size - 4
     pair = lpair = 0.0

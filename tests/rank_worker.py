@@ -94,7 +94,9 @@ def run_controller(outdir, backend, ngpu_entries, q):
         from varnet_amd import ADPDE, Domain1D, VarNet
         pde = ADPDE(Domain1D(), diff=0.1 / pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0],
                     IC=lambda x: -np.sin(pi * x), cEx=cExact)               # lambdas: only a fork can carry them
-        procs = ['GPU:%d' % (i if backend == 'nccl' else 0) for i in range(ngpu_entries)]
+        # the reference's own list, whatever the backend: over a rehearsal backend on a box with fewer cards the towers map
+        # GPU:n onto the cards there are, and that wrap must reach each tower's ENGINE (varnet_amd/towers.py)
+        procs = ['GPU:%d' % i for i in range(ngpu_entries)]
         vn = VarNet(pde, layerWidth=[20, 20, 20], discNum=20, bDiscNum=None, tDiscNum=30, processors=procs,
                     controller='GPU:0')
         assert not torch.cuda.is_initialized()                             # the controller never touches the GPU

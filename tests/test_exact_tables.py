@@ -193,8 +193,17 @@ def _grad_bar(theta, d_in, widths, kw64, gref, lref=None):
     cond = float(np.max(np.abs(np.asarray(g32, dtype=np.float64) - gref)) / np.max(np.abs(gref)))
     if lref is not None:                    # the loss at a converged theta is a sum of squared small residuals R_k: same rule
         lcond = abs(float(r32['loss']) - lref) / abs(lref)
-        return max(1e-4, 2.0 * cond), cond, max(1e-5, 2.0 * lcond), lcond
-    return max(1e-4, 2.0 * cond), cond
+        assert cond <= GRAD_COND_CAP and lcond <= LOSS_COND_CAP, ('theta* is worse conditioned than any converged run so far', cond, lcond)
+        return min(max(1e-4, 2.0 * cond), 2.0 * GRAD_COND_CAP), cond, min(max(1e-5, 2.0 * lcond), 2.0 * LOSS_COND_CAP), lcond
+    assert cond <= GRAD_COND_CAP, ('theta* is worse conditioned than any converged run so far', cond)
+    return min(max(1e-4, 2.0 * cond), 2.0 * GRAD_COND_CAP), cond
+
+
+# The self-calibrated bars above are CAPPED: the condition estimate itself -- the deviation of the oracle's own fp32 run from
+# its fp64 run at theta* -- must stay under these bounds (measured over the three converged runs: gradient 4.1e-4 on config 1,
+# loss <= 5e-6), so an ill-conditioned theta* fails the test instead of loosening its bar without limit; the bar never exceeds twice the cap.
+GRAD_COND_CAP = 1e-3
+LOSS_COND_CAP = 5e-5
 
 
 def _config1_problem(engine=True):

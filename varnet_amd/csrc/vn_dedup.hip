@@ -90,17 +90,34 @@ __global__ __launch_bounds__(256) void vn_dedup_seed_kernel(VnDedupArgs a) {
   }
 }
 
+// One thread per unique point sums the seeds of its rows in CSR order (fixed -> bitwise reproducible).  The chain
+// rowidx[e] -> srow[r], gcoef[r] is two dependent gathers per row; the loads of four rows are issued together before
+// the sums (same order of additions as a one-row-at-a-time walk), so a thread has eight gathers in flight, not two.
 __global__ __launch_bounds__(256) void vn_dedup_gather_kernel(VnDedupArgs a) {
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= a.U) return;
   const int dim = a.dim, q = a.q;
   float su = 0.f, sg[3] = {0.f, 0.f, 0.f};
-  for (int e = a.rowptr[j]; e < a.rowptr[j + 1]; ++e) {
-    const long r = a.rowidx[e];
-    const float s = a.srow[r];
-    const int p = (int)(r % q);
-    if (a.time_dependent) su -= a.fedNt[p] * s;
-    for (int d = 0; d < dim; ++d) sg[d] += a.gcoef[r * dim + d] * s;
+  const int e1 = a.rowptr[j + 1];
+  for (int e = a.rowptr[j]; e < e1; e += 4) {
+    long r[4];
+    float s[4], g[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (e + i < e1) ? a.rowidx[e + i] : -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i] = (r[i] >= 0) ? a.srow[r[i]] : 0.f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) g[i][d] = (r[i] >= 0 && d < dim) ? a.gcoef[r[i] * dim + d] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (r[i] < 0) continue;
+      if (a.time_dependent) su -= a.fedNt[(int)(r[i] % q)] * s[i];
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if (d < dim) sg[d] += g[i][d] * s[i];
+    }
   }
   a.seed_u[j] = su;
   for (int d = 0; d < dim; ++d) a.seed_g[j * dim + d] = sg[d];

@@ -41,10 +41,17 @@ def _tower_main(rank, world, port, conn, cls, args, kwargs, device, backend):
             torch.cuda.set_device(device)
         elif torch.cuda.is_available():
             # rehearsal over another backend (VN_DIST_BACKEND=gloo): the towers share the cards there are, as bench.py's
-            # ranks do; a CPU-only rehearsal has no device to pick
+            # ranks do; a CPU-only rehearsal has no device to pick.  The wrap must reach the ENGINE: VarNet takes
+            # processors[rank] = 'GPU:k' and creates its engine on device k, so this tower's entry of `processors` is rewritten
+            # (['GPU:0', 'GPU:1'] on a one-GPU box used to set device 0 here and create the engine on device 1)
             device = device % torch.cuda.device_count()
             os.environ['LOCAL_RANK'] = str(device)
             torch.cuda.set_device(device)
+            procs = kwargs.get('processors')
+            if isinstance(procs, (list, tuple)) and len(procs) == world:
+                procs = list(procs)
+                procs[rank] = 'GPU:%d' % device
+                kwargs = dict(kwargs, processors=procs)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device))
         else:
