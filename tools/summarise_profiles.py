@@ -63,13 +63,18 @@ import bench
 # the hash that goes into a counter file is the one taken AT COLLECTION TIME (tools/collect_profiles.sh writes it before its
 # first pass); a tree that has moved since then must not have its new code blessed by old counters
 COLLECTED = {}
-if os.path.exists(src + '/kernel_source_sha256.json'):
-    COLLECTED = json.load(open(src + '/kernel_source_sha256.json'))
+_hf = sorted(glob.glob(src + '/kernel_source_sha256*.json'))
+if _hf:
+    for f in _hf:                                # one file per collection call (parts A, B): all must name the same code
+        h = json.load(open(f))
+        if COLLECTED and h != COLLECTED:
+            raise SystemExit('the collection calls of %s ran on different sources (%s): collect again' % (src, _hf))
+        COLLECTED = h
     moved = [k for k, v in COLLECTED.items() if bench.kernel_source_hash(k) != v]
     if moved:
         raise SystemExit('the sources of %s changed after %s was collected: re-run tools/collect_profiles.sh, then summarise' % (moved, src))
 else:
-    print('WARNING: %s/kernel_source_sha256.json absent (collected by an older script): hashing the tree as it is now' % src)
+    print('WARNING: %s/kernel_source_sha256*.json absent (collected by an older script): hashing the tree as it is now' % src)
 
 
 def collected_hash(kernel):
