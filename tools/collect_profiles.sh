@@ -22,6 +22,16 @@ sys.path.insert(0, '.')
 import bench
 print(json.dumps({k: bench.kernel_source_hash(k) for k in bench.KERNEL_SOURCES}))
 PY
+if [ "$part" = "D" ]; then      # only the de-duplicated formulation's passes (after an edit of vn_pgrad16.hip / vn_dedup.hip alone)
+rm -rf $out/stats_dedup $out/ddpmc_*
+rocprofv3 --kernel-trace --stats -d $out/stats_dedup -o s --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $out/stats_dedup.log 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  t=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace -d $out/ddpmc_$t -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $out/ddpmc_$t.log 2>&1
+done
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_dedup_only.json 2> $out/bench_dedup_only.err
+find $out -name "*.csv" | wc -l; exit 0
+fi
 if [ "$part" != "B" ]; then
 python3 bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err
 python3 bench.py --config 2 --steps 400 --warmup 40 --no-dedup --no-cpu-baseline > $out/bench_cfg2.json 2> $out/bench_cfg2.err

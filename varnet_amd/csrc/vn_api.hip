@@ -63,6 +63,8 @@ struct Batch {
   const int* rowptr = nullptr;
   const int* rowidx = nullptr;
   long U = 0;
+  float* gcsr = nullptr;      // owned: gcoef in CSR order, [n_k*integ_num, dim] (static per batch; built by vn_set_dedup)
+  long gcsr_cap = 0;
 };
 
 constexpr int PROF_CAP = 4096;
@@ -351,7 +353,7 @@ int run_dedup(vn_engine* h, const Batch& b, float* gradbuf) {
   HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, h->dd_uv, h->dd_ug, grid, h->pgrad_wgs, h->stream));
   VnDedupArgs a{};
   a.uv = h->dd_uv; a.ug = h->dd_ug; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
-  a.gcoef = b.gcoef; a.source = h->cfg.has_source ? b.source : nullptr;
+  a.gcoef = b.gcoef; a.gcoef_csr = b.gcsr; a.source = h->cfg.has_source ? b.source : nullptr;
   a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
   a.detJv = b.detJv; a.detJ = (float)b.detJ; a.n_k = b.n_k; a.U = b.U; a.q = q; a.dim = dim;
   a.time_dependent = h->cfg.time_dependent; a.w2 = (float)h->w[2];
@@ -577,6 +579,8 @@ int vn_destroy(vn_engine* h) {
                   h->dd_losspart, h->tp_losspart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (Batch& b : h->batches)
+    if (b.gcsr) (void)hipFree(b.gcsr);
   for (auto e : h->ev0) if (e) (void)hipEventDestroy(e);
   for (auto e : h->ev1) if (e) (void)hipEventDestroy(e);
   for (auto e : h->cev0) if (e) (void)hipEventDestroy(e);
@@ -760,6 +764,16 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     HIPCHK(hipMalloc((void**)&h->dd_losspart, (size_t)need_lp * sizeof(float)));
     h->dd_cap_lp = need_lp;
   }
+  // gcoef in CSR order (the gather kernel then reads it, like rowidx, as one contiguous stream: the per-row gather of 8-byte
+  // entries fetched 2.6 x the bytes it used, profiles/r5_pmc_traffic_dedup.json).  gcoef is static per batch: permuted once here.
+  const long nT = b.n_k * h->cfg.integ_num;
+  if (nT * dim > b.gcsr_cap) {
+    if (b.gcsr) (void)hipFree(b.gcsr);
+    b.gcsr = nullptr; b.gcsr_cap = 0;
+    HIPCHK(hipMalloc((void**)&b.gcsr, (size_t)nT * dim * sizeof(float)));
+    b.gcsr_cap = nT * dim;
+  }
+  HIPCHK(vn_dedup_permute_launch(b.gcoef, rowidx, b.gcsr, nT, dim, h->stream));
   b.Xu = Xu; b.U = U; b.uid = uid; b.rowptr = rowptr; b.rowidx = rowidx;
   return VN_OK;
 }

@@ -90,37 +90,57 @@ __global__ __launch_bounds__(256) void vn_dedup_seed_kernel(VnDedupArgs a) {
   }
 }
 
-// One thread per unique point sums the seeds of its rows in CSR order (fixed -> bitwise reproducible).  The chain
-// rowidx[e] -> srow[r], gcoef[r] is two dependent gathers per row; the loads of four rows are issued together before
-// the sums (same order of additions as a one-row-at-a-time walk), so a thread has eight gathers in flight, not two.
+// Seed gather: d loss / d u and d loss / d u_{x_d} of a unique point = sum over its rows, in CSR order (fixed -> bitwise
+// reproducible).  A block owns VN_GATHER_PB consecutive unique points, i.e. one contiguous range of CSR entries.  Phase 1 walks
+// that range ONE ENTRY PER THREAD -- row index and CSR-ordered gcoef are contiguous streams, the row's seed is the one true gather
+// (4 bytes out of a 25-MB array that lives in the last-level cache) -- and leaves the per-entry products in LDS; all loads of a
+// thread are independent, none waits for a neighbour's.  Phase 2: every point adds up its own entries from LDS in order.
+// (Round 5, first form: one thread per point walking its rows -- three dependent load latencies per four rows, 55 us; and before
+// that a gather of gcoef by row, which fetched 2.6 x the bytes it used.)
+constexpr int VN_GATHER_PB = 256;           // unique points per block
+constexpr int VN_GATHER_CH = 2304;          // CSR entries per LDS chunk (256 points x 8 rows + slack: normally one chunk)
 __global__ __launch_bounds__(256) void vn_dedup_gather_kernel(VnDedupArgs a) {
-  const long j = (long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= a.U) return;
-  const int dim = a.dim, q = a.q;
+  __shared__ float sp[VN_GATHER_CH][4];     // (-dNt s, g0 s, g1 s, g2 s) per entry
+  __shared__ int sptr[VN_GATHER_PB + 1];
+  const int tid = threadIdx.x, dim = a.dim, q = a.q;
+  const long j0 = (long)blockIdx.x * VN_GATHER_PB;
+  const int nj = (int)((a.U - j0 < VN_GATHER_PB) ? a.U - j0 : VN_GATHER_PB);
+  for (int i = tid; i <= nj; i += 256) sptr[i] = a.rowptr[j0 + i];
+  __syncthreads();
+  const int e0 = sptr[0], e1 = sptr[nj];
+  const int s0 = (tid < nj) ? sptr[tid] : 0, s1 = (tid < nj) ? sptr[tid + 1] : 0;
   float su = 0.f, sg[3] = {0.f, 0.f, 0.f};
-  const int e1 = a.rowptr[j + 1];
-  for (int e = a.rowptr[j]; e < e1; e += 4) {
-    long r[4];
-    float s[4], g[4][3];
+  for (int base = e0; base < e1; base += VN_GATHER_CH) {
+    const int n = (e1 - base < VN_GATHER_CH) ? e1 - base : VN_GATHER_CH;
+    for (int i = tid; i < n; i += 256) {
+      const long e = (long)base + i;
+      const long r = a.rowidx[e];
+      const float s = a.srow[r];
+      sp[i][0] = a.time_dependent ? -(a.fedNt[(int)(r % q)] * s) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (e + i < e1) ? a.rowidx[e + i] : -1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      s[i] = (r[i] >= 0) ? a.srow[r[i]] : 0.f;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) g[i][d] = (r[i] >= 0 && d < dim) ? a.gcoef[r[i] * dim + d] : 0.f;
+      for (int d = 0; d < 3; ++d) sp[i][1 + d] = (d < dim) ? a.gcoef_csr[e * dim + d] * s : 0.f;
     }
+    __syncthreads();
+    const int lo = (s0 > base) ? s0 : base, hi = (s1 < base + n) ? s1 : base + n;
+    for (int e = lo; e < hi; ++e) {
+      su += sp[e - base][0];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (r[i] < 0) continue;
-      if (a.time_dependent) su -= a.fedNt[(int)(r[i] % q)] * s[i];
-#pragma unroll
-      for (int d = 0; d < 3; ++d)
-        if (d < dim) sg[d] += g[i][d] * s[i];
+      for (int d = 0; d < 3; ++d) sg[d] += sp[e - base][1 + d];
     }
+    __syncthreads();
   }
-  a.seed_u[j] = su;
-  for (int d = 0; d < dim; ++d) a.seed_g[j * dim + d] = sg[d];
+  if (tid < nj) {
+    a.seed_u[j0 + tid] = su;
+    for (int d = 0; d < dim; ++d) a.seed_g[(j0 + tid) * dim + d] = sg[d];
+  }
+}
+
+// gcoef_csr[e] = gcoef[rowidx[e]]: once per vn_set_dedup
+__global__ __launch_bounds__(256) void vn_dedup_permute_kernel(const float* gcoef, const int* rowidx, float* out, long nT, int dim) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nT) return;
+  const long r = rowidx[e];
+  for (int d = 0; d < dim; ++d) out[e * dim + d] = gcoef[r * dim + d];
 }
 
 }  // namespace
@@ -130,8 +150,14 @@ hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t vn_dedup_permute_launch(const float* gcoef, const int* rowidx, float* gcoef_csr, long nT, int dim, hipStream_t s) {
+  if (nT <= 0) return hipSuccess;
+  hipLaunchKernelGGL(vn_dedup_permute_kernel, dim3((unsigned)((nT + 255) / 256)), dim3(256), 0, s, gcoef, rowidx, gcoef_csr, nT, dim);
+  return hipGetLastError();
+}
+
 hipError_t vn_dedup_gather_launch(const VnDedupArgs& a, hipStream_t s) {
-  const int grid = (int)((a.U + 255) / 256);
+  const int grid = (int)((a.U + VN_GATHER_PB - 1) / VN_GATHER_PB);
   hipLaunchKernelGGL(vn_dedup_gather_kernel, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }

@@ -438,28 +438,43 @@ __global__ __launch_bounds__(64 * RED_GROUPS) void vn_reduce_kernel(const float*
       opt.theta[p] = th - mi;
     }
   }
-  // loss scalars: wave 1 of block 0 folds the per-workgroup partials (lane-strided, then a fixed
-  // shuffle tree, in fp64)
-  if (blockIdx.x == 0 && grp == 1 && losspart != nullptr) {
+  // loss scalars: wave 1 of block 0 folds the per-workgroup partials (lane-strided, four rows per lane in flight, then a
+  // fixed shuffle tree, in fp64).  The de-duplicated step hands over one row per 32 test functions (3 381 rows on the bench
+  // workload: 14 dependent round trips for one wave, 21 us): beyond 1 024 rows ALL waves of block 0 but the first fold a
+  // slice each and wave 1 adds the fifteen sub-sums in wave order.  Either way the order is fixed: bitwise reproducible.
+  if (blockIdx.x == 0 && losspart != nullptr) {
+    __shared__ double lsub[RED_GROUPS][3];
+    const bool wide = nlp > 1024;
+    const int nw = wide ? RED_GROUPS - 1 : 1, w = wide ? grp - 1 : 0;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    for (int gb = lane; gb < nlp; gb += 64 * 4) {       // four rows of partials per lane in flight
-      float a[4][3];
+    if (wide ? grp >= 1 : grp == 1) {
+      for (int gb = w * 64 + lane; gb < nlp; gb += 64 * nw * 4) {
+        float a[4][3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int g = gb + 64 * j;
+        for (int j = 0; j < 4; ++j) {
+          const int g = gb + 64 * nw * j;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a[j][c] = g < nlp ? losspart[g * 3 + c] : 0.f;
+          for (int c = 0; c < 3; ++c) a[j][c] = g < nlp ? losspart[g * 3 + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { t0 += (double)a[j][0]; t1 += (double)a[j][1]; t2 += (double)a[j][2]; }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { t0 += (double)a[j][0]; t1 += (double)a[j][1]; t2 += (double)a[j][2]; }
+      for (int o = 32; o > 0; o >>= 1) {
+        t0 += __shfl_down(t0, o, 64);
+        t1 += __shfl_down(t1, o, 64);
+        t2 += __shfl_down(t2, o, 64);
+      }
+      if (wide && lane == 0) { lsub[grp][0] = t0; lsub[grp][1] = t1; lsub[grp][2] = t2; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      t0 += __shfl_down(t0, o, 64);
-      t1 += __shfl_down(t1, o, 64);
-      t2 += __shfl_down(t2, o, 64);
+    if (wide) {                                       // (block-uniform: nlp is a kernel argument)
+      __syncthreads();
+      if (grp == 1 && lane == 0) {
+        t0 = t1 = t2 = 0.0;
+        for (int v = 1; v < RED_GROUPS; ++v) { t0 += lsub[v][0]; t1 += lsub[v][1]; t2 += lsub[v][2]; }
+      }
     }
-    if (lane == 0) {
+    if (grp == 1 && lane == 0) {
       const double var = t0;
       const double bc = bDof > 0 ? t1 / (double)bDof : 0.0;               // reduce_mean, TFModel.py:645
       const double ic = (nB - bDof) > 0 ? t2 / (double)(nB - bDof) : 0.0; // TFModel.py:648

@@ -122,6 +122,7 @@ struct VnDedupArgs {
   const int* uid;                            // [nT] row -> unique point
   const int* rowptr; const int* rowidx;      // CSR unique point -> rows
   const float* gcoef; const float* source;   // [nT, dim], [nT] or nullptr
+  const float* gcoef_csr;                    // [nT, dim]: gcoef[rowidx[e]] (what the gather kernel reads, contiguously)
   const float* feN; const float* fedNt; const float* feW;
   const float* detJv; float detJ;
   long n_k, U; int q, dim, time_dependent;
@@ -134,6 +135,7 @@ struct VnDedupArgs {
 constexpr int VN_DEDUP_TFB = 32;            // test functions per workgroup of the seed kernel = per loss partial (grid = ceil(n_k / 32))
 hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s);
 hipError_t vn_dedup_gather_launch(const VnDedupArgs& a, hipStream_t s);
+hipError_t vn_dedup_permute_launch(const float* gcoef, const int* rowidx, float* gcoef_csr, long nT, int dim, hipStream_t s);
 
 // ---- simple per-point evaluation kernels (float / double): vn_pointwise.hip --------------
 hipError_t vn_pointwise_forward_f32(const VnNet& net, const float* theta, const float* X, long n,
