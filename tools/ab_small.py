@@ -21,7 +21,15 @@ for wl in sys.argv[2].split(','):
     engs = []
     for nm in names:
         lib = 'libvarnet_hip_%s.so' % nm if nm else 'libvarnet_hip.so'
-        engine._lib = engine.load_library(os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), lib))
+        path = os.path.join(os.path.dirname(os.path.abspath(engine.__file__)), lib)
+        import ctypes
+        _probe = ctypes.CDLL(path)
+        engine.VN_ABI_VERSION = _probe.vn_abi_version()     # an older build may report an older ABI; the entry points used here have not changed
+        _all = getattr(engine, '_SIGS_ALL', None) or dict(engine._SIGS)
+        engine._SIGS_ALL = _all
+        engine._SIGS.clear(); engine._SIGS.update({k: v for k, v in _all.items() if hasattr(_probe, k)})
+        engine._lib = None
+        engine._lib = engine.load_library(path)
         e = engine.VNEngine(dim, d_in, widths, True, q)
         e.init_params(0); e.set_fe_table(N1, dN1); e.set_interior(0, X, G, None, n_k=n_k, detJ=1e-3)
         e.set_bic(bi, bl, nB // 2, 2.0); e.set_weights([1, 1, 1])
