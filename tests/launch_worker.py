@@ -70,7 +70,10 @@ if mode == 'bootstrap':
             assert ordinal == 0
 
         def _gpu_identity(self, ordinal):
-            return ('node%d' % rank, 'uuid:GPU-%04d' % rank) if kind == 'distinct' else ('node0', 'uuid:GPU-0000')
+            # (host, identifiers, visibility mask, ordinal): per-rank masks, every rank sees its card as ordinal 0
+            if kind == 'distinct':
+                return ('node0', 'uuid:GPU-%04d|pci:0:%x:0' % (rank, 0x5a + rank), '%d|' % rank, 0)
+            return ('node0', 'uuid:GPU-0000|pci:0:5a:0', '%s|' % ('0' if rank == 0 else '0,1'), 0)
 
         def comm_unique_id(self):
             return bytes(range(128))

@@ -106,9 +106,18 @@ def test_comm_bootstrap_compares_physical_gpus_not_ordinals(kind, expect_ok, cap
 def test_shared_gpus_flags_exact_duplicates_only():
     sys.path.insert(0, ROOT)
     from varnet_amd.engine import VNEngine
-    assert VNEngine.shared_gpus([('a', 'uuid:1'), ('b', 'uuid:1'), ('a', 'uuid:2')]) == []          # same uuid string on two hosts
-    assert VNEngine.shared_gpus([('a', 'uuid:1'), ('a', 'uuid:2'), ('a', 'uuid:1')]) == [(0, 2)]
-    assert VNEngine.shared_gpus([['a', 'x'], ['a', 'x']]) == [(0, 1)]                                # all_gather_object hands lists back
+    sg = VNEngine.shared_gpus
+    assert sg([('a', 'uuid:1'), ('b', 'uuid:1'), ('a', 'uuid:2')]) == []          # same uuid string on two hosts
+    assert sg([('a', 'uuid:1'), ('a', 'uuid:2'), ('a', 'uuid:1')]) == [(0, 2)]
+    assert sg([['a', 'x'], ['a', 'x']]) == [(0, 1)]                                # all_gather_object hands lists back
+    # one host, ONE visibility mask: the ordinal decides, even when the runtime reports the same (degenerate) identifiers
+    assert sg([('a', 'uuid:0', '0,1|', 0), ('a', 'uuid:0', '0,1|', 1)]) == []
+    assert sg([('a', 'uuid:7', '0,1|', 1), ('a', 'uuid:9', '0,1|', 1)]) == [(0, 1)]
+    # per-rank masks (every rank sees its card as ordinal 0): the identifiers decide
+    assert sg([('a', 'uuid:1|pci:0:5a:0', '0|', 0), ('a', 'uuid:2|pci:0:5b:0', '1|', 0)]) == []
+    assert sg([('a', 'uuid:1|pci:0:5a:0', '0|', 0), ('a', 'uuid:1|pci:0:5a:0', '0,1|', 0)]) == [(0, 1)]
+    # 8 ranks of one node, the launcher's usual picture
+    assert sg([('n', 'uuid:%d' % r, '|', r) for r in range(8)]) == []
 
 
 def test_static_traffic_is_refused_for_another_kernel_or_config():

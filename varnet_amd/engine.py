@@ -426,35 +426,42 @@ class VNEngine:
         self._ck(self.lib.vn_comm_init(self.h, int(rank), int(world), buf))
 
     def _gpu_identity(self, ordinal):
-        """What distinguishes one physical GPU from another across ranks: (host name, device UUID | PCI address).  A device
-        ORDINAL is only unique within one node and one visibility mask: with per-rank HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES
-        (SLURM --gpus-per-task: every rank sees its card as cuda:0) or with several nodes, distinct GPUs share an ordinal."""
+        """What distinguishes one physical GPU from another across ranks: (host name, device UUID + PCI address, visibility
+        mask, ordinal).  A device ORDINAL is only unique within one node and one visibility mask: with per-rank
+        HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (SLURM --gpus-per-task: every rank sees its card as cuda:0) or with several
+        nodes, distinct GPUs share an ordinal."""
         import socket
         p = self.torch.cuda.get_device_properties(ordinal)
-        ident = getattr(p, 'uuid', None)
-        if ident is not None:
-            ident = 'uuid:%s' % ident
-        else:
-            bus = [getattr(p, a, None) for a in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')]
-            if all(b is not None for b in bus):
-                ident = 'pci:%04x:%02x:%02x' % tuple(bus)
-            else:       # nothing physical to read: the ordinal qualified by the visibility mask it is an index into
-                ident = 'ordinal:%d|%s|%s' % (ordinal, os.environ.get('HIP_VISIBLE_DEVICES', ''), os.environ.get('ROCR_VISIBLE_DEVICES', ''))
-        return (socket.gethostname(), ident)
+        uuid = getattr(p, 'uuid', None)
+        bus = [getattr(p, a, None) for a in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')]
+        ident = 'uuid:%s|pci:%s' % (uuid, ':'.join('%x' % b for b in bus) if all(b is not None for b in bus) else None)
+        mask = '%s|%s' % (os.environ.get('HIP_VISIBLE_DEVICES', ''), os.environ.get('ROCR_VISIBLE_DEVICES', ''))
+        return (socket.gethostname(), ident, mask, int(ordinal))
 
     def _make_current(self, ordinal):
         self.torch.cuda.set_device(ordinal)          # what vn_comm_init's hipSetDevice would fail on
 
     @staticmethod
     def shared_gpus(identities):
-        """Ranks that name the SAME physical GPU (exact duplicates of the (host, device) pair): [(rank, rank), ...]."""
-        seen, dup = {}, []
-        for r, ident in enumerate(identities):
-            ident = tuple(ident) if isinstance(ident, (list, tuple)) else ident
-            if ident in seen:
-                dup.append((seen[ident], r))
-            else:
-                seen[ident] = r
+        """Pairs of ranks that name the SAME physical GPU, from (host, device identifiers, visibility mask, ordinal) tuples:
+        on one host, under one visibility mask, the ordinal decides (equal ordinal = same card, different ordinal = different
+        cards whatever the identifiers say: a runtime that reports a degenerate UUID must not cost the ranks their RCCL
+        communicator); under different masks, or with two-field (host, identifier) tuples, equal identifiers decide; ranks on
+        different hosts never share a card."""
+        ids = [tuple(i) if isinstance(i, (list, tuple)) else (i,) for i in identities]
+        dup = []
+        for r in range(len(ids)):
+            for q in range(r):
+                a, b = ids[q], ids[r]
+                if a[0] != b[0]:
+                    continue
+                if len(a) >= 4 and len(b) >= 4 and a[2] == b[2]:
+                    same = a[3] == b[3]
+                else:
+                    same = a[1:2] == b[1:2]
+                if same:
+                    dup.append((q, r))
+                    break
         return dup
 
     def comm_init_from_torch(self, dist):
