@@ -5,7 +5,9 @@ discNum=[80,40], bDiscNum=40, tDiscNum=75) -> 240 000 test functions x 64 = 15.3
 train(weight=[5,1,1], smpScheme='uniform').  Prints the script's "approximation error" against its analytical solution
 (Leij & Dane, integrated over time) at t = T.
 
-    python examples/operator_2dt.py [out_folder] [epochs]
+    python examples/operator_2dt.py [out_folder] [epochs] [dedup]
+(a third argument `dedup` trains on the de-duplicated formulation, train(dedup=True): one network evaluation per unique
+quadrature point -- 2.05 M points instead of 15.36 M rows here; same loss and gradient up to fp32 rounding)
 """
 import os
 import sys
@@ -44,6 +46,7 @@ def cExFun(x, t=None):
 def main():
     folder = sys.argv[1] if len(sys.argv) > 1 else 'out_operator_2dt'
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    dedup = len(sys.argv) > 3 and sys.argv[3] == 'dedup'
     vertices = np.array([[0.0, -0.5], [0.0, -a], [0.0, a], [0.0, 0.5], [2.0, 0.5], [2.0, -0.5]])
     domain = PolygonDomain2D(vertices)
     BC = [[], [0.0, 1.0, c0], [], [], [], []]                  # Dirichlet c = c0 on the inlet segment, natural elsewhere
@@ -53,14 +56,14 @@ def main():
     print('test functions %d, training points per epoch %d, BC/IC points %d' % (fd.nt, fd.nT, int(np.sum(fd.biDof))))
     os.makedirs(folder, exist_ok=True)
     t0 = time.perf_counter()
-    vn.train(folder, weight=[5., 1., 1.], smpScheme='uniform', epochNum=epochs, saveFreq=500, verbose=False)
+    vn.train(folder, weight=[5., 1., 1.], smpScheme='uniform', epochNum=epochs, saveFreq=500, verbose=False, dedup=dedup)
     dt = time.perf_counter() - t0
     vn.loadModel()
     coord = domain.getMesh(discNum=[60, 30], bDiscNum=20).coordinates
     cEx = cExFun(coord, [T])
     cApp = vn.evaluate(coord, T)
-    print('%d epochs in %.1f s (%.2f ms/epoch, %.3e training points/s); approximation error at t = T: %2.5f'
-          % (len(vn.trainRes.lossAll), dt, dt / len(vn.trainRes.lossAll) * 1e3, fd.nT * len(vn.trainRes.lossAll) / dt,
+    print('%s%d epochs in %.1f s (%.2f ms/epoch, %.3e training points/s); approximation error at t = T: %2.5f'
+          % ('de-duplicated formulation: ' if dedup else '', len(vn.trainRes.lossAll), dt, dt / len(vn.trainRes.lossAll) * 1e3, fd.nT * len(vn.trainRes.lossAll) / dt,
              uf.l2Err(cEx, cApp)))
 
 
