@@ -144,6 +144,7 @@ int vn_set_interior(vn_engine* h, int32_t batch, const float* Input_dev, const f
  * uid [n_k*integ_num] row -> unique point and its CSR inverse (rowptr [U+1], rowidx [n_k*integ_num]),
  * vn_grad evaluates value and input gradient once per unique point and assembles the same loss and
  * gradient (same math, different rounding).  All device pointers.  Xu == NULL switches it off.
+ * The map is validated on the device at this call (which therefore synchronises): an inconsistent one returns VN_EINVAL.
  * Requires the 8-wave fused kernel and uniform supports.  The batch's gcoef is READ at this call (the engine keeps a copy
  * in CSR order for its seed gather): register again after changing gcoef in place; vn_set_interior clears the registration. */
 int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu_dev, int64_t U, const int32_t* uid_dev,

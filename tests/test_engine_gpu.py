@@ -536,6 +536,45 @@ def test_forward_grad_parity(d_in, dim, widths, act, n):
     eng.close()
 
 
+def test_inconsistent_dedup_map_is_an_error_not_a_fault():
+    """vn_set_dedup validates the map on the device: every later kernel indexes device memory with it."""
+    from varnet_amd.engine import VNEngine, VNError
+    rng = np.random.default_rng(3)
+    d_in, dim, q, n_k, U = 3, 2, 16, 20, 100
+    n = n_k * q
+    Xu = rng.uniform(-1, 1, (U, d_in)).astype(np.float32)
+    uid = rng.integers(0, U, n).astype(np.int32)
+    uid[:U] = np.arange(U)
+    rowptr, rowidx = _csr(uid, U)
+    eng = VNEngine(dim, d_in, [20, 20], True, q)
+    eng.init_params(seed=1)
+    eng.set_fe_table(rng.uniform(0, 1, q).astype(np.float32), rng.standard_normal(q).astype(np.float32))
+    eng.set_interior(0, Xu[uid], rng.standard_normal((n, dim)).astype(np.float32), None, n_k=n_k, detJ=0.1)
+    eng.set_bic(rng.uniform(-1, 1, (8, d_in)).astype(np.float32), rng.standard_normal((8, 1)).astype(np.float32), 4, 2.0)
+    eng.set_weights([1.0, 1.0, 1.0])
+    eng.set_dedup(0, Xu, uid, rowptr, rowidx)                         # the consistent map registers
+    for what in ('uid', 'rowidx_range', 'rowidx_owner', 'rowptr_end', 'rowptr_order'):
+        u2, rp2, ri2 = uid.copy(), rowptr.copy(), rowidx.copy()
+        if what == 'uid':
+            u2[5] = U + 7
+        elif what == 'rowidx_range':
+            ri2[11] = n + 1000000
+        elif what == 'rowidx_owner':
+            ri2[[0, -1]] = ri2[[-1, 0]]                              # two rows filed under the wrong points
+        elif what == 'rowptr_end':
+            rp2[-1] = n - 1
+        else:
+            rp2[3], rp2[4] = rp2[4] + 5, rp2[3]
+        with pytest.raises(VNError, match='inconsistent de-duplication map'):
+            eng.set_dedup(0, Xu, u2, rp2, ri2)
+    gb = eng.bind_grad_buffer()
+    eng.set_dedup(0, Xu, uid, rowptr, rowidx)
+    eng.grad(0)                                                      # the engine is still usable
+    torch.cuda.synchronize()
+    assert np.isfinite(gb.cpu().numpy()).all()
+    eng.close()
+
+
 def test_forward_grad_refuses_networks_outside_the_fused_family():
     from varnet_amd.engine import VNEngine, VNError
     eng = VNEngine(2, 3, [128, 128], True, 16)

@@ -764,6 +764,22 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     HIPCHK(hipMalloc((void**)&h->dd_losspart, (size_t)need_lp * sizeof(float)));
     h->dd_cap_lp = need_lp;
   }
+  // The map indexes device memory in every later kernel: validate it once, here (a registration call may synchronise), so
+  // that an inconsistent map is an error code and never a GPU fault.  The rowptr reads assume U + 1 entries, rowidx / uid nT.
+  {
+    const long nTc = b.n_k * h->cfg.integ_num;
+    int* err_dev = nullptr;
+    HIPCHK(hipMalloc((void**)&err_dev, sizeof(int)));
+    hipError_t e = hipMemsetAsync(err_dev, 0, sizeof(int), h->stream);
+    if (e == hipSuccess) e = vn_dedup_check_launch(uid, rowptr, rowidx, nTc, U, err_dev, h->stream);
+    int bad = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, err_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(err_dev);
+    if (e != hipSuccess) return fail(VN_EHIP, "vn_set_dedup: %s", hipGetErrorString(e));
+    if (bad) return fail(VN_EINVAL, "inconsistent de-duplication map: %d violation(s) (need 0 <= uid < U, rowptr[0] = 0 <= ... <= rowptr[U] = n_k*integ_num, "
+                                    "0 <= rowidx < n_k*integ_num and uid[rowidx[e]] = the point whose segment holds e)", bad);
+  }
   // gcoef in CSR order (the gather kernel then reads it, like rowidx, as one contiguous stream: the per-row gather of 8-byte
   // entries fetched 2.6 x the bytes it used, profiles/r5_pmc_traffic_dedup.json).  gcoef is static per batch: permuted once here.
   const long nT = b.n_k * h->cfg.integ_num;

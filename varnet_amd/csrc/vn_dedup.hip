@@ -135,6 +135,31 @@ __global__ __launch_bounds__(256) void vn_dedup_gather_kernel(VnDedupArgs a) {
   }
 }
 
+// Registration-time check of a de-duplication map (vn_set_dedup): every later kernel indexes device memory with these
+// arrays, so an inconsistent map must come back as an error code, not as a GPU fault.  err[0] = number of violations:
+// uid[r] in [0, U); rowptr[0] = 0, non-decreasing, rowptr[U] = nT; rowidx[e] in [0, nT) and uid[rowidx[e]] = the point
+// whose segment holds e.
+__global__ __launch_bounds__(256) void vn_dedup_check_kernel(const int* uid, const int* rowptr, const int* rowidx, long nT, long U,
+                                                             int* err) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  int bad = 0;
+  if (i < nT) bad += (uid[i] < 0 || uid[i] >= U);
+  if (i == 0) bad += (rowptr[0] != 0) + (rowptr[U] != nT);
+  if (i < U) {
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    if (e0 > e1 || e0 < 0 || e1 > nT) {
+      bad += 1;
+    } else {
+      for (int e = e0; e < e1; ++e) {
+        const int r = rowidx[e];
+        if (r < 0 || r >= nT) bad += 1;
+        else if (uid[r] != i) bad += 1;
+      }
+    }
+  }
+  if (bad) atomicAdd(err, bad);
+}
+
 // gcoef_csr[e] = gcoef[rowidx[e]]: once per vn_set_dedup
 __global__ __launch_bounds__(256) void vn_dedup_permute_kernel(const float* gcoef, const int* rowidx, float* out, long nT, int dim) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -147,6 +172,13 @@ __global__ __launch_bounds__(256) void vn_dedup_permute_kernel(const float* gcoe
 
 hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL(vn_dedup_seed_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t vn_dedup_check_launch(const int* uid, const int* rowptr, const int* rowidx, long nT, long U, int* err_dev, hipStream_t s) {
+  const long n = nT > U ? nT : U;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(vn_dedup_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, uid, rowptr, rowidx, nT, U, err_dev);
   return hipGetLastError();
 }
 

@@ -135,6 +135,8 @@ struct VnDedupArgs {
 constexpr int VN_DEDUP_TFB = 32;            // test functions per workgroup of the seed kernel = per loss partial (grid = ceil(n_k / 32))
 hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s);
 hipError_t vn_dedup_gather_launch(const VnDedupArgs& a, hipStream_t s);
+// *err_dev += number of inconsistencies of the map (see vn_dedup_check_kernel); err_dev must hold 0 on entry
+hipError_t vn_dedup_check_launch(const int* uid, const int* rowptr, const int* rowidx, long nT, long U, int* err_dev, hipStream_t s);
 hipError_t vn_dedup_permute_launch(const float* gcoef, const int* rowidx, float* gcoef_csr, long nT, int dim, hipStream_t s);
 
 // ---- simple per-point evaluation kernels (float / double): vn_pointwise.hip --------------
