@@ -145,7 +145,8 @@ int vn_set_interior(vn_engine* h, int32_t batch, const float* Input_dev, const f
  * vn_grad evaluates value and input gradient once per unique point and assembles the same loss and
  * gradient (same math, different rounding).  All device pointers.  Xu == NULL switches it off.
  * The map is validated on the device at this call (which therefore synchronises): an inconsistent one returns VN_EINVAL.
- * Requires the 8-wave fused kernel and uniform supports.  The batch's gcoef is READ at this call (the engine keeps a copy
+ * Requires a network of the 8-wave fused kernel (integ_num <= 256: the two-pass route's 216 included) and uniform supports.
+ * The batch's gcoef is READ at this call (the engine keeps a copy
  * in CSR order for its seed gather): register again after changing gcoef in place; vn_set_interior clears the registration. */
 int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu_dev, int64_t U, const int32_t* uid_dev,
                  const int32_t* rowptr_dev, const int32_t* rowidx_dev);

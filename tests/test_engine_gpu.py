@@ -433,6 +433,9 @@ def _csr(uid, U):
     (2, 1, [50, 50, 50],         36,  53,  700,  31, 11,  True,  True),       # integPnum 3 in 1D+t
     (2, 1, [24, 31],             100, 37,  900,  8,  5,   False, True),       # integPnum 5 in 1D+t
     (4, 3, [50, 50, 50, 50],     64,  21,  333,  40, 22,  True,  False),      # dim 3 (+ time): three coordinates in one sweep
+    # beyond one 128-point tile (the two-pass route's networks): the formulation has no tiles of whole test functions
+    (3, 2, [50, 50, 50, 50, 50], 216, 11,  410,  33, 17,  True,  True),       # integPnum 3 in 2D+t
+    (4, 3, [20, 30],             256, 7,   600,  12, 6,   False, False),      # integPnum 2 in 3D+t
 ])
 def test_dedup_formulation_parity(case):
     """De-duplicated formulation (one network evaluation per unique quadrature point): same loss

@@ -246,6 +246,27 @@ def test_dedup_training_matches_rowwise(tmp_path):
     assert np.max(np.abs(losses[0] - losses[1]) / losses[0]) < 2e-3
 
 
+def test_dedup_training_three_point_gauss(tmp_path):
+    """train(dedup=True) with integPnum = 3 in 2D+t: 216 quadrature points per test function do not fit one 128-point tile (the
+    row-wise step runs the two-pass route, 8 F_pt per ROW); the de-duplicated formulation has no such tiles and evaluates the
+    27 points of an element once (8 F_pt per UNIQUE point): same loss trajectory to fp32 rounding."""
+    verts = np.array([[0.0, -0.5], [0.0, -0.2], [0.0, 0.2], [0.0, 0.5], [2.0, 0.5], [2.0, -0.5]])
+    BC = [[], [0.0, 1.0, 1.0], [], [], [], []]
+    losses = []
+    for dd in (False, True):
+        pde = ADPDE(PolygonDomain2D(verts), diff=1e-3, vel=[1., 0.], tInterval=[0, 1.5], BCs=BC, IC=0.0)
+        vn = VarNet(pde, layerWidth=[20, 20, 20], discNum=[8, 6], bDiscNum=6, tDiscNum=8, integPnum=3)
+        assert vn.fixData.integNum == 216 and vn.engine.kernel_path() == (3, True)
+        res = vn.train(str(tmp_path / ('g3dd%d' % dd)), weight=[5., 1., 1.], epochNum=40, saveFreq=20, verbose=False, dedup=dd)
+        if dd:
+            assert vn.tData.dedup_on
+            U = vn.tData._dd_cache[(0, 0)][0].shape[0]
+            assert vn.fixData.nT / U > 5.0
+        losses.append(np.array(res.lossAll))
+        vn.engine.close()
+    assert np.max(np.abs(losses[0] - losses[1]) / losses[0]) < 2e-3
+
+
 def test_shuffled_feeds_on_device(tmp_path):
     """Non-MOR mini-batches with shuffleData: after a shuffle every mini-batch carries its own permutation of the BC/IC rows
     (vn_set_batch_bic; the reference's quirk, VarNetUtility.py:988-996).  One shuffled mini-batch's loss / gradient against

@@ -741,7 +741,10 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     return VN_OK;
   }
   if (!uid || !rowptr || !rowidx || U <= 0) return fail(VN_EINVAL, "null argument");
-  if (!h->use_fused16) return fail(VN_EUNSUPPORTED, "de-duplication needs the 8-wave fused kernel for this network");
+  // the formulation has no tiles of whole test functions (its rows are unique points), so it also serves integ_num beyond one
+  // 128-point tile -- the networks of the two-pass route (216: three-point Gauss in 2D+t) -- up to the seed kernel's 256-row chunk
+  if (!h->use_fused16 && !h->two_pass) return fail(VN_EUNSUPPORTED, "de-duplication needs the 8-wave fused kernel for this network");
+  if (h->cfg.integ_num > 256) return fail(VN_EUNSUPPORTED, "de-duplication supports integ_num <= 256");
   if (b.Nrow || b.detJv) return fail(VN_EUNSUPPORTED, "de-duplication needs uniform supports (no per-row tables)");
   if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "de-duplication supports dim <= 3");
   HIPCHK(hipSetDevice(h->cfg.device));
@@ -837,7 +840,7 @@ int vn_grad(vn_engine* h, int32_t batch) {
   if (int rc = check_batch(h, batch)) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   const Batch& b = h->batches[batch];
-  if (b.Xu && h->use_fused16) return run_dedup(h, b, h->gradbuf);
+  if (b.Xu && (h->use_fused16 || h->two_pass)) return run_dedup(h, b, h->gradbuf);
   if (h->two_pass) return run_twopass(h, b, h->gradbuf);
   if (h->use_fused) {
     VnFusedArgs a{};

@@ -555,8 +555,10 @@ class VNEngine:
         return k.value, bool(tp.value)
 
     def dedup_supported(self):
+        """The de-duplicated formulation needs a network of the 8-wave fused kernel; it has no tiles of whole test functions, so it
+        also serves the two-pass route's integNum (216: three-point Gauss in 2D+t) up to the seed kernel's 256-row chunk."""
         k, tp = self.kernel_path()
-        return k == VN_KERNEL_FUSED16 and not tp
+        return k == VN_KERNEL_FUSED16 and (not tp or self.integNum <= 256)
 
     def calibrate(self):
         """Sustained fp32 MFMA rate and fp32 vector issue cost of this GPU (vn_calib.hip): dict for bench.py."""
