@@ -53,16 +53,18 @@ def test_launch_deadline_says_where_every_rank_was(capfd):
     sys.path.insert(0, ROOT)
     from varnet_amd import launch
     t0 = time.time()
-    rc = launch.spawn_ranks([WORKER, 'stuck'], 2, deadline_s=4.0, import_grace_s=60.0)
+    # (the clock starts when both ranks have finished their imports; the gloo rendezvous behind that takes a few seconds on a
+    # loaded machine, so the deadline leaves room for both ranks to reach `comm_init` before it expires)
+    rc = launch.spawn_ranks([WORKER, 'stuck'], 2, deadline_s=15.0, import_grace_s=90.0)
     dt = time.time() - t0
-    assert rc == 124 and dt < 100
+    assert rc == 124 and dt < 150
     out = capfd.readouterr().out
     lines = [json.loads(ln) for ln in out.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     js = lines[0]
     assert 'deadline' in js['error'] and js['alive'] == [0, 1] and js['ranks'] == 2
     assert js['last_stage'] == {'0': 'comm_init', '1': 'comm_init'}
-    assert js['s_in_last_stage']['1'] >= 3.5
+    assert js['s_in_last_stage']['1'] >= 5.0
     assert launch.last_report['reason'].startswith('launch deadline')
 
 
