@@ -47,6 +47,8 @@ def run_rank(rank, world, port, outdir, backend, engine, problem, train_kw, tag,
     res = vn.train(os.path.join(outdir, '%s_w%d' % (tag, world)), **train_kw)
     theta = vn.engine.theta if engine != 'hip' else vn.engine.get_params()
     td = vn.tData
+    if engine == 'hip' and train_kw.get('dedup'):
+        assert td.dedup_on, 'train(dedup=True) did not engage the de-duplicated formulation on rank %d' % rank
     inp = td.mor[0]['Input']
     inp = inp.cpu().numpy() if hasattr(inp, 'cpu') else np.asarray(inp)
     np.savez(os.path.join(outdir, '%s_w%d_r%d.npz' % (tag, world, rank)), theta=np.asarray(theta, dtype=np.float64),

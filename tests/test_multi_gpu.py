@@ -99,6 +99,22 @@ def test_two_ranks_share_one_gpu_gloo(tmp_path, batchNum):
     assert str(b0['comm']) == 'torch' and list(b0['block']) == [0, 300] and list(b1['block']) == [300, 600]
 
 
+def test_two_ranks_dedup_matches_one_rank_gloo(tmp_path):
+    """train(dedup=True) under towers: every rank de-duplicates its own contiguous block of test functions (points on the
+    seam between the blocks are evaluated once per rank), the gradient SUM is unchanged -- world 2 reproduces the one-rank
+    de-duplicated run, and that run the row-wise one."""
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    out = str(tmp_path)
+    kw = dict(weight=[10., 10., 1.], epochNum=30, saveFreq=1000, verbose=False, dedup=True)
+    rw.launch(conftest.FORKSERVER, 1, out, 'gloo', 'hip', _problem(), kw, 'd')
+    rw.launch(conftest.FORKSERVER, 2, out, 'gloo', 'hip', _problem(), kw, 'd')
+    a, b0, b1 = _compare(out, 'd', 2e-4, 2e-4)
+    rw.launch(conftest.FORKSERVER, 1, out, 'gloo', 'hip', _problem(), dict(kw, dedup=False), 'r')
+    r = np.load(os.path.join(out, 'r_w1_r0.npz'))
+    np.testing.assert_allclose(a['loss'], r['loss'], rtol=2e-4)
+
+
 def test_rccl_missing_on_one_rank_falls_back_on_all_ranks(tmp_path):
     """VN_COMM=try attempts the in-engine RCCL communicator; rank 1 alone cannot load RCCL
     (VN_RCCL_LIB names a missing file).  The bootstrap must not hang or mismatch collectives: BOTH ranks skip the
