@@ -733,6 +733,8 @@ def _main():
                 "backend": ("RCCL communicator inside the engine (vn_comm_init / vn_allreduce_grad)" if vn.comm == 'rccl'
                             else "torch.distributed " + dist.get_backend()),
                 "ranks_reported": int(n_ranks), "payload_bytes": (P + 4) * 4,
+                # '' when the engine's own communicator is up; else why all ranks kept the SUM in torch.distributed
+                "in_engine_rccl_skipped_because": getattr(vn, 'comm_why', ''),
                 # what summed the gradient: the version of the RCCL library this process loaded (ncclGetVersion) and the
                 # (ranks, rank) the engine's communicator reports (vn_comm_size; [1, 0] when the collective is torch's)
                 "rccl_version": eng.comm_version(), "vn_comm_size": list(eng.comm_size()),
@@ -766,6 +768,9 @@ def _main():
         dist.destroy_process_group()
     mark_stage('done')
     disarm()
+    if getattr(eng, '_comm_abandoned', False):     # a helper thread still sits in ncclCommInitRank: do not wait for it at exit
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

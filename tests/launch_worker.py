@@ -6,6 +6,7 @@
     launch_worker.py bootstrap KIND VNEngine.comm_init_from_torch over gloo on a stand-in engine whose probes are scripted:
                                     KIND = distinct  the ranks share ORDINAL 0 but sit on different hosts / devices
                                     KIND = same      both ranks name the same (host, device)
+                                    KIND = wedged    rank 1's comm_init never returns (a wedged ncclCommInitRank)
                                     prints {"rank":, "ok":, "why":} per rank
 """
 import json
@@ -73,23 +74,32 @@ if mode == 'bootstrap':
             # (host, identifiers, visibility mask, ordinal): per-rank masks, every rank sees its card as ordinal 0
             if kind == 'distinct':
                 return ('node0', 'uuid:GPU-%04d|pci:0:%x:0' % (rank, 0x5a + rank), '%d|' % rank, 0)
+            if kind == 'wedged':
+                return ('node0', 'uuid:GPU-%04d|pci:0:%x:0' % (rank, 0x5a + rank), '0,1|', rank)
             return ('node0', 'uuid:GPU-0000|pci:0:5a:0', '%s|' % ('0' if rank == 0 else '0,1'), 0)
 
         def comm_unique_id(self):
             return bytes(range(128))
 
+        destroyed = False
+
         def comm_init(self, r, w, uid):
             assert uid == bytes(range(128))
+            if kind == 'wedged' and r == 1:
+                time.sleep(600)
             self.inited = (r, w)
 
         def comm_destroy(self):
             self.inited = None
+            self.destroyed = True
 
     eng = StandIn()
     ok, why = VNEngine.comm_init_from_torch(eng, dist)
-    print(json.dumps({"rank": rank, "ok": bool(ok), "why": why, "inited": eng.inited, "last_stage": mark_stage.last}), flush=True)
+    print(json.dumps({"rank": rank, "ok": bool(ok), "why": why, "inited": eng.inited, "last_stage": mark_stage.last,
+                      "abandoned": bool(getattr(eng, '_comm_abandoned', False)), "destroyed": eng.destroyed}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    sys.exit(0)
+    sys.stdout.flush()
+    os._exit(0)                # (a helper thread may still sit in the scripted wedge)
 
 raise SystemExit('unknown mode ' + mode)

@@ -105,6 +105,22 @@ def test_comm_bootstrap_compares_physical_gpus_not_ordinals(kind, expect_ok, cap
             assert js['inited'] is None and 'share a physical GPU' in js['why'] and js['last_stage'] == 'probe'
 
 
+def test_comm_bootstrap_survives_a_wedged_comm_init(capfd):
+    """ncclCommInitRank has no timeout.  Rank 1's comm_init never returns: within $VN_COMM_INIT_TIMEOUT_S BOTH ranks fall back
+    to torch.distributed, and rank 0 -- whose communicator came up -- abandons it instead of calling ncclCommDestroy against
+    a wedged peer.  A first multi-GPU run then still produces its numbers (on the three-call path) instead of a dead record."""
+    sys.path.insert(0, ROOT)
+    from varnet_amd import launch
+    rc = launch.spawn_ranks([WORKER, 'bootstrap', 'wedged'], 2, deadline_s=120.0, env_extra={'VN_COMM_INIT_TIMEOUT_S': '3'})
+    assert rc == 0
+    lines = {js['rank']: js for js in (json.loads(ln) for ln in capfd.readouterr().out.splitlines() if ln.startswith('{'))}
+    assert sorted(lines) == [0, 1]
+    for r, js in lines.items():
+        assert js['ok'] is False and js['abandoned'] is True and js['destroyed'] is False and js['last_stage'] == 'comm_agree'
+    assert 'did not return within 3 s on rank 1' in lines[1]['why'] and 'abandoned' in lines[0]['why']
+    assert lines[0]['inited'] == [0, 2] and lines[1]['inited'] is None
+
+
 def test_shared_gpus_flags_exact_duplicates_only():
     sys.path.insert(0, ROOT)
     from varnet_amd.engine import VNEngine

@@ -99,6 +99,64 @@ def test_two_ranks_share_one_gpu_gloo(tmp_path, batchNum):
     assert str(b0['comm']) == 'torch' and list(b0['block']) == [0, 300] and list(b1['block']) == [300, 600]
 
 
+def _bootstrap_world1(q):
+    """forked child: a one-rank gloo group, then the whole bootstrap VarNet runs at world > 1 -- probes, id broadcast, the REAL
+    ncclCommInitRank on its helper thread, agreement -- and training steps through the communicator made there"""
+    try:
+        import socket
+        import torch
+        import torch.distributed as dist
+        from tests.test_engine_gpu import synth
+        from varnet_amd.engine import VNEngine
+        sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+        dist.init_process_group('gloo', rank=0, world_size=1, init_method='tcp://127.0.0.1:%d' % port)
+        d = synth(5, 3, 2, [50] * 5, 64, 40, 60, 25)
+        outs = []
+        for use_comm in (False, True):
+            eng = VNEngine(2, 3, [50] * 5, True, 64)
+            eng.init_params(seed=3)
+            eng.set_fe_table(d['N1'], d['dNt1'], None)
+            eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=40, detJ=d['detJ'])
+            eng.set_bic(d['biInput'], d['biLabel'], 25, 2.0)
+            eng.set_weights(d['w'])
+            if use_comm:
+                ok, why = eng.comm_init_from_torch(dist)
+                assert ok and why == '', why
+                assert eng.comm_size() == (1, 0) and not getattr(eng, '_comm_abandoned', False)
+            acc = torch.zeros((), dtype=torch.float32, device='cuda')
+            for _ in range(5):
+                eng.train_epoch([0], acc)                    # main thread drives the communicator the helper thread created
+            torch.cuda.synchronize()
+            if use_comm:
+                eng.comm_destroy()
+            outs.append((eng.get_params(), float(acc.item())))
+            eng.close()
+        dist.destroy_process_group()
+        np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=1e-6)
+        np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-6, atol=1e-7)
+        q.put((0, 'ok'))
+    except Exception:
+        import traceback
+        q.put((1, traceback.format_exc()))
+
+
+def test_bootstrap_through_torch_with_the_real_rccl_world1():
+    """VNEngine.comm_init_from_torch end to end against the REAL library (a communicator of one rank is the most a one-GPU box
+    allows): since round 5 ncclCommInitRank runs on a helper thread with a timeout; the communicator it creates must serve the
+    main thread's training steps."""
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    from varnet_amd.engine import VNEngine
+    if not VNEngine.comm_available():
+        pytest.skip('RCCL cannot be loaded on this box')
+    q = conftest.FORKSERVER.Queue()
+    p = conftest.FORKSERVER.Process(target=_bootstrap_world1, args=(q,))
+    p.start()
+    rc, text = q.get(timeout=300)
+    p.join(60)
+    assert rc == 0, text
+
+
 def test_two_ranks_dedup_matches_one_rank_gloo(tmp_path):
     """train(dedup=True) under towers: every rank de-duplicates its own contiguous block of test functions (points on the
     seam between the blocks are evaluated once per rank), the gradient SUM is unchanged -- world 2 reproduces the one-rank

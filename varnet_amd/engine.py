@@ -198,6 +198,9 @@ class VNEngine:
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
+            if getattr(self, '_comm_abandoned', False):
+                self.h = None                        # vn_destroy would call ncclCommDestroy on a communicator whose peer is wedged
+                return
             self.lib.vn_destroy(self.h)
             self.h = None
 
@@ -475,10 +478,12 @@ class VNEngine:
              visibility masks (RCCL refuses a device that appears twice in a communicator: ranks sharing a card over gloo,
              VN_COMM=try);
           3. rank 0 makes the id inside try/except and ALWAYS broadcasts an (ok, id) pair;
-          4. all ranks call comm_init together, then agree (MIN) that it came up everywhere; else all destroy.
-        What is NOT covered: a rank that dies, or whose ncclCommInitRank fails on its own, between 3 and 4 leaves its peers
-        in RCCL's bootstrap until RCCL gives up; the launcher (varnet_amd/launch.py: deadline + stage breadcrumbs, towers.py)
-        ends the peers of a dead rank and says where every rank last was.
+          4. all ranks call comm_init together -- each on a helper thread it waits for at most $VN_COMM_INIT_TIMEOUT_S (90 s) --
+             then agree (MIN) that it came up everywhere; else all destroy, or, if any rank's call has not come back, all
+             ABANDON the communicator (no ncclCommDestroy against a wedged peer) and keep the SUM in torch.distributed.
+        What is NOT covered: a rank that DIES between 3 and 4 leaves its peers' helper threads in RCCL's bootstrap (they fall
+        back after the timeout, then fail in torch's own collective); the launcher (varnet_amd/launch.py: deadline + stage
+        breadcrumbs, towers.py) ends the peers of a dead rank and says where every rank last was.
         Returns (True, '') when the communicator is up on every rank, (False, reason) when all ranks skipped it."""
         from .launch import mark_stage
         rank, world = dist.get_rank(), dist.get_world_size()
@@ -525,14 +530,40 @@ class VNEngine:
         if not ok0:
             return False, 'rank 0 could not create the RCCL id: %s' % payload
         mark_stage('comm_init')
-        up, why = True, ''
-        try:
-            self.comm_init(rank, world, payload)
-        except Exception as e:                       # noqa: BLE001
-            up, why = False, str(e)
+        # ncclCommInitRank has no timeout of its own.  The call runs on a helper thread that this rank waits for at most
+        # $VN_COMM_INIT_TIMEOUT_S (default 90 s; 0 = wait for ever on the calling thread): a rank whose call does not come
+        # back reports that, ALL ranks then keep the gradient SUM in torch.distributed (whose own communicator is up already),
+        # and a communicator that came up on some ranks while a peer is wedged is ABANDONED, not destroyed -- ncclCommDestroy
+        # could block on the wedged peer; `close()` then leaves the handle to the process exit.
+        import threading
+        limit = float(os.environ.get('VN_COMM_INIT_TIMEOUT_S', '90'))
+        box = {}
+
+        def _join():
+            try:
+                self.comm_init(rank, world, payload)
+                box['ok'] = True
+            except Exception as e:                   # noqa: BLE001
+                box['err'] = str(e)
+        up, why, late = True, '', False
+        if limit > 0:
+            th = threading.Thread(target=_join, daemon=True)
+            th.start()
+            th.join(limit)
+            if th.is_alive():
+                up, late, why = False, True, 'vn_comm_init (ncclCommInitRank) did not return within %g s on rank %d' % (limit, rank)
+        else:
+            _join()
+        if not late and 'err' in box:
+            up, why = False, box['err']
         mark_stage('comm_agree')
-        if all_ok(up):
+        flags = t.tensor([1 if up else 0, 0 if late else 1], dtype=t.int32, device=dev)      # MIN: all up? nobody late?
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        if int(flags[0].item()) == 1:
             return True, ''
+        if int(flags[1].item()) == 0:
+            self._comm_abandoned = True              # a peer (or this rank) is still inside the bootstrap: touch nothing
+            return False, why or 'ncclCommInitRank did not return on another rank: communicator abandoned'
         if up:
             self.comm_destroy()
         return False, why or 'ncclCommInitRank failed on another rank'

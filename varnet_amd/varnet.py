@@ -743,7 +743,7 @@ class VarNet:
         # tower gradient SUM (TFModel.py:342-377): by default an RCCL communicator inside the engine, so a
         # step is gradient -> all-reduce -> optimizer on one stream with one host call; VN_COMM=torch keeps the
         # collective in torch.distributed (three host calls per step)
-        self.comm = 'none'
+        self.comm, self.comm_why = 'none', ''
         if self.world > 1:
             self.comm = 'torch'
             # auto: in-engine RCCL whenever the ranks own distinct GPUs (nccl backend); rccl: required; try: attempted
@@ -754,6 +754,7 @@ class VarNet:
                 # every rank must end up on the SAME route; the bootstrap itself is collective-safe (a rank that cannot
                 # load RCCL makes ALL ranks skip it: VNEngine.comm_init_from_torch), so the decision needs no extra vote
                 ok, why = self.engine.comm_init_from_torch(self.dist)
+                self.comm_why = why                 # why the in-engine communicator was skipped ('' when it is up)
                 if ok:
                     self.comm = 'rccl'
                 else:
