@@ -991,7 +991,13 @@ int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
     LAYCHK(vn_layered_forward(h->layered, h->theta, sl, h->stream, lerr_, sizeof lerr_));
     return VN_OK;
   }
-  if (h->use_fused16 || h->two_pass || h->fused_only) return fused_forward(h, X, nullptr, n, u, nullptr);
+  // networks of the 8-wave family: the value-only sweep of vn_pgrad16 (F_pt per point; the fused kernel's forward-only mode
+  // would carry a tangent stream of zeros through every layer)
+  if (h->use_fused16 || h->two_pass) {
+    HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, nullptr, h->ncu, h->pgrad_wgs, h->stream));
+    return VN_OK;
+  }
+  if (h->fused_only) return fused_forward(h, X, nullptr, n, u, nullptr);
   VnRows s0{}, s1{};
   s0.X = X; s0.G = nullptr; s0.u = u; s0.ud = nullptr; s0.n = n;
   HIPCHK(vn_generic_forward(h->net, h->theta, s0, s1, h->fwd_grid, h->stream));

@@ -2,7 +2,9 @@
 // sweep back to the inputs with seed 1 -- the reference's own tf.gradients(model(Input), Input) (TFModel.py:536-541):
 // 2 F_pt per point whatever the number of coordinates, where one forward-tangent pass per coordinate costs dim * 2 F_pt.
 // Serves the de-duplicated formulation (vn_dedup.hip), which needs (u, du/dx_d) once per unique quadrature point
-// before the weak-form assembly over rows.
+// before the weak-form assembly over rows, vn_forward_grad, and -- without the adjoint sweep (out_g == nullptr) -- vn_forward:
+// the value alone at F_pt per point (the fused kernel's forward-only mode carries a tangent stream of zeros through every
+// layer for such calls: twice the matrix work).
 //
 // Same geometry and data layout as vn_fused16.hip (8 waves, 16 points per wave, v_mfma_f32_16x16x4_f32, feature f in
 // k-step f/4 / lane group f%4, layers chained in registers, weight images [in-feature][out-position] with row stride 65
@@ -234,6 +236,10 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_pgrad16_kern
       }
       u = rowsum4(u2[0] + u2[1]) + bo;
     }
+    if (A.out_g == nullptr) {                        // value only (vn_forward): F_pt per point, no adjoint sweep
+      if (valid && g == 3) A.out_u[row] = u;
+      continue;
+    }
 
     // ---------------------------------------------------------------- value-adjoint sweep to the inputs
 #pragma unroll
@@ -352,7 +358,7 @@ hipError_t launch_one(const VnPgradArgsD& a, int ncu, int wgs_per_cu, hipStream_
 hipError_t vn_pgrad16_launch(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g,
                              int ncu, int wgs_per_cu, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  if (net.dim > 3 || net.d_in > 4 * KS0) return hipErrorInvalidValue;
+  if ((out_g && net.dim > 3) || net.d_in > 4 * KS0) return hipErrorInvalidValue;
   VnPgradArgsD a;
   a.net = net; a.theta = theta; a.X = X; a.n = n; a.out_u = out_u; a.out_g = out_g;
   const int ks = vn_fused16_ks(net);
