@@ -539,6 +539,52 @@ def test_forward_grad_parity(d_in, dim, widths, act, n):
     eng.close()
 
 
+@pytest.mark.parametrize('d_in,dim,widths,act,n,with_src,with_ddx', [
+    (2, 1, [20, 20, 20], 'sigmoid', 1000, True, True),            # <3,5>: edge rows with 4 features; 1D+t
+    (3, 2, [50, 50, 50, 50, 50], 'sigmoid', 4099, True, False),   # <5,13>: the bench network; n not a multiple of 16
+    (3, 2, [50, 50, 50, 50, 50], 'tanh', 777, False, True),
+    (3, 1, [10, 20, 30], 'sigmoid', 515, True, True),             # <3,8>: padding k-steps / row tiles branched over; MOR input
+    (4, 3, [64, 64, 64], 'tanh', 2048, True, True),               # <3,16>: three spatial directions + time
+    (3, 2, [50], 'sigmoid', 130, False, False),                   # one hidden layer
+    (4, 3, [33, 50, 41, 17, 50, 50, 50, 50], 'sigmoid', 300, True, True),    # <8,13>
+    (3, 2, [7, 5], 'tanh', 15, True, True),                       # fewer points than one wave chunk
+])
+def test_taylor_residual_parity(d_in, dim, widths, act, n, with_src, with_ddx, monkeypatch):
+    """vn_residual of the 8-wave family (vn_taylor16.hip: second-order forward mode on the matrix pipe, one pass per coordinate
+    direction) against the fp64 oracle's residual (TFModel.py:743-754 restated) and against the per-point kernel it replaces."""
+    from varnet_amd.engine import VNEngine
+    rng = np.random.default_rng(17)
+    X = rng.uniform(-1.2, 1.2, (n, d_in))
+    diff = rng.uniform(0.1, 1, (n, 1)); vel = rng.standard_normal((n, dim))
+    src = rng.standard_normal((n, 1)) if with_src else None
+    ddx = rng.standard_normal((n, dim)) if with_ddx else None
+    eng = VNEngine(dim, d_in, widths, True, 16, activationFun=act)
+    eng.init_params(seed=5)
+    flat = (eng.get_params() * 2.0).astype(np.float32)            # steeper than glorot: second derivatives that are not tiny
+    eng.set_params(flat)
+    uref, rref = og.residual(flat.astype(np.float64), d_in, widths, torch.float64, X, diff, vel,
+                             np.zeros((n, 1)) if src is None else src, np.zeros((n, dim)) if ddx is None else ddx, dim, True,
+                             activation=act)
+    X32 = X.astype(np.float32)
+    u, r = eng.residual(X32, diff, vel, src, ddx, fp64=False)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(np.max(np.abs(rref))))
+    er = float(np.max(np.abs(r.cpu().numpy() - rref[:, 0]))) / scale
+    eu = float(np.max(np.abs(u.cpu().numpy() - uref[:, 0]))) / max(1.0, float(np.max(np.abs(uref))))
+    monkeypatch.setenv('VN_RESIDUAL_POINTWISE', '1')              # the per-point kernel, same inputs
+    u_p, r_p = eng.residual(X32, diff, vel, src, ddx, fp64=False)
+    torch.cuda.synchronize()
+    monkeypatch.delenv('VN_RESIDUAL_POINTWISE')
+    ep = float(np.max(np.abs(r_p.cpu().numpy() - rref[:, 0]))) / scale
+    ERRORS['taylor_residual %s %s' % (widths, act)] = {'res': er, 'u': eu, 'res_pointwise_kernel': ep}
+    assert er <= 5e-5 and eu <= 2e-6, (er, eu, ep)                # the bar of test_forward_and_residual_parity
+    assert float(np.max(np.abs(r.cpu().numpy() - r_p.cpu().numpy()))) / scale <= 5e-5
+    u2, r2 = eng.residual(X32, diff, vel, src, ddx, fp64=False)
+    torch.cuda.synchronize()
+    assert torch.equal(r, r2) and torch.equal(u, u2)
+    eng.close()
+
+
 def test_inconsistent_dedup_map_is_an_error_not_a_fault():
     """vn_set_dedup validates the map on the device: every later kernel indexes device memory with it."""
     from varnet_amd.engine import VNEngine, VNError

@@ -1,6 +1,7 @@
 // C-ABI host layer of libvarnet_hip.so (see include/varnet_hip.h for the contract and the
 // reference call sites each entry point replaces).
 #include "vn_internal.h"
+#include "vn_taylor16.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen'ed by vn_comm_*, never linked
@@ -1035,6 +1036,12 @@ int vn_residual(vn_engine* h, const float* X, const float* diff, const float* ve
   if (h->layered) {
     LAYCHK(vn_layered_residual_f32(h->layered, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->stream,
                                    lerr_, sizeof lerr_));
+    return VN_OK;
+  }
+  // networks of the 8-wave family: second-order forward mode on the matrix pipe (vn_taylor16.hip); the per-point kernel keeps
+  // the generic / 4-wave requests (and is what the new kernel is cross-checked against)
+  if ((h->use_fused16 || h->two_pass) && !getenv("VN_RESIDUAL_POINTWISE")) {
+    HIPCHK(vn_taylor16_residual(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->ncu, h->stream));
     return VN_OK;
   }
   HIPCHK(vn_pointwise_residual_f32(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res,

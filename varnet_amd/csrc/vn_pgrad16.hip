@@ -12,23 +12,12 @@
 // direction instead of two, no weight gradient, hence no transposition images, no workgroup barrier after the prologue:
 // every wave walks its own 16-point chunks.  The activations of all layers stay in registers between the two sweeps
 // (KS * L values per lane: 65 at 5x50).
-#include "vn_fused16_common.h"
+#include "vn_points16.h"
 
 #include <atomic>
 
 namespace {
 using namespace vn16;
-
-template <int L, int KS>
-struct PLay {
-  static constexpr int HP = 4 * KS;
-  static constexpr int HPWS = al4(HP * WS);
-  static constexpr int W1_OFF = 0;                          // [8][WS]
-  static constexpr int WH_OFF = al4(8 * WS);                // [L-1][HP][WS]
-  static constexpr int BI_OFF = WH_OFF + (L - 1) * HPWS;    // [L][64] biases in (tile, g, i) order
-  static constexpr int WO_OFF = BI_OFF + L * 64;            // [4*KS]
-  static constexpr int TOTAL = WO_OFF + al4(4 * KS);
-};
 
 struct VnPgradArgsD {
   VnNet net;
@@ -71,57 +60,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_pgrad16_kern
   float* BI = lds + LY::BI_OFF;
   float* WO = lds + LY::WO_OFF;
   const float bo = A.theta[net.boff[L + 1]];
-  // ------------------------------------------------------------------ prologue: weight images (as in vn_fused16.hip:
-  // parameters read in their own row-major order, every load issued before anything waits, scattered into the images)
-  {
-    const int d_in = net.d_in, H1 = net.H[1];
-    constexpr int NSRC = (LY::HP * LY::HP + NTHREADS - 1) / NTHREADS;
-    static_assert(8 * 64 <= NTHREADS, "layer 1: one parameter per thread");
-    float v1 = 0.f, vh[L > 1 ? L - 1 : 1][NSRC];
-    if (tid < d_in * H1) v1 = A.theta[net.woff[1] + tid];
-#pragma unroll
-    for (int l = 2; l <= L; ++l) {
-      const int n = net.H[l - 1] * net.H[l];
-      const float* src = A.theta + net.woff[l];
-#pragma unroll
-      for (int it = 0; it < NSRC; ++it) {
-        const int j = tid + it * NTHREADS;
-        vh[l - 2][it] = j < n ? src[j] : 0.f;
-      }
-    }
-    static_assert(L * 64 <= NTHREADS && 4 * KS <= NTHREADS, "one bias / output weight per thread");
-    float vb = 0.f, vo = 0.f;
-    if (tid < L * 64) {
-      const int l = tid / 64 + 1, idx = tid % 64;
-      const int mt = idx >> 4, g = (idx >> 2) & 3, r = idx & 3;       // [tile][g][i]
-      const int ks = 4 * mt + r, f = 4 * ks + g;
-      vb = (ks < KS && f < net.H[l]) ? A.theta[net.boff[l] + f] : 0.f;
-    }
-    if (tid < 4 * KS) vo = (tid < net.H[L]) ? A.theta[net.woff[L + 1] + tid] : 0.f;
-    static_assert(LY::BI_OFF % 4 == 0, "16-byte zero fill");
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < LY::BI_OFF / 4; i += NTHREADS) reinterpret_cast<f32x4a*>(lds)[i] = z4;                    // W1 | WH
-    __syncthreads();
-    if (tid < d_in * H1) {
-      const int k = tid / H1, f = tid - k * H1;
-      W1[k * WS + vpos(f >> 2, f & 3)] = v1;
-    }
-#pragma unroll
-    for (int l = 2; l <= L; ++l) {
-      float* Wl = WH + (l - 2) * LY::HPWS;
-      const int Hout = net.H[l], n = net.H[l - 1] * Hout;
-      const int dq = NTHREADS / Hout, dr = NTHREADS - dq * Hout;      // j -> j + NTHREADS: k += dq, f += dr (one carry)
-      int k = tid / Hout, f = tid - k * Hout;
-#pragma unroll
-      for (int it = 0; it < NSRC; ++it) {
-        if (tid + it * NTHREADS < n) Wl[k * WS + vpos(f >> 2, f & 3)] = vh[l - 2][it];
-        f += dr; k += dq;
-        if (f >= Hout) { f -= Hout; ++k; }
-      }
-    }
-    if (tid < L * 64) BI[tid] = vb;
-    if (tid < 4 * KS) WO[tid] = vo;
-  }
+  stage_weight_images<L, KS>(net, A.theta, lds, tid);      // vn_points16.h
   __syncthreads();
 
   const int g = lane >> 4, c = lane & 15;
