@@ -37,8 +37,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), de
 # header that unit includes, and the compile flags of the Makefile (-fno-slp-vectorize and friends decide the code too)
 _F16 = ('varnet_amd/csrc/vn_fused16.hip', 'varnet_amd/csrc/vn_fused16_common.h', 'varnet_amd/csrc/vn_internal.h', 'include/varnet_hip.h')
 KERNEL_SOURCES = {'vn_fused16_kernel': _F16,
-                  'vn_pgrad16_kernel': ('varnet_amd/csrc/vn_pgrad16.hip', 'varnet_amd/csrc/vn_points16.h') + _F16[1:],
-                  'vn_dedup_': ('varnet_amd/csrc/vn_dedup.hip',) + _F16[2:]}
+                  'vn_pgrad16_kernel': ('varnet_amd/csrc/vn_pgrad16.hip', 'varnet_amd/csrc/vn_pgrad16.h', 'varnet_amd/csrc/vn_points16.h') + _F16[1:],
+                  'vn_dedup_': ('varnet_amd/csrc/vn_dedup.hip', 'varnet_amd/csrc/vn_dedup.h') + _F16[2:]}
 # counter files bench.py may quote `roofline.traffic` from, by --config (tools/collect_profiles.sh + tools/summarise_profiles.py)
 TRAFFIC_FILES = {3: 'pmc_traffic.json', 2: 'pmc_traffic_cfg2.json'}
 DEDUP_TRAFFIC_FILE = 'pmc_traffic_dedup.json'

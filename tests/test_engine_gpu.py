@@ -585,6 +585,61 @@ def test_taylor_residual_parity(d_in, dim, widths, act, n, with_src, with_ddx, m
     eng.close()
 
 
+@pytest.mark.parametrize('q,dim,d_in,widths,integW', [(64, 2, 3, [50, 50, 50], False), (16, 1, 2, [20, 20], False), (36, 1, 2, [10, 20, 30], True)])
+def test_dedup_periodic_gcoef_table_is_bitwise_the_csr_path(q, dim, d_in, widths, integW, monkeypatch):
+    """With constant coefficients gcoef repeats with period integNum along the rows (VarNet.py:837 tiles the tables): vn_set_dedup
+    detects that bitwise and the two assembly kernels read the integNum-entry table instead of 8 bytes per row each.  Same bits
+    as the general path (VN_DEDUP_NO_TABLE=1: CSR-ordered copy of gcoef); one perturbed row switches the detection off."""
+    from varnet_amd.engine import VNEngine
+    rng = np.random.default_rng(8)
+    n_k, U, nB, bDof = 70, 900, 20, 9
+    n = n_k * q
+    Xu = rng.uniform(-1, 1, (U, d_in)).astype(np.float32)
+    uid = rng.integers(0, U, n).astype(np.int32)
+    uid[:U] = np.arange(U)
+    rng.shuffle(uid)
+    table = rng.standard_normal((q, dim)).astype(np.float32)
+    gcoef = np.tile(table, (n_k, 1))
+    N1 = rng.uniform(0, 1, q).astype(np.float32); dNt1 = rng.standard_normal(q).astype(np.float32)
+    W = rng.uniform(0.5, 1, (1, q)).astype(np.float32) if integW else None
+    eng = VNEngine(dim, d_in, widths, True, q, integWflag=integW)
+    eng.init_params(seed=2)
+    eng.set_fe_table(N1, dNt1, W)
+    eng.set_bic(rng.uniform(-1, 1, (nB, d_in)).astype(np.float32), rng.standard_normal((nB, 1)).astype(np.float32), bDof, 2.0)
+    eng.set_weights([3.0, 2.0, 5.0])
+    gb = eng.bind_grad_buffer()
+    rowptr, rowidx = _csr(uid, U)
+
+    def grad_with(g, no_table):
+        eng.set_interior(0, Xu[uid], g, None, n_k=n_k, detJ=0.05)
+        if no_table:
+            monkeypatch.setenv('VN_DEDUP_NO_TABLE', '1')
+        eng.set_dedup(0, Xu, uid, rowptr, rowidx)
+        if no_table:
+            monkeypatch.delenv('VN_DEDUP_NO_TABLE')
+        eng.grad(0)
+        torch.cuda.synchronize()
+        return gb.cpu().numpy().copy()
+    g_tab, g_csr = grad_with(gcoef, False), grad_with(gcoef, True)
+    assert np.array_equal(g_tab, g_csr)
+    eng.set_dedup(0)
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g_rows = gb.cpu().numpy().copy()
+    assert np.max(np.abs(g_tab[:eng.P] - g_rows[:eng.P])) <= 1e-4 * np.max(np.abs(g_rows[:eng.P]))
+    # one row off the period: the table must not be used (the general path then agrees with the row-wise launch on THAT data)
+    g2 = gcoef.copy()
+    g2[5 * q + 3, 0] += 0.75
+    a = grad_with(g2, False)
+    eng.set_dedup(0)
+    eng.grad(0)
+    torch.cuda.synchronize()
+    b = gb.cpu().numpy().copy()
+    assert np.max(np.abs(a[:eng.P] - b[:eng.P])) <= 1e-4 * np.max(np.abs(b[:eng.P]))
+    assert not np.array_equal(a, g_tab)
+    eng.close()
+
+
 def test_inconsistent_dedup_map_is_an_error_not_a_fault():
     """vn_set_dedup validates the map on the device: every later kernel indexes device memory with it."""
     from varnet_amd.engine import VNEngine, VNError

@@ -1,6 +1,8 @@
 // C-ABI host layer of libvarnet_hip.so (see include/varnet_hip.h for the contract and the
 // reference call sites each entry point replaces).
 #include "vn_internal.h"
+#include "vn_dedup.h"
+#include "vn_pgrad16.h"
 #include "vn_taylor16.h"
 
 #include <dlfcn.h>
@@ -66,6 +68,7 @@ struct Batch {
   long U = 0;
   float* gcsr = nullptr;      // owned: gcoef in CSR order, [n_k*integ_num, dim] (static per batch; built by vn_set_dedup)
   long gcsr_cap = 0;
+  bool gper = false;          // gcoef repeats with period integ_num along the rows (constant coefficients): no CSR copy needed
 };
 
 constexpr int PROF_CAP = 4096;
@@ -351,14 +354,14 @@ int run_dedup(vn_engine* h, const Batch& b, float* gradbuf) {
     if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
     HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
   }
-  HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, h->dd_uv, h->dd_ug, grid, h->pgrad_wgs, h->stream));
+  HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, grid, h->pgrad_wgs, h->stream));
   VnDedupArgs a{};
-  a.uv = h->dd_uv; a.ug = h->dd_ug; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
+  a.upack = h->dd_uv; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
   a.gcoef = b.gcoef; a.gcoef_csr = b.gcsr; a.source = h->cfg.has_source ? b.source : nullptr;
   a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
   a.detJv = b.detJv; a.detJ = (float)b.detJ; a.n_k = b.n_k; a.U = b.U; a.q = q; a.dim = dim;
-  a.time_dependent = h->cfg.time_dependent; a.w2 = (float)h->w[2];
-  a.srow = h->u; a.lossVec = nullptr; a.part = lp + (long)grid * 3;
+  a.time_dependent = h->cfg.time_dependent; a.w2 = (float)h->w[2]; a.gper = b.gper ? 1 : 0;
+  a.stf = h->u; a.lossVec = nullptr; a.part = lp + (long)grid * 3;
   a.seed_u = h->dd_su; a.seed_g = h->dd_sg;
   HIPCHK(vn_dedup_seed_launch(a, sblk, h->stream));
   HIPCHK(vn_dedup_gather_launch(a, h->stream));
@@ -751,9 +754,9 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
   HIPCHK(hipSetDevice(h->cfg.device));
   const int dim = h->cfg.dim;
   if (U > h->dd_capU) {
-    float** bufs[] = {&h->dd_uv, &h->dd_ug, &h->dd_su, &h->dd_sg};
-    const long sizes[] = {U, U * dim, U, U * dim};
-    for (int i = 0; i < 4; ++i) {
+    float** bufs[] = {&h->dd_uv, &h->dd_su, &h->dd_sg};          // dd_uv: [U, 4] packed (u, grad u) records
+    const long sizes[] = {4 * U, U, U * dim};
+    for (int i = 0; i < 3; ++i) {
       if (*bufs[i]) (void)hipFree(*bufs[i]);
       *bufs[i] = nullptr;
       HIPCHK(hipMalloc((void**)bufs[i], (size_t)sizes[i] * sizeof(float)));
@@ -784,16 +787,33 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     if (bad) return fail(VN_EINVAL, "inconsistent de-duplication map: %d violation(s) (need 0 <= uid < U, rowptr[0] = 0 <= ... <= rowptr[U] = n_k*integ_num, "
                                     "0 <= rowidx < n_k*integ_num and uid[rowidx[e]] = the point whose segment holds e)", bad);
   }
-  // gcoef in CSR order (the gather kernel then reads it, like rowidx, as one contiguous stream: the per-row gather of 8-byte
-  // entries fetched 2.6 x the bytes it used, profiles/r5_pmc_traffic_dedup.json).  gcoef is static per batch: permuted once here.
+  // With constant coefficients gcoef = kappa dN/dx + v N repeats with period integ_num along the rows (the reference tiles the
+  // tables to nT rows, VarNet.py:837): detected here, bitwise, and both assembly kernels then read the rows of test function 0
+  // as an integ_num-entry table instead of 8 bytes per row each.  Otherwise the gather kernel gets gcoef in CSR order (it then
+  // reads it, like rowidx, as one contiguous stream: a per-row gather of 8-byte entries fetched 2.6 x the bytes it used,
+  // profiles/r5_pmc_traffic_dedup.json).  gcoef is static per batch: examined / permuted once, here.
   const long nT = b.n_k * h->cfg.integ_num;
-  if (nT * dim > b.gcsr_cap) {
-    if (b.gcsr) (void)hipFree(b.gcsr);
-    b.gcsr = nullptr; b.gcsr_cap = 0;
-    HIPCHK(hipMalloc((void**)&b.gcsr, (size_t)nT * dim * sizeof(float)));
-    b.gcsr_cap = nT * dim;
+  {
+    int* err_dev = nullptr;
+    HIPCHK(hipMalloc((void**)&err_dev, sizeof(int)));
+    hipError_t e = hipMemsetAsync(err_dev, 0, sizeof(int), h->stream);
+    if (e == hipSuccess) e = vn_dedup_periodic_launch(b.gcoef, nT, h->cfg.integ_num, dim, err_dev, h->stream);
+    int bad = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, err_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(err_dev);
+    if (e != hipSuccess) return fail(VN_EHIP, "vn_set_dedup: %s", hipGetErrorString(e));
+    b.gper = bad == 0 && !getenv("VN_DEDUP_NO_TABLE");
   }
-  HIPCHK(vn_dedup_permute_launch(b.gcoef, rowidx, b.gcsr, nT, dim, h->stream));
+  if (!b.gper) {
+    if (nT * dim > b.gcsr_cap) {
+      if (b.gcsr) (void)hipFree(b.gcsr);
+      b.gcsr = nullptr; b.gcsr_cap = 0;
+      HIPCHK(hipMalloc((void**)&b.gcsr, (size_t)nT * dim * sizeof(float)));
+      b.gcsr_cap = nT * dim;
+    }
+    HIPCHK(vn_dedup_permute_launch(b.gcoef, rowidx, b.gcsr, nT, dim, h->stream));
+  }
   b.Xu = Xu; b.U = U; b.uid = uid; b.rowptr = rowptr; b.rowidx = rowidx;
   return VN_OK;
 }
@@ -995,7 +1015,7 @@ int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
   // networks of the 8-wave family: the value-only sweep of vn_pgrad16 (F_pt per point; the fused kernel's forward-only mode
   // would carry a tangent stream of zeros through every layer)
   if (h->use_fused16 || h->two_pass) {
-    HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, nullptr, h->ncu, h->pgrad_wgs, h->stream));
+    HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, nullptr, nullptr, h->ncu, h->pgrad_wgs, h->stream));
     return VN_OK;
   }
   if (h->fused_only) return fused_forward(h, X, nullptr, n, u, nullptr);
@@ -1011,7 +1031,7 @@ int vn_forward_grad(vn_engine* h, const float* X, int64_t n, float* u, float* g)
   if (!h->use_fused16 && !h->two_pass) return fail(VN_EUNSUPPORTED, "vn_forward_grad needs a network of the 8-wave fused kernel");
   if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "vn_forward_grad supports dim <= 3");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, g, h->ncu, h->pgrad_wgs, h->stream));
+  HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, g, nullptr, h->ncu, h->pgrad_wgs, h->stream));
   return VN_OK;
 }
 

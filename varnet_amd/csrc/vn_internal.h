@@ -107,37 +107,12 @@ size_t vn_fused16_lds_bytes(const VnNet& net);
 int vn_fused16_ks(const VnNet& net);               // k-steps per hidden layer of the instantiation that serves `net` (0: none)
 hipError_t vn_fused16_launch(const VnFusedArgs& a, int grid, hipStream_t s);
 
-// ---- value + input gradient at points in one pass (vn_pgrad16.hip): value forward + value-adjoint sweep to the inputs,
-// 2 F_pt per point (TFModel.py:536-541); every network vn_fused16_net_supported accepts, dim <= 3.
-// out_u[n], out_g[n, net.dim]; ncu = CUs of the device; wgs_per_cu = 0: as many resident workgroups per CU as fit, at most 2.
-hipError_t vn_pgrad16_launch(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g,
-                             int ncu, int wgs_per_cu, hipStream_t s);
-
 // ---- measurement aid (vn_calib.hip): sustained fp32 MFMA rate and fp32 vector issue cost of this GPU; out[5], see there
 hipError_t vn_calibrate(int ncu, hipStream_t s, double out[5]);
 
-// ---- de-duplicated weak-form assembly (vn_dedup.hip) -----------------------------------------
-struct VnDedupArgs {
-  const float* uv; const float* ug;          // [U], [U, dim]: model value / input gradient at unique points
-  const int* uid;                            // [nT] row -> unique point
-  const int* rowptr; const int* rowidx;      // CSR unique point -> rows
-  const float* gcoef; const float* source;   // [nT, dim], [nT] or nullptr
-  const float* gcoef_csr;                    // [nT, dim]: gcoef[rowidx[e]] (what the gather kernel reads, contiguously)
-  const float* feN; const float* fedNt; const float* feW;
-  const float* detJv; float detJ;
-  long n_k, U; int q, dim, time_dependent;
-  float w2;
-  float* srow;                               // [nT] per-row seed (nullptr: loss only)
-  float* lossVec;                            // [n_k] or nullptr
-  float* part;                               // [grid*3] block partials (var, 0, 0)
-  float* seed_u; float* seed_g;              // [U], [U, dim] gathered seeds
-};
-constexpr int VN_DEDUP_TFB = 32;            // test functions per workgroup of the seed kernel = per loss partial (grid = ceil(n_k / 32))
-hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s);
-hipError_t vn_dedup_gather_launch(const VnDedupArgs& a, hipStream_t s);
-// *err_dev += number of inconsistencies of the map (see vn_dedup_check_kernel); err_dev must hold 0 on entry
-hipError_t vn_dedup_check_launch(const int* uid, const int* rowptr, const int* rowidx, long nT, long U, int* err_dev, hipStream_t s);
-hipError_t vn_dedup_permute_launch(const float* gcoef, const int* rowidx, float* gcoef_csr, long nT, int dim, hipStream_t s);
+// (value + input gradient at points: vn_pgrad16.h; de-duplicated weak-form assembly: vn_dedup.h; strong residual on the matrix
+// pipe: vn_taylor16.h -- kept out of this header,
+// which every kernel's source hash covers)
 
 // ---- simple per-point evaluation kernels (float / double): vn_pointwise.hip --------------
 hipError_t vn_pointwise_forward_f32(const VnNet& net, const float* theta, const float* X, long n,

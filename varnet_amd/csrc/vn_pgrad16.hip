@@ -13,6 +13,7 @@
 // every wave walks its own 16-point chunks.  The activations of all layers stay in registers between the two sweeps
 // (KS * L values per lane: 65 at 5x50).
 #include "vn_points16.h"
+#include "vn_pgrad16.h"
 
 #include <atomic>
 
@@ -26,6 +27,7 @@ struct VnPgradArgsD {
   long n;
   float* out_u;              // [n]
   float* out_g;              // [n, dim]: du/dx_d, d < dim (the leading coordinates of X)
+  float* out_pack;           // [n, 4] = (u, du/dx_0, du/dx_1, du/dx_2) or nullptr
 };
 
 template <int L, int KS, bool TANH>
@@ -175,8 +177,8 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_pgrad16_kern
       }
       u = rowsum4(u2[0] + u2[1]) + bo;
     }
-    if (A.out_g == nullptr) {                        // value only (vn_forward): F_pt per point, no adjoint sweep
-      if (valid && g == 3) A.out_u[row] = u;
+    if (A.out_g == nullptr && A.out_pack == nullptr) {   // value only (vn_forward): F_pt per point, no adjoint sweep
+      if (valid && g == 3 && A.out_u) A.out_u[row] = u;
       continue;
     }
 
@@ -246,8 +248,10 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_pgrad16_kern
       }
     }
     if (valid) {
-      if (g == 3) A.out_u[row] = u;
-      else if (g < net.dim) A.out_g[row * net.dim + g] = (g == 0) ? xg[0] : (g == 1) ? xg[1] : xg[2];
+      const float mine = (g == 3) ? u : (g == 0) ? xg[0] : (g == 1) ? xg[1] : xg[2];       // xg of an absent coordinate is 0
+      if (A.out_pack) A.out_pack[row * 4 + ((g + 1) & 3)] = mine;                          // (u, g0, g1, g2): lane group 3 holds u
+      if (g == 3) { if (A.out_u) A.out_u[row] = u; }
+      else if (g < net.dim && A.out_g) A.out_g[row * net.dim + g] = mine;
     }
   }
 }
@@ -295,11 +299,11 @@ hipError_t launch_one(const VnPgradArgsD& a, int ncu, int wgs_per_cu, hipStream_
   X(1, 16) X(2, 16) X(3, 16) X(4, 16) X(5, 16) X(6, 16)
 
 hipError_t vn_pgrad16_launch(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g,
-                             int ncu, int wgs_per_cu, hipStream_t s) {
+                             float* out_pack, int ncu, int wgs_per_cu, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  if ((out_g && net.dim > 3) || net.d_in > 4 * KS0) return hipErrorInvalidValue;
+  if (((out_g || out_pack) && net.dim > 3) || net.d_in > 4 * KS0) return hipErrorInvalidValue;
   VnPgradArgsD a;
-  a.net = net; a.theta = theta; a.X = X; a.n = n; a.out_u = out_u; a.out_g = out_g;
+  a.net = net; a.theta = theta; a.X = X; a.n = n; a.out_u = out_u; a.out_g = out_g; a.out_pack = out_pack;
   const int ks = vn_fused16_ks(net);
 #define X(LL, KK)                                                                              \
   if (net.L == LL && ks == KK)                                                                  \
