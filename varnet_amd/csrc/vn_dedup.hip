@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256) void vn_dedup_gather_kernel(VnDedupArgs a) {
   __shared__ float sp[VN_GATHER_CH][4];     // (-dNt s, g0 s, g1 s, g2 s) per entry
   __shared__ int sptr[VN_GATHER_PB + 1];
   const int tid = threadIdx.x, dim = a.dim, q = a.q;
+  const bool qpow2 = (q & (q - 1)) == 0;
+  const int qshift = __ffs(q) - 1;
   const long j0 = (long)blockIdx.x * VN_GATHER_PB;
   const int nj = (int)((a.U - j0 < VN_GATHER_PB) ? a.U - j0 : VN_GATHER_PB);
   for (int i = tid; i <= nj; i += 256) sptr[i] = a.rowptr[j0 + i];
@@ -148,8 +150,11 @@ __global__ __launch_bounds__(256) void vn_dedup_gather_kernel(VnDedupArgs a) {
       int pp[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int k = r[c] >= 0 ? r[c] / q : 0;
-        pp[c] = r[c] >= 0 ? r[c] - k * q : 0;
+        // row -> (test function, quadrature point): a shift when integ_num is a power of two (16, 64: two-point Gauss), else one
+        // unsigned division (a signed one by a run-time divisor is ~30 vector instructions per entry)
+        const unsigned ru = r[c] >= 0 ? (unsigned)r[c] : 0u;
+        const int k = (int)(qpow2 ? ru >> qshift : ru / (unsigned)q);
+        pp[c] = (int)(ru - (unsigned)k * (unsigned)q);
         sv[c] = r[c] >= 0 ? a.stf[k] : 0.f;
         const float* gp = a.gper ? a.gcoef + (long)pp[c] * dim : a.gcoef_csr + ((long)base + i0 + 256 * c) * dim;
 #pragma unroll
