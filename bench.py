@@ -445,6 +445,40 @@ def cpu_full_size(vn, tdata, kw_sample, theta0, cores, budget_s=45.0):
                       % (nt, rows, T, blk, T, len(times) - 1, cores)}
 
 
+def inference_line(vn, tdata, eng, F_pt):
+    """The callers either side of the training step, on the headline's own points: `vn_forward` (VarNet.evaluate: value-only sweep of
+    vn_pgrad16, F_pt per point) on all training rows and `vn_residual` (strong residual incl. the Laplacian: every monitor of the training
+    loop and the residual-driven re-sampling; second-order forward mode on the matrix pipe, vn_taylor16, (3 dim + 2) F_pt per point) on
+    the first 10^6 of them.  HIP-side time only (inputs resident); reported under `extra`, never `value`."""
+    import torch
+    from varnet_amd.engine import _ptr
+    d = tdata.mor[0]
+    X = d['Input']
+    n = int(X.shape[0])
+    m = min(n, 1000000)
+    dim = vn.dim
+    g = torch.Generator(device='cuda'); g.manual_seed(0)
+    diff = torch.full((m,), 1e-3, device='cuda'); vel = torch.randn(m, dim, device='cuda', generator=g)
+    u = torch.empty(n, device='cuda'); r = torch.empty(m, device='cuda')
+
+    def t(fn, reps=5):
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    tf = t(lambda: eng._ck(eng.lib.vn_forward(eng.h, _ptr(X), n, _ptr(u))))
+    tr = t(lambda: eng._ck(eng.lib.vn_residual(eng.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, m, _ptr(u), _ptr(r))))
+    nd = 3 * dim + 2
+    return {"forward": {"points": n, "ms": tf * 1e3, "points_per_s": n / tf, "tflops_of_F_pt": F_pt * n / tf / 1e12,
+                        "frac_of_peak": F_pt * n / tf / 1e12 / PEAK_FP32_MFMA_TFLOPS, "kernel": "vn_pgrad16_kernel (value-only sweep)"},
+            "residual": {"points": m, "ms": tr * 1e3, "points_per_s": m / tr, "tflops_executed": nd * F_pt * m / tr / 1e12,
+                         "frac_of_peak": nd * F_pt * m / tr / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "kernel": "vn_taylor16_kernel: (3 dim + 2) F_pt per point, one pass of three chained streams per coordinate direction"},
+            "note": "vn_forward = VarNet.evaluate; vn_residual = TFModel.py:743-754, what every training monitor (VarNet.py:1363) and the "
+                    "residual-driven re-sampling (VarNet.py:1696-1868) call; profiles/r5_forward_perf.txt, r5_residual_perf.txt"}
+
+
 def small_step_line(cfg, steps, warmup, cal=None, with_dedup=False):
     """One more workload in the same process, reported under `extra`: BASELINE config 2 (1D+t, 4x50, 160 k points), a step
     of ~0.16 ms where per-step fixed cost, not the tile loop, decides.  Same timing rules as the headline (inputs resident,
@@ -749,16 +783,19 @@ def _main():
                 out["rehearsal"] = "ranks share %d GPU(s) over %s: a plumbing check, not a scaling number" % (ndev, backend)
         if dd is not None:
             out["dedup"] = dd
+        inference = None
+        if world == 1 and not args.no_extra:
+            inference = inference_line(vn, tdata, eng, F_pt)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(vn, tdata)
         if world == 1 and args.config == 3 and not args.no_extra:
             eng.close()
-            out["extra"] = {"sustained": sustained,
+            out["extra"] = {"sustained": sustained, "inference": inference,
                             "config2_small_step": small_step_line(2, 400, 40, cal, with_dedup=not args.no_dedup),
                             "config1_small_step": small_step_line(1, 1000, 100, cal),
                             "config5_mor_epoch": mor_epoch_line(5, 2, cal)}
         elif sustained is not None:
-            out["extra"] = {"sustained": sustained}
+            out["extra"] = {"sustained": sustained, "inference": inference}
         print(json.dumps(out), flush=True)
     if world > 1:
         mark_stage('teardown')
