@@ -1,0 +1,72 @@
+"""Randomised parity of the two point kernels of round 5 over their instantiations (8-wave family: 1-8 hidden layers up to 50 wide,
+1-6 up to 64 wide, sigmoid / tanh, ragged widths): `vn_forward_grad` / `vn_forward` (vn_pgrad16.hip) and `vn_residual`
+(vn_taylor16.hip, second-order forward mode on the matrix pipe) against the fp64 oracle (TFModel.py:536-545, 743-754 restated),
+and the residual against the per-point kernel it replaced.  Bars: u 2e-6, grad u 2e-5, residual 1e-4 of their own scales
+(the engine tests' bars are 2e-6 / 1e-5 / 5e-5 on hand-picked nets; random steep nets get a factor 2)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import tf1_graph as og  # noqa: E402
+
+
+def _draw(rng):
+    wide = rng.random() < 0.3
+    L = int(rng.integers(1, 7 if wide else 9))
+    hi = 65 if wide else 51
+    if rng.random() < 0.4:
+        widths = [int(rng.choice([5, 10, 20, 21, 32, 33, 48, 49, 50] + ([51, 60, 63, 64] if wide else [])))] * L
+    else:
+        widths = [int(rng.integers(1, hi)) for _ in range(L)]
+    dim = int(rng.integers(1, 4))
+    d_in = dim + 1 + int(rng.integers(0, 2))
+    act = 'tanh' if rng.random() < 0.35 else 'sigmoid'
+    n = int(rng.choice([1, 15, 16, 17, 127, 128, 1000, 4099]))
+    return L, widths, dim, d_in, act, n
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_point_kernels_against_the_oracle(seed, monkeypatch):
+    from varnet_amd.engine import VNEngine
+    rng = np.random.default_rng(100 + seed)
+    worst = {'u': 0.0, 'grad': 0.0, 'res': 0.0, 'res_vs_pointwise': 0.0}
+    for case in range(12):
+        L, widths, dim, d_in, act, n = _draw(rng)
+        eng = VNEngine(dim, d_in, widths, True, 16, activationFun=act)
+        if not eng.dedup_supported():                 # not a network of the 8-wave family
+            eng.close()
+            continue
+        eng.init_params(seed=case)
+        flat = (eng.get_params() * float(rng.uniform(1.0, 2.5))).astype(np.float32)
+        eng.set_params(flat)
+        X = rng.uniform(-1.2, 1.2, (n, d_in))
+        diff = rng.uniform(0.05, 1, (n, 1)); vel = rng.standard_normal((n, dim))
+        src = rng.standard_normal((n, 1)); ddx = rng.standard_normal((n, dim))
+        f64 = flat.astype(np.float64)
+        uref, rref = og.residual(f64, d_in, widths, torch.float64, X, diff, vel, src, ddx, dim, True, activation=act)
+        params = og.unflatten(f64, d_in, widths, torch.float64)
+        Xt = torch.tensor(X, requires_grad=True)
+        _, gref, _, _ = og.model_grad(params, Xt, dim, activation=act)
+        gref = gref.detach().numpy()
+        X32 = X.astype(np.float32)
+        u, g = eng.forward_grad(X32)
+        uf = eng.forward(X32)
+        _, r = eng.residual(X32, diff, vel, src, ddx, fp64=False)
+        monkeypatch.setenv('VN_RESIDUAL_POINTWISE', '1')
+        _, rp = eng.residual(X32, diff, vel, src, ddx, fp64=False)
+        monkeypatch.delenv('VN_RESIDUAL_POINTWISE')
+        torch.cuda.synchronize()
+        su, sg, sr = max(1.0, np.abs(uref).max()), max(1e-30, np.abs(gref).max()), max(1.0, np.abs(rref).max())
+        e = {'u': max(np.abs(u.cpu().numpy() - uref[:, 0]).max(), np.abs(uf.cpu().numpy() - uref[:, 0]).max()) / su,
+             'grad': np.abs(g.cpu().numpy() - gref).max() / sg,
+             'res': np.abs(r.cpu().numpy() - rref[:, 0]).max() / sr,
+             'res_vs_pointwise': np.abs(r.cpu().numpy() - rp.cpu().numpy()).max() / sr}
+        msg = 'seed %d case %d %s L=%d widths=%s d_in=%d dim=%d n=%d: %s' % (seed, case, act, L, widths, d_in, dim, n, e)
+        print(msg)
+        assert e['u'] <= 2e-6 and e['grad'] <= 2e-5 and e['res'] <= 1e-4 and e['res_vs_pointwise'] <= 1e-4, msg
+        for k in worst:
+            worst[k] = max(worst[k], float(e[k]))
+        eng.close()
+    print('worst over the cases of seed %d: %s' % (seed, worst))
