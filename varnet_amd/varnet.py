@@ -763,6 +763,8 @@ class VarNet:
                                            + (': ' + why if why else ''))
                     warnings.warn('in-engine RCCL communicator unavailable (%s): gradient SUM stays in torch.distributed'
                                   % (why or 'another rank failed'))
+            else:
+                self.comm_why = 'not attempted: VN_COMM=%s on the %s backend' % (mode, self.dist.get_backend())
         fd = self.fixData
         self.engine.set_fe_table(fd.N, fd.dNt, None if fd.integW is None else fd.integW)
         self.tfData = self.engine       # name kept for scripts that poke at `VarNet.tfData`
