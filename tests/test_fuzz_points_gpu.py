@@ -57,8 +57,14 @@ def test_point_kernels_against_the_oracle(seed, monkeypatch):
         monkeypatch.setenv('VN_RESIDUAL_POINTWISE', '1')
         _, rp = eng.residual(X32, diff, vel, src, ddx, fp64=False)
         monkeypatch.delenv('VN_RESIDUAL_POINTWISE')
+        # fp64 entry points (the fp64 matrix pipe, vn_taylor16d.hip, where the double-precision images fit the LDS; else per thread)
+        u64 = eng.forward_f64(X)
+        u64r, r64 = eng.residual(X, diff, vel, src, ddx, fp64=True)
         torch.cuda.synchronize()
         su, sg, sr = max(1.0, np.abs(uref).max()), max(1e-30, np.abs(gref).max()), max(1.0, np.abs(rref).max())
+        e64 = (max(np.abs(u64.cpu().numpy() - uref[:, 0]).max(), np.abs(u64r.cpu().numpy() - uref[:, 0]).max()) / su,
+               np.abs(r64.cpu().numpy() - rref[:, 0]).max() / sr)
+        assert e64[0] <= 1e-13 and e64[1] <= 1e-11, ('fp64', widths, act, e64)          # config 5's bar is 1e-10
         e = {'u': max(np.abs(u.cpu().numpy() - uref[:, 0]).max(), np.abs(uf.cpu().numpy() - uref[:, 0]).max()) / su,
              'grad': np.abs(g.cpu().numpy() - gref).max() / sg,
              'res': np.abs(r.cpu().numpy() - rref[:, 0]).max() / sr,

@@ -1044,6 +1044,11 @@ int vn_forward_f64(vn_engine* h, const double* X, int64_t n, double* u) {
     LAYCHK(vn_layered_forward_f64(h->layered, h->theta64, X, n, u, h->stream, lerr_, sizeof lerr_));
     return VN_OK;
   }
+  // networks of the 8-wave family whose fp64 images fit the LDS: the fp64 matrix pipe (vn_taylor16d.hip); else per thread
+  if ((h->use_fused16 || h->two_pass) && vn_taylor16d_supported(h->net) && !getenv("VN_RESIDUAL_POINTWISE")) {
+    HIPCHK(vn_taylor16d_launch(h->net, h->theta64, X, nullptr, nullptr, nullptr, nullptr, h->cfg.time_dependent, n, u, nullptr, h->ncu, h->stream));
+    return VN_OK;
+  }
   HIPCHK(vn_pointwise_forward_f64(h->net, h->theta64, X, n, u, h->stream));
   return VN_OK;
 }
@@ -1078,6 +1083,10 @@ int vn_residual_f64(vn_engine* h, const double* X, const double* diff, const dou
   if (h->layered) {
     LAYCHK(vn_layered_residual_f64(h->layered, h->theta64, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->stream,
                                    lerr_, sizeof lerr_));
+    return VN_OK;
+  }
+  if ((h->use_fused16 || h->two_pass) && vn_taylor16d_supported(h->net) && !getenv("VN_RESIDUAL_POINTWISE")) {
+    HIPCHK(vn_taylor16d_launch(h->net, h->theta64, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->ncu, h->stream));
     return VN_OK;
   }
   HIPCHK(vn_pointwise_residual_f64(h->net, h->theta64, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res,
