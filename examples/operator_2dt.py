@@ -5,9 +5,11 @@ discNum=[80,40], bDiscNum=40, tDiscNum=75) -> 240 000 test functions x 64 = 15.3
 train(weight=[5,1,1], smpScheme='uniform').  Prints the script's "approximation error" against its analytical solution
 (Leij & Dane, integrated over time) at t = T.
 
-    python examples/operator_2dt.py [out_folder] [epochs] [dedup]
-(a third argument `dedup` trains on the de-duplicated formulation, train(dedup=True): one network evaluation per unique
-quadrature point -- 2.05 M points instead of 15.36 M rows here; same loss and gradient up to fp32 rounding)
+    python examples/operator_2dt.py [out_folder] [epochs] [rowwise]
+Without a third argument train() chooses the formulation itself (dedup='auto', the default): on this uniform, unshuffled set
+that is the de-duplicated one -- one network evaluation per unique quadrature point, 2.05 M points instead of 15.36 M rows;
+same loss and gradient up to fp32 rounding.  `rowwise` as third argument asks for train(dedup=False), the reference's one
+evaluation per (test function, point) row.
 """
 import os
 import sys
@@ -46,7 +48,7 @@ def cExFun(x, t=None):
 def main():
     folder = sys.argv[1] if len(sys.argv) > 1 else 'out_operator_2dt'
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-    dedup = len(sys.argv) > 3 and sys.argv[3] == 'dedup'
+    dedup = False if (len(sys.argv) > 3 and sys.argv[3] == 'rowwise') else 'auto'
     vertices = np.array([[0.0, -0.5], [0.0, -a], [0.0, a], [0.0, 0.5], [2.0, 0.5], [2.0, -0.5]])
     domain = PolygonDomain2D(vertices)
     BC = [[], [0.0, 1.0, c0], [], [], [], []]                  # Dirichlet c = c0 on the inlet segment, natural elsewhere
@@ -63,7 +65,8 @@ def main():
     cEx = cExFun(coord, [T])
     cApp = vn.evaluate(coord, T)
     print('%s%d epochs in %.1f s (%.2f ms/epoch, %.3e training points/s); approximation error at t = T: %2.5f'
-          % ('de-duplicated formulation: ' if dedup else '', len(vn.trainRes.lossAll), dt, dt / len(vn.trainRes.lossAll) * 1e3, fd.nT * len(vn.trainRes.lossAll) / dt,
+          % ('de-duplicated formulation (%d unique points): ' % vn.dedup_state['unique_points'] if vn.dedup_state['on']
+             else 'row-wise formulation (%s): ' % vn.dedup_state['reason'], len(vn.trainRes.lossAll), dt, dt / len(vn.trainRes.lossAll) * 1e3, fd.nT * len(vn.trainRes.lossAll) / dt,
              uf.l2Err(cEx, cApp)))
 
 

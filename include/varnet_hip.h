@@ -144,7 +144,11 @@ int vn_set_interior(vn_engine* h, int32_t batch, const float* Input_dev, const f
  * uid [n_k*integ_num] row -> unique point and its CSR inverse (rowptr [U+1], rowidx [n_k*integ_num]),
  * vn_grad evaluates value and input gradient once per unique point and assembles the same loss and
  * gradient (same math, different rounding).  All device pointers.  Xu == NULL switches it off.
- * The map is validated on the device at this call (which therefore synchronises): an inconsistent one returns VN_EINVAL.
+ * The map is validated on the device at this call (which therefore synchronises): an inconsistent one returns VN_EINVAL
+ * (ranges, rowptr a partition of [0, n_k*integ_num), uid[rowidx[e]] = the point whose segment holds e, the rows of a point in
+ * increasing order -- hence rowidx a permutation).  The array LENGTHS are the caller's contract (the ABI carries pointers only).
+ * A call replaces the batch's previous registration even when it fails: after an error the batch is row-wise.
+ * A batch without interior rows (n_k == 0) is VN_EINVAL.
  * Requires a network of the 8-wave fused kernel (integ_num <= 256: the two-pass route's 216 included) and uniform supports.
  * The batch's gcoef is READ at this call (the engine keeps a copy
  * in CSR order for its seed gather): register again after changing gcoef in place; vn_set_interior clears the registration. */

@@ -657,9 +657,23 @@ def test_inconsistent_dedup_map_is_an_error_not_a_fault():
     eng.set_bic(rng.uniform(-1, 1, (8, d_in)).astype(np.float32), rng.standard_normal((8, 1)).astype(np.float32), 4, 2.0)
     eng.set_weights([1.0, 1.0, 1.0])
     eng.set_dedup(0, Xu, uid, rowptr, rowidx)                         # the consistent map registers
-    for what in ('uid', 'rowidx_range', 'rowidx_owner', 'rowptr_end', 'rowptr_order'):
+    gb = eng.bind_grad_buffer()
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g_dd = gb.cpu().numpy().copy()
+    eng.set_dedup(0)
+    eng.grad(0)
+    torch.cuda.synchronize()
+    g_row = gb.cpu().numpy().copy()
+    for what in ('uid', 'rowidx_range', 'rowidx_owner', 'rowptr_end', 'rowptr_order', 'rowidx_duplicate'):
         u2, rp2, ri2 = uid.copy(), rowptr.copy(), rowidx.copy()
-        if what == 'uid':
+        eng.set_dedup(0, Xu, uid, rowptr, rowidx)                     # a good registration that the bad call must REPLACE
+        if what == 'rowidx_duplicate':
+            # a row listed twice under its own point (and its neighbour never): every range / owner test passes, the
+            # gradient would be silently wrong -- caught by the order rule that makes rowidx a permutation
+            i = int(np.argmax(np.diff(rowptr) >= 2))
+            ri2[rowptr[i] + 1] = ri2[rowptr[i]]
+        elif what == 'uid':
             u2[5] = U + 7
         elif what == 'rowidx_range':
             ri2[11] = n + 1000000
@@ -671,11 +685,20 @@ def test_inconsistent_dedup_map_is_an_error_not_a_fault():
             rp2[3], rp2[4] = rp2[4] + 5, rp2[3]
         with pytest.raises(VNError, match='inconsistent de-duplication map'):
             eng.set_dedup(0, Xu, u2, rp2, ri2)
-    gb = eng.bind_grad_buffer()
+        # a rejected map leaves the batch ROW-WISE (not on the previous registration, whose arrays the binding released)
+        eng.grad(0)
+        torch.cuda.synchronize()
+        assert np.array_equal(gb.cpu().numpy(), g_row), what
+    with pytest.raises(AssertionError, match='one entry per interior row'):
+        eng.set_dedup(0, Xu, uid[:-q], rowptr, rowidx[:-q])           # short arrays never reach the device validator
     eng.set_dedup(0, Xu, uid, rowptr, rowidx)
     eng.grad(0)                                                      # the engine is still usable
     torch.cuda.synchronize()
-    assert np.isfinite(gb.cpu().numpy()).all()
+    assert np.array_equal(gb.cpu().numpy(), g_dd)
+    # a batch without interior rows has nothing to de-duplicate: an error code, not a zero-size launch
+    eng.set_interior(1, Xu[uid][:0], np.zeros((0, dim), dtype=np.float32), None, n_k=0, detJ=0.1)
+    with pytest.raises(VNError, match='no interior rows'):
+        eng.set_dedup(1, Xu, uid[:0], rowptr, rowidx[:0])
     eng.close()
 
 

@@ -2,6 +2,9 @@
 GPU tests through the public API (VarNet on the real HIP engine) and full-size property tests at
 the BASELINE configuration sizes, where the oracle is too slow to be the checker.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -160,6 +163,70 @@ def test_fullsize_sampled_oracle_check(cfg3):
     # by the cancellation inside R_k, not of the arithmetic.
     assert abs(g[P] - ref['loss']) <= 1e-5 * abs(ref['loss'])
     assert np.max(np.abs(g[:P] - gref)) <= 1e-4 * np.max(np.abs(gref))
+
+
+def test_fullsize_dedup_formulation(cfg3):
+    """The de-duplicated formulation at the size it is claimed for (BASELINE config 3: 6.4 M rows, 853 128 unique
+    quadrature points; the rows it must reproduce are VarNet.py:576-588 / TFModel.py:653-664): against the row-wise
+    gradient of the same engine (1e-4), against the fp64 oracle on the first 300 test functions at the stated bars
+    (loss 1e-5, gradient 1e-4), bitwise repeatable, and switching it off restores the row-wise bits."""
+    from varnet_amd.varnet import unique_points
+    vn, td = cfg3
+    fd, eng = vn.fixData, vn.engine
+    P, q, d = eng.P, fd.integNum, td.mor[0]
+    g_row = _grad(eng)
+    assert td.dedup_applies() is None and td.dedup_pays()
+    U = td.enable_dedup()
+    assert td.dedup_reason is None and U == 853128 and fd.nT == 6400000
+    g1 = _grad(eng)
+    g2 = _grad(eng)
+    assert np.array_equal(g1, g2)                                    # CSR-ordered sums: fixed summation order
+    assert not np.array_equal(g1, g_row)                             # ... and it IS another formulation that ran
+    gerr = np.max(np.abs(g1[:P] - g_row[:P])) / np.max(np.abs(g_row[:P]))
+    assert gerr <= 1e-4, gerr
+    for i in range(P, P + 4):                                        # loss, BC, IC, variational term
+        assert abs(g1[i] - g_row[i]) <= 1e-5 * abs(g_row[i]), (i - P, g1[i], g_row[i])
+    # the fp64 oracle on the first 300 test functions (the sample of test_fullsize_sampled_oracle_check)
+    n_s = 300
+    rows = n_s * q
+    eng.set_interior(3, d['Input'][:rows], d['gcoef'][:rows], None, n_k=n_s, detJ=fd.detJ)
+    g_row3 = _grad(eng, 3)
+    blk = d['Input_host'][:rows]
+    first, uid, rowptr, rowidx = unique_points(blk, fd.feDim, fd.hVec)
+    assert len(first) < rows / 2                                     # the sample's rows do share points
+    eng.set_dedup(3, blk[first], uid, rowptr, rowidx)
+    g3 = _grad(eng, 3)
+    flat = eng.get_params().astype(np.float64)
+    ref, gref = og.loss_and_grad(
+        flat, 3, [50] * 5, torch.float64, Input=d['Input'][:rows].cpu().numpy().astype(np.float64),
+        gcoef=d['gcoef'][:rows].cpu().numpy().astype(np.float64), source=None,
+        N=np.tile(fd.N, n_s).reshape(rows, 1).astype(np.float32).astype(np.float64),
+        dNt=np.tile(fd.dNt, n_s).reshape(rows, 1).astype(np.float32).astype(np.float64), integW=None,
+        intShape=[n_s, q], detJ=float(np.float32(fd.detJ)), detJvec=False,
+        biInput=d['biInput'].cpu().numpy().astype(np.float64),
+        biLabel=d['biLabel'].cpu().numpy().astype(np.float64).reshape(-1, 1), bDof=fd.bDofsum,
+        biDimVal=float(fd.biDimVal), w=np.array([3.0, 2.0, 5.0]), dim=2, time_dependent=True, is_source=False,
+        integWflag=False)
+    lerr = abs(g3[P] - ref['loss']) / abs(ref['loss'])
+    gerr3 = np.max(np.abs(g3[:P] - gref)) / np.max(np.abs(gref))
+    assert lerr <= 1e-5 and gerr3 <= 1e-4, (lerr, gerr3)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'dedup_fullsize_parity.json'), 'w') as f:
+            json.dump({'rows': int(fd.nT), 'unique_points': int(U), 'grad_err_vs_rowwise': float(gerr),
+                       'loss_err_vs_rowwise': float(abs(g1[P] - g_row[P]) / abs(g_row[P])),
+                       'sample_300_test_functions': {'unique_points': int(len(first)), 'loss_err_vs_fp64_oracle': float(lerr),
+                                                     'grad_err_vs_fp64_oracle': float(gerr3),
+                                                     'rowwise_grad_err_vs_fp64_oracle':
+                                                         float(np.max(np.abs(g_row3[:P] - gref)) / np.max(np.abs(gref)))}}, f, indent=1)
+    except OSError:
+        pass
+    # off again: the row-wise bits come back, for the full batch and for the sample
+    eng.set_dedup(3)
+    td.disable_dedup()
+    assert np.array_equal(_grad(eng, 3), g_row3)
+    assert np.array_equal(_grad(eng), g_row)
 
 
 @pytest.mark.parametrize('suppFactor', [1.0, 0.5])

@@ -444,3 +444,105 @@ def test_iter_plot_writes_the_reference_files(tmp_path):
     assert '20_loss.pdf' in os.listdir(tr.plotpath)
     with pytest.raises(ValueError):
         tr.iterPlot(pltFrmt='bmp')
+
+
+class _DedupRecorder(OracleEngine):
+    """Stand-in engine that accepts `vn_set_dedup` registrations (and keeps training row-wise on the oracle): what
+    `train(dedup=...)` asks of an engine can then be observed without a GPU."""
+    supported = True
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.dd = {}
+
+    def set_dedup(self, batch, Xu=None, uid=None, rowptr=None, rowidx=None):
+        if Xu is None:
+            self.dd.pop(batch, None)
+        else:
+            self.dd[batch] = (int(Xu.shape[0]), np.asarray(uid), np.asarray(rowptr), np.asarray(rowidx))
+
+    def dedup_supported(self):
+        return self.supported
+
+
+@pytest.fixture
+def dedup_engine(monkeypatch):
+    def make(self, processors):
+        fd = self.fixData
+        return _DedupRecorder(self.dim, self.inpDim, self.layerWidth, self.PDE.timeDependent, fd.integNum,
+                              isSource=self.lossOpt['isSource'], integWflag=self.lossOpt['integWflag'],
+                              learning_rate=self.learning_rate)
+    monkeypatch.setattr(VarNet, '_make_engine', make)
+
+
+def test_train_chooses_the_formulation_and_says_why(tmp_path, dedup_engine, monkeypatch):
+    """`train(dedup='auto')` is the default: on a uniform, unshuffled set whose step is large enough the
+    de-duplicated formulation is registered for every block; where it is not, the reason is WRITTEN (caseData.txt,
+    `vn.dedup_state`) and, for an explicit dedup=True, warned -- never a silent row-wise run."""
+    import warnings
+    kw = dict(weight=[10., 10., 1.], epochNum=2, saveFreq=100, verbose=False)
+    monkeypatch.setattr(vmod, 'DEDUP_MODEL', dict(vmod.DEDUP_MODEL, fixed_us=-1e9))      # the tiny test problem "pays"
+    vn = op1dt([6, 5], 5, 6)
+    vn.train(str(tmp_path / 'a'), **kw)
+    q = vn.fixData.integNum
+    assert vn.dedup_state['on'] and vn.dedup_state['requested'] == 'auto' and list(vn.engine.dd) == [0]
+    U, uid, rowptr, rowidx = vn.engine.dd[0]
+    assert U == vn.dedup_state['unique_points'] == 7 * 6 * 4 and len(uid) == 30 * q     # (5+1)(6+1) elements... x 2x2 Gauss points
+    assert np.array_equal(np.sort(rowidx), np.arange(30 * q)) and rowptr[-1] == 30 * q
+    assert 'de-duplicated formulation, %d unique quadrature points' % U in open(str(tmp_path / 'a' / 'caseData.txt')).read()
+    # two mini-batches: every block has its own map
+    vn.train(str(tmp_path / 'b'), batchNum=2, **kw)
+    assert sorted(vn.engine.dd) == [0, 1] and vn.dedup_state['on']
+    # the real threshold: this step is far too small to pay -> 'auto' stays row-wise and says so; True forces it
+    monkeypatch.undo()
+    monkeypatch.setattr(VarNet, '_make_engine', lambda self, p: _DedupRecorder(
+        self.dim, self.inpDim, self.layerWidth, self.PDE.timeDependent, self.fixData.integNum,
+        isSource=self.lossOpt['isSource'], integWflag=self.lossOpt['integWflag'], learning_rate=self.learning_rate))
+    vn = op1dt([6, 5], 5, 6)
+    vn.train(str(tmp_path / 'c'), **kw)
+    assert not vn.dedup_state['on'] and 'too small' in vn.dedup_state['reason'] and not vn.engine.dd
+    assert 'row-wise formulation (dedup=\'auto\'): the step is too small' in open(str(tmp_path / 'c' / 'caseData.txt')).read()
+    vn.train(str(tmp_path / 'd'), dedup=True, **kw)
+    assert vn.dedup_state['on'] and list(vn.engine.dd) == [0]
+    vn.train(str(tmp_path / 'e'), dedup=False, **kw)
+    assert not vn.dedup_state['on'] and not vn.tData.dedup_on
+    # every reason it cannot apply is named: shuffled mini-batches, non-uniform supports, unsupported network, dim > 3
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        vn.train(str(tmp_path / 'f'), dedup=True, batchNum=2, shuffleData=True, **kw)
+    assert not vn.dedup_state['on'] and any('shuffled' in str(w.message) for w in rec)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        vn.train(str(tmp_path / 'g'), dedup='auto', batchNum=2, shuffleData=True, **kw)
+    assert 'shuffled' in vn.dedup_state['reason'] and not any('dedup' in str(w.message) for w in rec)    # 'auto' records, True warns
+    vn.engine.supported = False
+    with pytest.warns(UserWarning, match='outside the 8-wave fused kernel family'):
+        vn.train(str(tmp_path / 'h'), dedup=True, **kw)
+    vn.engine.supported = True
+    td = vn._build_tdata()
+    vn.fixData.detJvec = True
+    assert 'non-uniform' in td.dedup_applies()
+    vn.fixData.detJvec = False
+    td.shuffled = True
+    assert td.enable_dedup() == 0 and 'shuffled' in td.dedup_reason
+    with pytest.raises(ValueError, match='dedup must be'):
+        vn.train(str(tmp_path / 'i'), dedup='yes', **kw)
+
+
+def test_dedup_pay_off_estimate_tracks_the_real_map(dedup_engine):
+    """`dedup_pays` decides before the map exists: its rows-per-point estimate stays within 15 % of the ratio the map
+    then has, for whole grids and for mini-batch blocks, and BASELINE configs 2 and 3 are on the paying side."""
+    from varnet_amd.varnet import unique_points
+    for vn, bn in ((op1dt([20], 20, 30), None), (op1dt([20], 20, 30), 4), (op1dt([20], 50, 200), None),
+                   (op2dt([8, 6], 6, 8), None), (op2dt([8, 6], 6, 8), 3), (op2dt([16, 12], 10, 12), None)):
+        td = vn._build_tdata(batchNum=bn)
+        fd, q = vn.fixData, vn.fixData.integNum
+        n0, n1 = td.block(0)
+        first = unique_points(td.mor[0]['Input_host'][n0 * q:n1 * q], fd.feDim, fd.hVec)[0]
+        true = (n1 - n0) * q / len(first)
+        est = td.rows_per_point_estimate()
+        assert abs(est - true) <= 0.15 * true, (vn.discNum, vn.tDiscNum, bn, est, true)
+    assert op1dt([50] * 4, 50, 200)._build_tdata().dedup_pays()          # config 2: 0.170 -> 0.116 ms/step measured
+    assert not op1dt([6, 5], 5, 6)._build_tdata().dedup_pays()
+    assert not op1dt([20] * 3, 20, 300)._build_tdata().dedup_pays()      # config 1: 36.8 us either way -> row-wise
+    assert not op1dt([20], 50, 200)._build_tdata().dedup_pays()          # 160 k rows on a [20] net: 21.0 against 28.8 us

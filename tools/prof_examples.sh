@@ -19,7 +19,7 @@ for r in rows[:9]: print('  %-70s calls %7s total %8.1f ms (%4.1f %%) avg %8.1f 
 PY
   rm -rf gpurun_out/exprof $2
 }
-if [ "$1" = "2dt" ]; then run operator_2dt gpurun_out/ex3 3000 dedup; exit 0; fi
+if [ "$1" = "2dt" ]; then run operator_2dt gpurun_out/ex3 3000; exit 0; fi
 run operator_1dt gpurun_out/ex1 30000
 run operator_1dtmor gpurun_out/ex2 300
-run operator_2dt gpurun_out/ex3 3000 dedup
+run operator_2dt gpurun_out/ex3 3000

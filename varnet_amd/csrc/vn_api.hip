@@ -744,6 +744,10 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     b.Xu = nullptr; b.uid = nullptr; b.rowptr = nullptr; b.rowidx = nullptr; b.U = 0;
     return VN_OK;
   }
+  // A registration replaces the previous one: from here on the batch is row-wise until THIS map has been accepted, so a
+  // rejected call never leaves the engine pointing at the previous call's arrays (which the caller may release on error).
+  b.Xu = nullptr; b.uid = nullptr; b.rowptr = nullptr; b.rowidx = nullptr; b.U = 0;
+  if (b.n_k <= 0) return fail(VN_EINVAL, "batch %d has no interior rows: nothing to de-duplicate", batch);
   if (!uid || !rowptr || !rowidx || U <= 0) return fail(VN_EINVAL, "null argument");
   // the formulation has no tiles of whole test functions (its rows are unique points), so it also serves integ_num beyond one
   // 128-point tile -- the networks of the two-pass route (216: three-point Gauss in 2D+t) -- up to the seed kernel's 256-row chunk
@@ -785,7 +789,7 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     (void)hipFree(err_dev);
     if (e != hipSuccess) return fail(VN_EHIP, "vn_set_dedup: %s", hipGetErrorString(e));
     if (bad) return fail(VN_EINVAL, "inconsistent de-duplication map: %d violation(s) (need 0 <= uid < U, rowptr[0] = 0 <= ... <= rowptr[U] = n_k*integ_num, "
-                                    "0 <= rowidx < n_k*integ_num and uid[rowidx[e]] = the point whose segment holds e)", bad);
+                                    "0 <= rowidx < n_k*integ_num, uid[rowidx[e]] = the point whose segment holds e, rows of a point in increasing order)", bad);
   }
   // With constant coefficients gcoef = kappa dN/dx + v N repeats with period integ_num along the rows (the reference tiles the
   // tables to nT rows, VarNet.py:837): detected here, bitwise, and both assembly kernels then read the rows of test function 0

@@ -197,8 +197,12 @@ __global__ __launch_bounds__(256) void vn_dedup_periodic_kernel(const unsigned* 
 
 // Registration-time check of a de-duplication map (vn_set_dedup): every later kernel indexes device memory with these
 // arrays, so an inconsistent map must come back as an error code, not as a GPU fault.  err[0] = number of violations:
-// uid[r] in [0, U); rowptr[0] = 0, non-decreasing, rowptr[U] = nT; rowidx[e] in [0, nT) and uid[rowidx[e]] = the point
-// whose segment holds e.
+// uid[r] in [0, U); rowptr[0] = 0, non-decreasing, rowptr[U] = nT; rowidx[e] in [0, nT), uid[rowidx[e]] = the point
+// whose segment holds e, and the rows of a point in strictly increasing order.  Together: the nT entries of rowidx are
+// distinct (within a segment by the order, across segments by their uid) and in range, i.e. a permutation of the rows --
+// a row listed twice (and another one never) would pass every range test and give a silently wrong gradient.
+// The arrays' LENGTHS are the caller's contract (uid, rowidx: n_k * integ_num entries, rowptr: U + 1): the ABI carries
+// pointers only, the Python binding asserts them.
 __global__ __launch_bounds__(256) void vn_dedup_check_kernel(const int* uid, const int* rowptr, const int* rowidx, long nT, long U,
                                                              int* err) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -210,10 +214,12 @@ __global__ __launch_bounds__(256) void vn_dedup_check_kernel(const int* uid, con
     if (e0 > e1 || e0 < 0 || e1 > nT) {
       bad += 1;
     } else {
+      int prev = -1;
       for (int e = e0; e < e1; ++e) {
         const int r = rowidx[e];
         if (r < 0 || r >= nT) bad += 1;
-        else if (uid[r] != i) bad += 1;
+        else if (uid[r] != i || r <= prev) bad += 1;
+        prev = r;
       }
     }
   }
@@ -231,6 +237,7 @@ __global__ __launch_bounds__(256) void vn_dedup_permute_kernel(const float* gcoe
 }  // namespace
 
 hipError_t vn_dedup_seed_launch(const VnDedupArgs& a, int grid, hipStream_t s) {
+  if (grid <= 0) return hipSuccess;              // no test functions: nothing to assemble (a grid of 0 is a launch error)
   hipLaunchKernelGGL(vn_dedup_seed_kernel, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }
@@ -257,6 +264,7 @@ hipError_t vn_dedup_permute_launch(const float* gcoef, const int* rowidx, float*
 
 hipError_t vn_dedup_gather_launch(const VnDedupArgs& a, hipStream_t s) {
   const int grid = (int)((a.U + VN_GATHER_PB - 1) / VN_GATHER_PB);
+  if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL(vn_dedup_gather_kernel, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }

@@ -301,9 +301,17 @@ class VNEngine:
         i32 = lambda a: (a if isinstance(a, t.Tensor) else t.as_tensor(np.ascontiguousarray(a))).to(
             device=self.device, dtype=t.int32).contiguous()
         uid, rowptr, rowidx = i32(uid), i32(rowptr), i32(rowidx)
+        # the ABI carries pointers only: the lengths the validator and every later kernel rely on are checked here
+        kept = self._keep.get(('int', batch))
+        nT = None if kept is None else int(kept[0].shape[0])
         assert rowptr.numel() == Xu.shape[0] + 1 and uid.numel() == rowidx.numel()
+        assert nT is None or uid.numel() == nT, 'uid / rowidx must have one entry per interior row (%s != %s)' % (uid.numel(), nT)
+        old = self._keep.pop(('dd', batch), None)
+        try:
+            self._ck(self.lib.vn_set_dedup(self.h, batch, _ptr(Xu), Xu.shape[0], _ptr(uid), _ptr(rowptr), _ptr(rowidx)))
+        finally:
+            del old           # the engine dropped the previous registration before validating this one (vn_set_dedup)
         self._keep[('dd', batch)] = (Xu, uid, rowptr, rowidx)
-        self._ck(self.lib.vn_set_dedup(self.h, batch, _ptr(Xu), Xu.shape[0], _ptr(uid), _ptr(rowptr), _ptr(rowidx)))
 
     def set_bic(self, biInput, biLabel, bDof, biDimVal):
         if biInput is None or len(biInput) == 0:

@@ -32,6 +32,14 @@ uf = UF()
 shape = np.shape
 size = np.size
 
+# `train(dedup='auto')`: time model of one step in either formulation, fitted to 36 measured (grid, net) pairs on one MI355X
+# (tools/dedup_auto_perf.py -> profiles/r6_dedup_auto_perf.txt; every pair the model sends to the de-duplicated formulation was
+# measured faster there, and no pair it keeps row-wise was more than 4 % faster de-duplicated).  S = sum of the hidden widths:
+#   row-wise        rows * row_ps * S
+#   de-duplicated   unique points * point_ps * S + rows * asm_ps (the two assembly kernels) + fixed_us + param_ns * P
+#                   (three more kernel boundaries and a second prologue that images the P parameters into LDS)
+DEDUP_MODEL = {'row_ps': 4.5, 'point_ps': 6.2, 'asm_ps': 10.0, 'fixed_us': 20.0, 'param_ns': 2.2}
+
 
 def unique_points(Input, feDim, hVec):
     """
@@ -518,6 +526,7 @@ class ManageTrainData:
         self.batchNum, self.batchLen, self.puNum = batchNum, batchLen, puNum
         self.batchInd = np.arange(self.nt)
         self.shuffled = False
+        self.dedup_on, self.dedup_reason = False, None
         self._register()
 
     def block(self, bi):
@@ -608,26 +617,82 @@ class ManageTrainData:
         if self.vn.PDE.MORvar is not None:
             self.biPerm = {}                        # reset by updateDictFields before the batch is used
         self.shuffled = True
+        self.dedup_on = False                       # vn_set_interior drops the registrations; a shuffled set is row-wise
         self._register()
 
     def activate(self):
         """(Re-)register this set's batches with the engine (after another set used it)."""
         self._register()
-        if getattr(self, 'dedup_on', False):
+        if self.dedup_on:
             self.enable_dedup()
+
+    def dedup_applies(self):
+        """None when the de-duplicated formulation can serve this set, else the reason it cannot (a sentence)."""
+        vn = self.vn
+        fd = vn.fixData
+        if self.shuffled:
+            return 'the mini-batches are shuffled (the point map of every block would have to be rebuilt at each shuffle)'
+        if fd.detJvec:
+            return ('the training set is non-uniform (per-test-function supports, detJvec=True, VarNetUtility.py:466-545): '
+                    'its rows share no quadrature points')
+        if vn.dim > 3:
+            return 'the problem has dim = %d > 3 space coordinates' % vn.dim
+        if not hasattr(vn.engine, 'set_dedup'):
+            return 'this engine has no vn_set_dedup'
+        if not getattr(vn.engine, 'dedup_supported', lambda: True)():
+            return ('the network %s with integNum = %d is outside the 8-wave fused kernel family the formulation runs on '
+                    '(widths <= 64, <= 8 layers, integNum <= 256)' % (list(vn.layerWidth), self.integNum))
+        return None
+
+    def dedup_pays(self):
+        """
+        The rule behind `train(dedup='auto')`: True when the de-duplicated step is expected to be the faster one.
+        It costs 8 F_pt per unique point in five launches against 6 F_pt per row in two, so it wins whenever the step is
+        work-bound (up to 5.2 x on BASELINE config 3) and loses on steps so small that its three extra kernel boundaries and
+        second prologue outweigh the work saved (0.5 x on an 8 000-row step).  Deterministic -- a function of the grid and
+        the network, never of a timing -- so that a run is reproducible: DEDUP_MODEL, evaluated on the smallest block.
+        """
+        m = DEDUP_MODEL
+        lw = [self.vn.inpDim] + list(self.vn.layerWidth) + [1]
+        P = sum(a * b + b for a, b in zip(lw[:-1], lw[1:]))
+        S = float(sum(self.vn.layerWidth))
+        rows = min([(n1 - n0) * self.integNum for n0, n1 in map(self.block, range(self.batchNum)) if n1 > n0] or [0])
+        if rows == 0:
+            return False
+        # the exact count of unique points is known only once the map is built (seconds of host work at 6.4 M rows): the
+        # decision uses the grid's own ratio, 2^feDim rows per point reached from below
+        U = rows / self.rows_per_point_estimate()
+        t_row = rows * m['row_ps'] * S * 1e-6
+        t_dd = U * m['point_ps'] * S * 1e-6 + rows * m['asm_ps'] * 1e-6 + m['fixed_us'] + m['param_ns'] * P * 1e-3
+        return t_row >= t_dd
+
+    def rows_per_point_estimate(self):
+        """Rows per unique quadrature point of one block on the uniform grid, without building the map: per dimension a
+        run of n consecutive hat functions covers n + 1 elements, so 2n element visits hit n + 1 distinct elements."""
+        n0, n1 = self.block(0)
+        nk = max(n1 - n0, 1)
+        tdn = int(self.vn.tDiscNum) if self.vn.PDE.timeDependent else 1
+        if self.vn.PDE.timeDependent:                 # blocks are contiguous in (space-major, time-minor) order
+            nt_t = min(nk, tdn)
+            ns = max(nk // tdn, 1)
+        else:
+            nt_t, ns = 1, nk
+        r = 2.0 * nt_t / (nt_t + 1.0) if self.vn.PDE.timeDependent else 1.0
+        per = max(ns ** (1.0 / self.vn.dim), 1.0)
+        r *= (2.0 * per / (per + 1.0)) ** self.vn.dim
+        return max(r, 1.0)
 
     def enable_dedup(self):
         """
         Switch every registered batch to the de-duplicated formulation (`vn_set_dedup`): one network
         evaluation per unique quadrature point instead of one per (test function, point) row.
         Needs the periodic FE tables (uniform supports) and an unshuffled set; returns the total
-        number of unique points, or 0 if it does not apply.
+        number of unique points, or 0 if it does not apply -- `self.dedup_reason` then says why.
         """
         vn = self.vn
         fd = vn.fixData
-        if self.shuffled or fd.detJvec or not hasattr(vn.engine, 'set_dedup') or self.vn.dim > 3:
-            return 0
-        if not getattr(vn.engine, 'dedup_supported', lambda: True)():
+        self.dedup_reason = self.dedup_applies()
+        if self.dedup_reason is not None:
             return 0
         q, total = self.integNum, 0
         cache = getattr(self, '_dd_cache', {})
@@ -651,7 +716,7 @@ class ManageTrainData:
 
     def disable_dedup(self):
         """Back to the row-wise formulation for every registered batch (`vn_set_dedup` with no points)."""
-        if not getattr(self, 'dedup_on', False):
+        if not self.dedup_on:
             return
         for mb in range(len(self.mor)):
             for bi in range(self.batchNum):
@@ -1177,12 +1242,44 @@ class VarNet:
             eng.apply()
             loss_acc += gb[P]
 
+    def _choose_formulation(self, tData, dedup, shuffleData=False):
+        """Apply `train(dedup=...)` to a training set; returns {'requested', 'on', 'unique_points', 'reason'} and records the
+        decision in caseData.txt.  A request that cannot be served is a warning (`dedup=True`) or a recorded sentence
+        ('auto'), never a silent row-wise run."""
+        state = {'requested': dedup, 'on': False, 'unique_points': 0, 'reason': None}
+        if dedup is False:
+            state['reason'] = 'dedup=False was requested'
+        elif shuffleData:
+            state['reason'] = 'shuffleData=True: ' + \
+                'the mini-batches are shuffled (the point map of every block would have to be rebuilt at each shuffle)'
+        else:
+            state['reason'] = tData.dedup_applies()
+            if state['reason'] is None and dedup == 'auto' and not tData.dedup_pays():
+                state['reason'] = ('the step is too small for it to pay (three more kernel launches and a second prologue '
+                                   'against the work saved: DEDUP_MODEL); dedup=True forces it')
+            if state['reason'] is None:
+                state['unique_points'] = int(tData.enable_dedup())
+                state['on'] = state['unique_points'] > 0
+                state['reason'] = tData.dedup_reason
+        if state['on']:
+            msg = ('interior term: de-duplicated formulation, %d unique quadrature points for %d rows per epoch '
+                   '(dedup=%r)\n\n' % (state['unique_points'], self.fixData.nT * self.fixData.MORbatchNum, dedup))
+        else:
+            msg = 'interior term: row-wise formulation (dedup=%r): %s\n\n' % (dedup, state['reason'])
+            if dedup is True:
+                warnings.warn('dedup=True cannot be served, training row-wise: ' + state['reason'])
+        if getattr(self, 'trainRes', None) is not None:
+            if self.trainRes.verbose and self.rank == 0:
+                print(msg)
+            self.trainRes.writeCase(msg)
+        return state
+
     def train(self, folderpath, weight=None, smpScheme='uniform', epochNum=500000, tol=1.e-1,
               verbose=True, saveFreq=100, pltReplace=True, saveMORdata=False, frac=None,
               addTrainPts=True, suppFactor=1.0, multiTrainUpd=False, trainUpdelay=2e4, tolUpd=0.01,
               reinitrain=True, updateWeights=False, normalizeW=False, adjustWeight=False,
               useOriginalW=False, batchNum=None, batchLen=None, shuffleData=False, shuffleFreq=1,
-              dedup=False, lossLag=0):
+              dedup='auto', lossLag=0):
         """Training loop of /root/reference/VarNet.py:1197-1421 (uniform, random and residual-driven
         "optimal" sampling with re-initialisation and re-weighting)."""
         if self._towers is not None:                  # controller of forked towers: every tower runs the loop
@@ -1218,11 +1315,15 @@ class VarNet:
         eng, fd = self.engine, self.fixData
         torch = eng.torch
         tData = self._build_tdata(batchNum, batchLen)        # first set is always uniform (VarNet.py:1300)
-        if dedup and not shuffleData:
-            tData.enable_dedup()                                # extension: one evaluation per unique point
         trainRes = TrainResult(folderpath if self.rank == 0 else None, fd.cEx is not None, verbose, saveFreq, pltReplace)
         trainRes.initializeCase(self, argDict)
         self.trainRes = trainRes
+        # Formulation of the interior term (extension; the arithmetic is the reference's either way, VarNet.py:576-588 and
+        # TFModel.py:653-664): 'auto' (default) evaluates the network once per UNIQUE quadrature point wherever that applies
+        # and pays, True asks for it and warns when it cannot be had, False keeps one evaluation per (test function, point) row.
+        if dedup not in (True, False, 'auto'):
+            raise ValueError('dedup must be True, False or \'auto\'!')
+        self.dedup_state = self._choose_formulation(tData, dedup, shuffleData)
 
         def set_train_weights(tD, wts):
             eng.set_weights([1.0, 1.0, 1.0])
