@@ -99,7 +99,7 @@ int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_ker
                                 * 4: vn_comm_available, Adam hyper-parameters validated (no silent NaN from a zeroed config);
                                 * 5: vn_comm_version;
                                 * 6: vn_forward_grad, vn_debug_calibrate */
-#define VN_ABI_VERSION 6     /* what this header describes: a binding must refuse a library that reports another number */
+#define VN_ABI_VERSION 7     /* what this header describes: a binding must refuse a library that reports another number */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
 int vn_create(const vn_config* cfg, vn_engine** out);
@@ -232,7 +232,21 @@ int vn_comm_init(vn_engine* h, int32_t rank, int32_t world, const void* unique_i
 /* Ranks RCCL reports for the attached communicator (1 if none); rank_out may be NULL. */
 int vn_comm_size(const vn_engine* h, int32_t* world_out, int32_t* rank_out);
 int vn_comm_destroy(vn_engine* h);
-/* In-place SUM all-reduce of the gradient buffer over the communicator, on the engine stream. */
+/* ncclCommInitRank has no timeout.  A caller that runs vn_comm_init on a helper thread and stops waiting for it (a peer is
+ * wedged) calls vn_comm_abandon from the thread that drives the engine: from then on the engine has no communicator and
+ * takes none -- a vn_comm_init that is still running leaves its communicator aside when it returns (VN_ESTATE), one that had
+ * come up is withdrawn WITHOUT ncclCommDestroy (which could block on the wedged peer) -- so vn_train_step / vn_train_epoch
+ * never enqueue a collective on it.  Idempotent.  After abandonment do not call vn_destroy while a vn_comm_init may still
+ * be running (it writes into the handle): leave the handle to the process exit. */
+int vn_comm_abandon(vn_engine* h);
+/* Failure under a communicator.  vn_train_step / vn_train_epoch on a handle with a communicator are gradient -> all-reduce
+ * -> update.  When the gradient fails on ONE rank (bad batch index, HIP error) that rank returns its error without entering
+ * the collective and with parameters, optimizer slots and step counter untouched; the all-reduce its peers enqueued for
+ * that step never completes.  A failed step under a communicator therefore ends the JOB: the failing process must exit
+ * non-zero and its launcher must end the peers (varnet_amd/launch.py and torch.distributed.run both do; the former also
+ * reports the failing rank's last stage).  Nothing in the library waits for a dead peer on the host: the peers' host
+ * threads block at their next synchronisation, not inside vn_train_*.
+ * In-place SUM all-reduce of the gradient buffer over the communicator, on the engine stream. */
 int vn_allreduce_grad(vn_engine* h);
 
 /* Adam step counter (global_step, TFModel.py:312). */

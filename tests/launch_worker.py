@@ -43,6 +43,39 @@ if mode == 'stuck':
     dist.barrier()
     sys.exit(0)
 
+if mode == 'long_healthy':
+    # a job that is past its bootstrap and simply runs longer than the launcher's deadline
+    mark_stage('comm_done')
+    mark_stage('timed')
+    time.sleep(float(sys.argv[2]))
+    dist.barrier()
+    mark_stage('done')
+    sys.exit(0)
+
+if mode == 'step_fail':
+    # rank 1's engine call fails inside a training step (VNEngine._ck) while rank 0 waits for it in the step's collective:
+    # what a one-rank vn_grad failure under a communicator looks like from outside (include/varnet_hip.h)
+    from varnet_amd.engine import VNEngine, VNError
+
+    class Lib:
+        @staticmethod
+        def vn_last_error():
+            return b'batch 7 was never registered'
+
+    class StandIn:
+        lib = Lib()
+    mark_stage('comm_done')
+    mark_stage('timed')
+    if rank == 1:
+        try:
+            VNEngine._ck(StandIn(), 1)
+        except VNError as e:
+            print(json.dumps({"error": str(e), "rank": rank}), flush=True)
+            sys.exit(3)
+    t = torch.zeros(4)
+    dist.all_reduce(t)                                # never completes: rank 1 is gone
+    sys.exit(0)
+
 if mode == 'bootstrap':
     from varnet_amd.engine import VNEngine
     kind = sys.argv[2]
@@ -93,10 +126,18 @@ if mode == 'bootstrap':
             self.inited = None
             self.destroyed = True
 
+        abandon_calls = 0
+
+        def comm_abandon(self, pending=None):         # VNEngine.comm_abandon: vn_comm_abandon + the exit guard
+            self.abandon_calls += 1
+            self._comm_abandoned = True
+
     eng = StandIn()
     ok, why = VNEngine.comm_init_from_torch(eng, dist)
-    print(json.dumps({"rank": rank, "ok": bool(ok), "why": why, "inited": eng.inited, "last_stage": mark_stage.last,
-                      "abandoned": bool(getattr(eng, '_comm_abandoned', False)), "destroyed": eng.destroyed}), flush=True)
+    assert mark_stage.last == 'comm_done'            # whatever the outcome: past the launcher's bootstrap deadline
+    print(json.dumps({"rank": rank, "ok": bool(ok), "why": why, "inited": eng.inited, "last_stage": mark_stage.history[-2],
+                      "abandoned": bool(getattr(eng, '_comm_abandoned', False)), "destroyed": eng.destroyed,
+                      "abandon_calls": eng.abandon_calls}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     sys.stdout.flush()

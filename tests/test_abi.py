@@ -29,9 +29,9 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), 'missing export ' + n
     assert set(names) == set(engine.ABI_SYMBOLS), set(names) ^ set(engine.ABI_SYMBOLS)
-    assert lib.vn_abi_version() == engine.VN_ABI_VERSION == 6
+    assert lib.vn_abi_version() == engine.VN_ABI_VERSION == 7
     hdr = open(os.path.join(ROOT, 'include', 'varnet_hip.h')).read()
-    assert re.search(r'#define\s+VN_ABI_VERSION\s+6\b', hdr)
+    assert re.search(r'#define\s+VN_ABI_VERSION\s+7\b', hdr)
 
 
 def test_no_silent_cpu_fallback():

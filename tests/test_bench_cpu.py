@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -78,6 +79,38 @@ def test_launch_reports_the_stage_of_a_rank_that_died():
     assert rep['reason'] == 'rank 1 exited with status 7' and rep['last_stage']['1'] == 'pg_init' and rep['exit_status']['1'] == 7
 
 
+def test_launch_deadline_is_a_bootstrap_deadline_not_a_wall_clock_limit():
+    """a healthy job whose ranks are past the bootstrap must not be ended for running longer than the deadline
+    (the staleness of a BOOTSTRAP stage is what the deadline bounds); an overall limit is opt-in."""
+    sys.path.insert(0, ROOT)
+    from varnet_amd import launch
+    t0 = time.time()
+    rc = launch.spawn_ranks([WORKER, 'long_healthy', '12'], 2, deadline_s=4.0)
+    assert rc == 0 and time.time() - t0 >= 12.0
+    assert launch.last_report['last_stage'] == {'0': 'done', '1': 'done'}
+    rc = launch.spawn_ranks([WORKER, 'long_healthy', '60'], 2, deadline_s=4.0, overall_s=15.0)
+    assert rc == 124 and 'overall limit' in launch.last_report['reason']
+
+
+def test_one_rank_step_failure_ends_the_job_and_names_the_error(capfd):
+    """VERDICT r5 (weak 6): under a communicator a rank whose gradient fails returns before the all-reduce and its peers wait
+    in it.  Settled semantics (include/varnet_hip.h, "Failure under a communicator"): the failing rank's process exits
+    non-zero, the launcher ends the peers by PID within seconds -- not at its deadline -- and its report carries the failing
+    rank's stage, which VNEngine._ck set to the engine's error text."""
+    sys.path.insert(0, ROOT)
+    from varnet_amd import launch
+    t0 = time.time()
+    rc = launch.spawn_ranks([WORKER, 'step_fail'], 2, deadline_s=120.0)
+    dt = time.time() - t0
+    assert rc == 3 and dt < 90
+    rep = launch.last_report
+    assert rep['reason'] == 'rank 1 exited with status 3' and rep['alive'] == [0]      # rank 0 sat in the collective: ended by PID
+    assert rep['last_stage']['1'].startswith('engine_error: varnet_hip error 1: batch 7 was never registered')
+    assert rep['last_stage']['0'] == 'timed'
+    lines = [json.loads(ln) for ln in capfd.readouterr().out.splitlines() if ln.startswith('{')]
+    assert any(js.get('rank') == 1 and 'batch 7' in js.get('error', '') for js in lines)
+
+
 def test_rank_watchdog_ends_a_rank_with_its_last_stage():
     """the same deadline for a rank started by another launcher (torch.distributed.run): the rank's own one-line diagnosis"""
     r = subprocess.run([sys.executable, WORKER, 'watchdog'], capture_output=True, text=True, timeout=120)
@@ -117,6 +150,7 @@ def test_comm_bootstrap_survives_a_wedged_comm_init(capfd):
     assert sorted(lines) == [0, 1]
     for r, js in lines.items():
         assert js['ok'] is False and js['abandoned'] is True and js['destroyed'] is False and js['last_stage'] == 'comm_agree'
+        assert js['abandon_calls'] == 1      # the communicator is withdrawn INSIDE the engine (vn_comm_abandon), not only flagged
     assert 'did not return within 3 s on rank 1' in lines[1]['why'] and 'abandoned' in lines[0]['why']
     assert lines[0]['inited'] == [0, 2] and lines[1]['inited'] is None
 

@@ -34,11 +34,13 @@ def _run(rank, world, port, outdir, batchNum):
         dist.init_process_group('gloo', rank=rank, world_size=world)
     _patch()
     vn = op1dt(layerWidth=[6, 5], discNum=5, tDiscNum=7)
-    res = vn.train(os.path.join(outdir, 'w%d' % world), weight=[10., 10., 1.], epochNum=3, saveFreq=100,
+    res = vn.train(os.path.join(outdir, 'w%d' % world), weight=[10., 10., 1.], epochNum=3, saveFreq=2,
                    verbose=False, batchNum=batchNum)
+    sim = vn.simRes(tcoord=[0.3], plot=False)                # every rank: the monitors it calls are rank-local
     if rank == 0:
         np.savez(os.path.join(outdir, 'out_w%d_b%s.npz' % (world, batchNum)),
-                 theta=vn.engine.theta, loss=np.array(res.lossAll), w=res.trainWeight)
+                 theta=vn.engine.theta, loss=np.array(res.lossAll), w=res.trainWeight,
+                 lossVec=np.asarray(res.lossVec[0]), lossField=np.asarray(sim['lossField'][0]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -61,10 +63,17 @@ def test_world2_matches_world1(tmp_path, batchNum):
     b = np.load(os.path.join(out, 'out_w2_b%s.npz' % batchNum))
     # the recorded weights are per feed: BC/IC entries divided by batchNum * puNum (VarNetUtility.py:900-901)
     np.testing.assert_allclose(b['w'] * np.array([2.0, 2.0, 1.0]), a['w'], rtol=1e-10)
+    # the loss field of a monitor is the towers' fields concatenated in tower order, mini-batch by mini-batch
+    # (TFModel.py:319, VarNetUtility.py:1085-1090): one entry per test function, whatever the world size
+    assert b['lossVec'].shape == a['lossVec'].shape == (35, 1)
     if batchNum is None:
         # identical partition of the sum -> same trajectory up to fp64 summation order
         np.testing.assert_allclose(b['loss'], a['loss'], rtol=1e-9)
         np.testing.assert_allclose(b['theta'], a['theta'], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(b['lossVec'], a['lossVec'], rtol=1e-6, atol=1e-14)
+        # ... and simRes interpolates it under towers as it does on one processor (VarNet.py:2043-2047)
+        assert np.abs(a['lossField']).max() > 0
+        np.testing.assert_allclose(b['lossField'], a['lossField'], rtol=1e-6, atol=1e-12 * np.abs(a['lossField']).max())
     else:
         # with mini-batches the (batch, tower) blocks differ between world sizes
         # (block j = bi*puNum + rank), so only the first epoch's first loss is comparable in size
@@ -82,6 +91,8 @@ def test_world4_uneven_blocks_match_world1(tmp_path):
     np.testing.assert_allclose(b['w'] * np.array([4.0, 4.0, 1.0]), a['w'], rtol=1e-10)
     np.testing.assert_allclose(b['loss'], a['loss'], rtol=1e-9)
     np.testing.assert_allclose(b['theta'], a['theta'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(b['lossVec'], a['lossVec'], rtol=1e-6, atol=1e-14)     # ragged / empty blocks gathered in tower order
+    np.testing.assert_allclose(b['lossField'], a['lossField'], rtol=1e-6, atol=1e-12 * np.abs(a['lossField']).max())
 
 
 def test_world8_uneven_blocks_match_world1(tmp_path):
@@ -96,6 +107,8 @@ def test_world8_uneven_blocks_match_world1(tmp_path):
     np.testing.assert_allclose(b['w'] * np.array([8.0, 8.0, 1.0]), a['w'], rtol=1e-10)
     np.testing.assert_allclose(b['loss'], a['loss'], rtol=1e-9)
     np.testing.assert_allclose(b['theta'], a['theta'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(b['lossVec'], a['lossVec'], rtol=1e-6, atol=1e-14)     # ragged / empty blocks gathered in tower order
+    np.testing.assert_allclose(b['lossField'], a['lossField'], rtol=1e-6, atol=1e-12 * np.abs(a['lossField']).max())
 
 
 # ---- cases the round-1 review asked for ------------------------------------------------------------

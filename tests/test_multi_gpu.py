@@ -157,6 +157,90 @@ def test_bootstrap_through_torch_with_the_real_rccl_world1():
     assert rc == 0, text
 
 
+def _abandon_world1(q):
+    """forked child: the C layer of an abandoned communicator"""
+    try:
+        import torch
+        from tests.test_engine_gpu import synth
+        from varnet_amd.engine import VNEngine, VNError
+        d = synth(5, 3, 2, [50] * 5, 64, 40, 60, 25)
+
+        def make():
+            eng = VNEngine(2, 3, [50] * 5, True, 64)
+            eng.init_params(seed=3)
+            eng.set_fe_table(d['N1'], d['dNt1'], None)
+            eng.set_interior(0, d['Input'], d['gcoef'], None, n_k=40, detJ=d['detJ'])
+            eng.set_bic(d['biInput'], d['biLabel'], 25, 2.0)
+            eng.set_weights(d['w'])
+            return eng
+
+        def train(eng):
+            acc = torch.zeros((), dtype=torch.float32, device='cuda')
+            for _ in range(4):
+                eng.train_epoch([0], acc)
+            torch.cuda.synchronize()
+            return eng.get_params(), float(acc.item())
+        plain = make()
+        ref = train(plain)
+        plain.close()
+        # (a) a communicator that had come up is withdrawn: the steps after run WITHOUT a collective, bit for bit the plain steps
+        a = make()
+        a.comm_init(0, 1, a.comm_unique_id())
+        assert a.comm_size() == (1, 0)
+        # a step whose gradient fails on this rank (batch never registered) returns BEFORE the collective and leaves the
+        # optimizer state as it found it (include/varnet_hip.h, "Failure under a communicator")
+        step0 = a.step
+        a.profile_begin()
+        with pytest.raises(VNError):
+            a.train_step(7, None)
+        with pytest.raises(VNError):
+            a.train_epoch([0, 7])                    # fails at its SECOND step: the first one counted
+        assert a.step == step0 + 1 and a.profile_comm()[1] == 1
+        a.init_params(seed=3)                        # back to the plain engine's start (parameters, Adam slots, step 0)
+        assert a.step == 0
+        assert a.lib.vn_comm_abandon(a.h) == 0 and a.lib.vn_comm_abandon(a.h) == 0        # idempotent
+        a.profile_begin()
+        got = train(a)
+        assert a.profile_comm()[1] == 0, 'a collective was enqueued on an abandoned communicator'
+        np.testing.assert_array_equal(got[0], ref[0])
+        with pytest.raises(VNError, match='abandoned'):
+            a.comm_init(0, 1, a.comm_unique_id())
+        with pytest.raises(VNError, match='no communicator'):
+            a.allreduce_grad()
+        # (b) vn_comm_init that returns AFTER the abandonment (the helper thread of a bootstrap that timed out) commits nothing
+        b = make()
+        uid = b.comm_unique_id()
+        assert b.lib.vn_comm_abandon(b.h) == 0
+        with pytest.raises(VNError, match='abandoned'):
+            b.comm_init(0, 1, uid)
+        assert b.comm_size() == (1, 0)
+        b.profile_begin()
+        got = train(b)
+        assert b.profile_comm()[1] == 0
+        np.testing.assert_array_equal(got[0], ref[0])
+        # (handles of abandoned engines are left to the process exit, as VNEngine.close does after comm_abandon)
+        q.put((0, 'ok'))
+    except Exception:
+        import traceback
+        q.put((1, traceback.format_exc()))
+
+
+def test_abandoned_communicator_is_never_used_by_the_engine():
+    """after the bootstrap gives up on ncclCommInitRank, the engine itself must ignore the communicator --
+    vn_train_step / vn_train_epoch key on it -- whether it had come up or comes up later on the helper thread."""
+    if conftest.FORKSERVER is None:
+        pytest.skip('no fork server')
+    from varnet_amd.engine import VNEngine
+    if not VNEngine.comm_available():
+        pytest.skip('RCCL cannot be loaded on this box')
+    q = conftest.FORKSERVER.Queue()
+    p = conftest.FORKSERVER.Process(target=_abandon_world1, args=(q,))
+    p.start()
+    rc, text = q.get(timeout=300)
+    p.join(60)
+    assert rc == 0, text
+
+
 def test_two_ranks_dedup_matches_one_rank_gloo(tmp_path):
     """train(dedup=True) under towers: every rank de-duplicates its own contiguous block of test functions (points on the
     seam between the blocks are evaluated once per rank), the gradient SUM is unchanged -- world 2 reproduces the one-rank

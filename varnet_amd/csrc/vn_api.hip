@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -125,6 +126,11 @@ struct vn_engine {
   // tower gradient SUM over RCCL (vn_comm_init); nullptr = single process or host-side collective
   ncclComm_t comm = nullptr;
   int comm_world = 1, comm_rank = 0;
+  // ncclCommInitRank has no timeout: a caller may run vn_comm_init on a helper thread and give up on it (vn_comm_abandon).
+  // `comm` is committed / withdrawn under this mutex only, so the thread that trains never sees a communicator appear late.
+  std::mutex comm_mu;
+  bool comm_abandoned = false;
+  ncclComm_t comm_orphan = nullptr;     // a communicator that came up after (or was up at) abandonment: never used, never destroyed
 
   // profiling of the dominant kernel
   bool prof_on = false;
@@ -445,7 +451,7 @@ int load_rccl() {
 extern "C" {
 
 const char* vn_last_error(void) { return g_err.c_str(); }
-int vn_abi_version(void) { return VN_ABI_VERSION; }   // 6: vn_forward_grad; 5: vn_comm_version; 4: vn_comm_available, validated Adam hyper-parameters (3: vn_config.widths[16], VN_KERNEL_LAYERED)
+int vn_abi_version(void) { return VN_ABI_VERSION; }   // 7: vn_comm_abandon; 6: vn_forward_grad; 5: vn_comm_version; 4: vn_comm_available, validated Adam hyper-parameters (3: vn_config.widths[16], VN_KERNEL_LAYERED)
 
 int vn_create(const vn_config* cfg, vn_engine** out) {
   if (!cfg || !out) return fail(VN_EINVAL, "null argument");
@@ -935,16 +941,18 @@ int vn_grad(vn_engine* h, int32_t batch) {
 static int apply_impl(vn_engine* h, float* loss_acc) {
   (void)hipGetLastError();   // a stale last-error of another library on this thread is not ours to report
   HIPCHK(hipSetDevice(h->cfg.device));
-  h->step += 1;
+  // the step counter moves only when the update was launched (a failed call leaves the optimizer state as it found it)
   if (h->cfg.optimizer == VN_OPT_RMSPROP) {
     HIPCHK(vn_rmsprop_launch(h->theta, h->m, h->v, h->gradbuf, h->net.P, (float)h->cfg.lr, 0.9f, 0.0f, 1e-10f, loss_acc,
                              h->stream));
+    h->step += 1;
     return VN_OK;
   }
-  const double t = (double)h->step;
+  const double t = (double)(h->step + 1);
   const double lr_t = h->cfg.lr * std::sqrt(1.0 - std::pow(h->cfg.beta2, t)) / (1.0 - std::pow(h->cfg.beta1, t));
   HIPCHK(vn_adam_launch(h->theta, h->m, h->v, h->gradbuf, h->net.P, (float)lr_t, (float)h->cfg.beta1,
                         (float)h->cfg.beta2, (float)h->cfg.eps, loss_acc, h->stream));
+  h->step += 1;
   return VN_OK;
 }
 
@@ -956,7 +964,11 @@ int vn_apply(vn_engine* h) {
 // gradient + optimizer step with the update folded into the gradient reduction (no collective in between)
 static int step_fused(vn_engine* h, int32_t batch, float* loss_acc) {
   if (h->comm) {
-    // towers: gradient -> SUM over ranks -> update, all on the engine stream, no host round trip
+    // towers: gradient -> SUM over ranks -> update, all on the engine stream, no host round trip.
+    // One-rank failure (include/varnet_hip.h, "Failure under a communicator"): this rank returns its error WITHOUT entering
+    // the collective and with its optimizer state untouched; its peers' ncclAllReduce for this step never completes, so the
+    // caller must end the job -- varnet_amd/launch.py ends the peers of a rank that exits non-zero by PID, within its poll
+    // interval, and reports the failing rank's last stage (VNEngine._ck leaves `engine_error: ...` there).
     if (int rc = vn_grad(h, batch)) return rc;
     if (int rc = vn_allreduce_grad(h)) return rc;
     return apply_impl(h, loss_acc);
@@ -1124,7 +1136,11 @@ int vn_comm_unique_id(void* id_out) {
 int vn_comm_init(vn_engine* h, int32_t rank, int32_t world, const void* unique_id) {
   if (!h || !unique_id) return fail(VN_EINVAL, "null argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(VN_EINVAL, "need 0 <= rank < world (got %d of %d)", rank, world);
-  if (h->comm) return fail(VN_ESTATE, "communicator already initialised (call vn_comm_destroy first)");
+  {
+    std::lock_guard<std::mutex> lk(h->comm_mu);
+    if (h->comm_abandoned) return fail(VN_ESTATE, "this engine's communicator was abandoned (vn_comm_abandon): it takes no other");
+    if (h->comm) return fail(VN_ESTATE, "communicator already initialised (call vn_comm_destroy first)");
+  }
   if (int rc = load_rccl()) return rc;
   HIPCHK(hipSetDevice(h->cfg.device));
   ncclUniqueId id;
@@ -1134,7 +1150,20 @@ int vn_comm_init(vn_engine* h, int32_t rank, int32_t world, const void* unique_i
   int cnt = 0;
   RCCLCHK(g_rccl.CommCount(c, &cnt));
   if (cnt != world) { (void)g_rccl.CommDestroy(c); return fail(VN_ECOMM, "RCCL reports %d ranks, expected %d", cnt, world); }
+  std::lock_guard<std::mutex> lk(h->comm_mu);
+  if (h->comm_abandoned) {       // the caller gave up on this call while it sat in ncclCommInitRank: the engine must not start using it
+    h->comm_orphan = c;
+    return fail(VN_ESTATE, "ncclCommInitRank returned after the communicator was abandoned (vn_comm_abandon)");
+  }
   h->comm = c; h->comm_world = world; h->comm_rank = rank;
+  return VN_OK;
+}
+
+int vn_comm_abandon(vn_engine* h) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  std::lock_guard<std::mutex> lk(h->comm_mu);
+  h->comm_abandoned = true;
+  if (h->comm) { h->comm_orphan = h->comm; h->comm = nullptr; h->comm_world = 1; h->comm_rank = 0; }
   return VN_OK;
 }
 

@@ -21,7 +21,7 @@ VN_MAX_DIN = 32
 VN_KMAX_LAYERS, VN_KMAX_WIDTH, VN_KMAX_DIN = 6, 64, 8
 VN_KERNEL_AUTO, VN_KERNEL_GENERIC, VN_KERNEL_FUSED, VN_KERNEL_FUSED16, VN_KERNEL_LAYERED = 0, 1, 2, 3, 4
 VN_COMM_ID_BYTES = 128
-VN_ABI_VERSION = 6          # include/varnet_hip.h: load_library refuses a library that reports another number
+VN_ABI_VERSION = 7          # include/varnet_hip.h: load_library refuses a library that reports another number
 
 
 class VnConfig(C.Structure):
@@ -74,6 +74,7 @@ _SIGS = {
     'vn_comm_init': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'vn_comm_size': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'vn_comm_destroy': (C.c_int, [C.c_void_p]),
+    'vn_comm_abandon': (C.c_int, [C.c_void_p]),
     'vn_allreduce_grad': (C.c_int, [C.c_void_p]),
     'vn_get_step': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     'vn_profile_comm': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -123,6 +124,46 @@ def _ptr(t):
     if isinstance(t, np.ndarray):
         return t.ctypes.data
     return t.data_ptr()
+
+
+_exit_guard = {'armed': False, 'code': 0, 'threads': []}
+
+
+def _exit_without_waiting(pending=None):
+    """After an abandoned communicator a helper thread may sit inside ncclCommInitRank for ever, and RCCL's own exit handlers
+    can wait for it.  Arm, once per process, an `atexit` hook that flushes the standard streams and leaves through
+    `os._exit` with the status the interpreter was going to return (1 after an uncaught exception, the argument of
+    `sys.exit`); registered last, so it runs FIRST and nothing of the normal teardown touches the wedged library.  The
+    process is never re-executed.  Only when a `pending` helper thread is in fact still alive at exit: otherwise the
+    interpreter leaves the normal way."""
+    if pending is not None:
+        _exit_guard['threads'].append(pending)
+    if _exit_guard['armed']:
+        return
+    _exit_guard['armed'] = True
+    import atexit
+    import sys
+    old_hook, old_exit = sys.excepthook, sys.exit
+
+    def hook(tp, val, tb):
+        _exit_guard['code'] = 1
+        old_hook(tp, val, tb)
+
+    def exit_(code=0):
+        _exit_guard['code'] = code if isinstance(code, int) else (0 if code is None else 1)
+        old_exit(code)
+
+    def leave():
+        if not any(t.is_alive() for t in _exit_guard['threads']):
+            return
+        for f in (sys.stdout, sys.stderr):
+            try:
+                f.flush()
+            except Exception:                        # noqa: BLE001
+                pass
+        os._exit(_exit_guard['code'])
+    sys.excepthook, sys.exit = hook, exit_
+    atexit.register(leave)
 
 
 class VNEngine:
@@ -194,7 +235,12 @@ class VNEngine:
     # -- plumbing ------------------------------------------------------------------------
     def _ck(self, rc):
         if rc != 0:
-            raise VNError('varnet_hip error %d: %s' % (rc, self.lib.vn_last_error().decode()))
+            msg = 'varnet_hip error %d: %s' % (rc, self.lib.vn_last_error().decode())
+            # under a launcher the failing rank's breadcrumb says what failed (launch.spawn_ranks reports it when it ends
+            # the peers this rank left in a collective: include/varnet_hip.h, "Failure under a communicator")
+            from .launch import mark_stage
+            mark_stage('engine_error: ' + msg[:160].replace('\n', ' '))
+            raise VNError(msg)
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -492,7 +538,15 @@ class VNEngine:
         What is NOT covered: a rank that DIES between 3 and 4 leaves its peers' helper threads in RCCL's bootstrap (they fall
         back after the timeout, then fail in torch's own collective); the launcher (varnet_amd/launch.py: deadline + stage
         breadcrumbs, towers.py) ends the peers of a dead rank and says where every rank last was.
-        Returns (True, '') when the communicator is up on every rank, (False, reason) when all ranks skipped it."""
+        Returns (True, '') when the communicator is up on every rank, (False, reason) when all ranks skipped it.  Leaves the
+        breadcrumb `comm_done` (past the launcher's bootstrap deadline, varnet_amd/launch.py) whatever the outcome."""
+        from .launch import mark_stage
+        try:
+            return VNEngine._comm_bootstrap(self, dist)     # (unbound: tests drive this with a scripted stand-in engine)
+        finally:
+            mark_stage('comm_done')
+
+    def _comm_bootstrap(self, dist):
         from .launch import mark_stage
         rank, world = dist.get_rank(), dist.get_world_size()
         t = self.torch
@@ -553,7 +607,7 @@ class VNEngine:
                 box['ok'] = True
             except Exception as e:                   # noqa: BLE001
                 box['err'] = str(e)
-        up, why, late = True, '', False
+        up, why, late, th = True, '', False, None
         if limit > 0:
             th = threading.Thread(target=_join, daemon=True)
             th.start()
@@ -570,7 +624,9 @@ class VNEngine:
         if int(flags[0].item()) == 1:
             return True, ''
         if int(flags[1].item()) == 0:
-            self._comm_abandoned = True              # a peer (or this rank) is still inside the bootstrap: touch nothing
+            # a peer (or this rank) is still inside the bootstrap: withdraw the communicator inside the engine, so that no
+            # vn_train_* ever enqueues a collective on it -- also when this rank's helper thread returns later
+            self.comm_abandon(th)
             return False, why or 'ncclCommInitRank did not return on another rank: communicator abandoned'
         if up:
             self.comm_destroy()
@@ -583,6 +639,14 @@ class VNEngine:
 
     def comm_destroy(self):
         self._ck(self.lib.vn_comm_destroy(self.h))
+
+    def comm_abandon(self, pending=None):
+        """Give up on a communicator whose bootstrap did not finish on every rank (vn_comm_abandon): the engine stops
+        using it and never destroys it; `close()` leaves the handle to the process exit, and the interpreter's exit
+        no longer waits for a helper thread inside ncclCommInitRank (`_exit_without_waiting`)."""
+        self._ck(self.lib.vn_comm_abandon(self.h))
+        self._comm_abandoned = True
+        _exit_without_waiting(pending)               # `pending`: the helper thread that may still sit in ncclCommInitRank
 
     def allreduce_grad(self):
         self._ck(self.lib.vn_allreduce_grad(self.h))

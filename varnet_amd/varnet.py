@@ -529,9 +529,9 @@ class ManageTrainData:
         self.dedup_on, self.dedup_reason = False, None
         self._register()
 
-    def block(self, bi):
-        """[n0,n1) test-function range of this rank's tower in mini-batch bi."""
-        j = bi * self.puNum + self.vn.rank
+    def block(self, bi, tower=None):
+        """[n0,n1) test-function range of a tower (default: this rank's) in mini-batch bi."""
+        j = bi * self.puNum + (self.vn.rank if tower is None else tower)
         n0 = min(j * self.batchLen, self.nt)
         return n0, min(n0 + self.batchLen, self.nt)
 
@@ -833,6 +833,8 @@ class VarNet:
         fd = self.fixData
         self.engine.set_fe_table(fd.N, fd.dNt, None if fd.integW is None else fd.integW)
         self.tfData = self.engine       # name kept for scripts that poke at `VarNet.tfData`
+        from .launch import mark_stage
+        mark_stage('engine_ready')      # past the launcher's bootstrap deadline: a rank that trains for hours is healthy
 
     # -- engine ----------------------------------------------------------------------------
     def _make_engine(self, processors):
@@ -1169,6 +1171,27 @@ class VarNet:
         if self.dist is not None and self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
+    def _gather_lossVec(self, lv, tData, bi):
+        """Loss field of mini-batch `bi` as the reference's controller sees it: the towers' fields concatenated in
+        tower order (`tf.concat([compTowers[pu].lossVec ...], axis=0)`, TFModel.py:319), one entry per test function
+        of the blocks `ManageTrainData.block(bi, pu)`.  One all-gather of `batchLen` floats per rank (ragged and empty
+        last blocks are padded for the collective and cut afterwards); every rank returns the same column."""
+        torch = self.engine.torch
+        if self.world == 1 or self.dist is None:
+            return lv.cpu().numpy().reshape(-1, 1)
+        L = int(tData.batchLen)
+        # gloo gathers host tensors only; RCCL gathers where the field lies
+        dev = lv.device if self.dist.get_backend() == 'nccl' else torch.device('cpu')
+        mine = torch.zeros(L, dtype=lv.dtype, device=dev)
+        mine[:lv.numel()] = lv.reshape(-1).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        cols = []
+        for pu in range(self.world):
+            n0, n1 = tData.block(bi, pu)
+            cols.append(parts[pu][:n1 - n0])
+        return torch.cat(cols).cpu().numpy().reshape(-1, 1)
+
     def splitLoss(self, tData, W=None):
         """BC, IC and variational loss summed over MOR batches (VarNet.py:1053-1090)."""
         if W is None:
@@ -1182,11 +1205,11 @@ class VarNet:
             var = 0.0
             lv_b = []
             for bi in range(tData.batchNum):
-                out, lv = eng.eval_loss(tData.engine_batch(mb, bi), lossVec=fd.lossVecflag and self.world == 1)
+                out, lv = eng.eval_loss(tData.engine_batch(mb, bi), lossVec=fd.lossVecflag)
                 bc, ic = out[1], out[2]
                 var += out[3]
                 if lv is not None:
-                    lv_b.append(lv.cpu().numpy().reshape(-1, 1))
+                    lv_b.append(self._gather_lossVec(lv, tData, bi))
             if self.world > 1:
                 t = torch.tensor([var], dtype=torch.float64, device=eng.device)
                 self._allreduce(t)
