@@ -470,7 +470,42 @@ def inference_line(vn, tdata, eng, F_pt):
     tf = t(lambda: eng._ck(eng.lib.vn_forward(eng.h, _ptr(X), n, _ptr(u))))
     tr = t(lambda: eng._ck(eng.lib.vn_residual(eng.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, m, _ptr(u), _ptr(r))))
     nd = 3 * dim + 2
-    return {"forward": {"points": n, "ms": tf * 1e3, "points_per_s": n / tf, "tflops_of_F_pt": F_pt * n / tf / 1e12,
+    # the fp64 checking path (BASELINE config 5's fp64 residual check runs these entry points): vn_taylor16d on the fp64 matrix pipe.
+    # Kernel time from events on the engine's stream (= torch's current stream, VNEngine.use_current_stream); priced against the
+    # fp64 MFMA rate THIS box sustains (vn_debug_calibrate_f64: the guide quotes no fp64 matrix peak), FLOPs stated both ways.
+    X64, diff64, vel64 = X[:m].double(), diff.double(), vel.double()
+    u64 = torch.empty(m, device='cuda', dtype=torch.float64); r64 = torch.empty(m, device='cuda', dtype=torch.float64)
+
+    def tev(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    tf64 = tev(lambda: eng._ck(eng.lib.vn_forward_f64(eng.h, _ptr(X64), m, _ptr(u64))))
+    tr64 = tev(lambda: eng._ck(eng.lib.vn_residual_f64(eng.h, _ptr(X64), _ptr(diff64), _ptr(vel64), None, None, m, _ptr(u64), _ptr(r64))))
+    cal64 = eng.calibrate_f64(eng.calibrate()["clock_ghz_implied_by_the_mfma_loop"])
+    pk64 = cal64["mfma_f64_tflops"]
+    W = list(vn.layerWidth)
+    ks, mt = -(-max(W) // 4), -(-max(W) // 16)
+    # matrix-pipe FLOPs vn_taylor16d issues per point and stream: every layer padded to 4*ks inputs x 16*mt outputs (no padding branches)
+    Fx_pt = 2.0 * 16 * mt * (4 * (-(-vn.inpDim // 4)) + (len(W) - 1) * 4 * ks)
+    on_pipe = max(W) <= 64 and len(W) <= 8
+    f64 = {"peak_measured_tflops": pk64, "calibration": cal64,
+           "forward_f64": {"points": m, "kernel_ms": tf64 * 1e3, "points_per_s": m / tf64, "flop_algorithmic": F_pt * m,
+                           "flop_issued_on_the_matrix_pipe": Fx_pt * m, "tflops_algorithmic": F_pt * m / tf64 / 1e12,
+                           "frac_of_peak_measured": F_pt * m / tf64 / 1e12 / pk64,
+                           "frac_of_peak_measured_issued": Fx_pt * m / tf64 / 1e12 / pk64},
+           "residual_f64": {"points": m, "kernel_ms": tr64 * 1e3, "points_per_s": m / tr64, "flop_algorithmic": nd * F_pt * m,
+                            "flop_issued_on_the_matrix_pipe": nd * Fx_pt * m, "tflops_algorithmic": nd * F_pt * m / tr64 / 1e12,
+                            "frac_of_peak_measured": nd * F_pt * m / tr64 / 1e12 / pk64,
+                            "frac_of_peak_measured_issued": nd * Fx_pt * m / tr64 / 1e12 / pk64},
+           "kernel": "vn_taylor16d_kernel (v_mfma_f64_16x16x4_f64; libm exp / tanh, true division)" if on_pipe else "per-thread kernels",
+           "note": "peak = what a loop of independent v_mfma_f64_16x16x4_f64 sustains on this box in this process (two waves per SIMD); "
+                   "(3 dim + 2) F_pt per residual point as in fp32; `issued` counts the padded 16-row tiles the kernel really runs"}
+    return {"fp64": f64, "forward": {"points": n, "ms": tf * 1e3, "points_per_s": n / tf, "tflops_of_F_pt": F_pt * n / tf / 1e12,
                         "frac_of_peak": F_pt * n / tf / 1e12 / PEAK_FP32_MFMA_TFLOPS, "kernel": "vn_pgrad16_kernel (value-only sweep)"},
             "residual": {"points": m, "ms": tr * 1e3, "points_per_s": m / tr, "tflops_executed": nd * F_pt * m / tr / 1e12,
                          "frac_of_peak": nd * F_pt * m / tr / 1e12 / PEAK_FP32_MFMA_TFLOPS,

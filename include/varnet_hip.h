@@ -98,7 +98,8 @@ int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_ker
                                 * 3: vn_config.widths holds VN_MAX_LAYERS = 16 entries, layer_act, VN_KERNEL_LAYERED;
                                 * 4: vn_comm_available, Adam hyper-parameters validated (no silent NaN from a zeroed config);
                                 * 5: vn_comm_version;
-                                * 6: vn_forward_grad, vn_debug_calibrate */
+                                * 6: vn_forward_grad, vn_debug_calibrate
+                                * 7: vn_comm_abandon, vn_debug_point_route, vn_debug_calibrate_f64 */
 #define VN_ABI_VERSION 7     /* what this header describes: a binding must refuse a library that reports another number */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
@@ -272,6 +273,18 @@ int vn_profile_end(vn_engine* h, double* mean_ms, int64_t* launches, char* name,
  * out[2] cycles per independent v_fma_f32 per SIMD (at the clock out[3]), out[3] GHz implied by 32 cycles per MFMA,
  * out[4] ms of the vector launch. */
 int vn_debug_calibrate(vn_engine* h, double out[5]);
+
+/* The same for the fp64 matrix pipe (vn_forward_f64 / vn_residual_f64 run on v_mfma_f64_16x16x4_f64): out[0] fp64 MFMA
+ * TFLOP/s of a loop of independent MFMAs, out[1] ms of that launch, out[2] cycles one MFMA occupies a SIMD at the clock
+ * `ghz` (vn_debug_calibrate's out[3]; 0 = not asked). */
+int vn_debug_calibrate_f64(vn_engine* h, double ghz, double out[3]);
+
+/* Test aid: route = 1 sends vn_residual, vn_residual_f64 and vn_forward_f64 of THIS engine to the per-thread kernels of
+ * vn_pointwise.hip (the independent implementation the matrix-pipe kernels are checked against); route = 2 keeps vn_forward and
+ * vn_residual on the f32-MFMA kernels (vn_pgrad16 / vn_taylor16) where the bf16-piece kernels of vn_split16.hip would run
+ * (A/B and cross-check of the two matrix-pipe forms); 0 restores the automatic choice.  (Round 5: an environment variable
+ * read on every call.) */
+int vn_debug_point_route(vn_engine* h, int32_t route);
 
 /* Diagnostic builds (-DVN_STAMPS) only: per-phase s_memtime cycle sums of workgroup 0 of the last
  * fused launch (zeros otherwise).  Never part of a timed or shipped build. */

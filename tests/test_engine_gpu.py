@@ -507,6 +507,8 @@ def test_dedup_formulation_parity(case):
     (4, 3, [33, 50, 41, 17, 50, 50, 50, 50], 'sigmoid', 300),   # <8,13>: most stored activations
     (2, 1, [64, 51, 64, 60, 55, 64], 'sigmoid', 97),            # <6,16>
     (3, 2, [7, 5], 'tanh', 15),                     # fewer points than one wave chunk
+    (3, 2, [50, 44, 33, 50, 36, 50, 50], 'tanh', 1031),         # <7,13>: the deepest net of the bf16-piece kernel (vn_forward)
+    (4, 3, [40, 52], 'sigmoid', 64),                # <2,16>: its shallowest
 ])
 def test_forward_grad_parity(d_in, dim, widths, act, n):
     """vn_forward_grad (vn_pgrad16.hip: value forward + value-adjoint sweep to the inputs, the reference's
@@ -530,9 +532,20 @@ def test_forward_grad_parity(d_in, dim, widths, act, n):
     uref, gref = Val.detach().numpy().reshape(-1), dM_dx.detach().numpy()
     eu = np.max(np.abs(u.cpu().numpy() - uref)) / np.max(np.abs(uref))
     eg = np.max(np.abs(g.cpu().numpy() - gref)) / np.max(np.abs(gref))
-    ERRORS['forward_grad %s %s' % (widths, act)] = {'u': float(eu), 'grad': float(eg)}
+    # vn_forward: hidden widths 33..64 run the bf16-piece kernel (vn_split16.hip: six products of exact bf16 pieces per layer), the
+    # others the value-only sweep of vn_pgrad16; route 2 forces the latter -- both against the oracle at the SAME bar, errors side by side
+    eng.debug_point_route(2)
+    u2f = eng.forward(X)
+    torch.cuda.synchronize()
+    eng.debug_point_route(0)
+    ef = np.max(np.abs(u2.cpu().numpy() - uref)) / np.max(np.abs(uref))
+    ef32 = np.max(np.abs(u2f.cpu().numpy() - uref)) / np.max(np.abs(uref))
+    ERRORS['forward_grad %s %s' % (widths, act)] = {'u': float(eu), 'grad': float(eg), 'vn_forward': float(ef),
+                                                    'vn_forward_f32_mfma_kernel': float(ef32)}
     assert eu <= 2e-6 and eg <= 1e-5, (eu, eg)
+    assert ef <= 2e-6 and ef32 <= 2e-6, (ef, ef32)
     assert np.max(np.abs(u.cpu().numpy() - u2.cpu().numpy())) <= 2e-6 * np.max(np.abs(uref))      # vn_forward: the same values
+    assert torch.equal(eng.forward(X), u2)                                                       # repeatable bit for bit
     u3, g3 = eng.forward_grad(X)
     torch.cuda.synchronize()
     assert torch.equal(u, u3) and torch.equal(g, g3)
@@ -548,10 +561,13 @@ def test_forward_grad_parity(d_in, dim, widths, act, n):
     (3, 2, [50], 'sigmoid', 130, False, False),                   # one hidden layer
     (4, 3, [33, 50, 41, 17, 50, 50, 50, 50], 'sigmoid', 300, True, True),    # <8,13>
     (3, 2, [7, 5], 'tanh', 15, True, True),                       # fewer points than one wave chunk
+    (3, 2, [50, 44, 33, 50, 36, 50, 50], 'sigmoid', 1031, True, True),       # <7,13>: the deepest net of the bf16-piece kernel
+    (2, 1, [64, 51, 64, 60, 55, 64], 'tanh', 97, False, True),               # <6,16> on the bf16-piece kernel, 1D+t
+    (4, 3, [40, 52], 'sigmoid', 64, True, False),                 # <2,16>
 ])
 def test_taylor_residual_parity(d_in, dim, widths, act, n, with_src, with_ddx, monkeypatch):
-    """vn_residual of the 8-wave family (vn_taylor16.hip: second-order forward mode on the matrix pipe, one pass per coordinate
-    direction) against the fp64 oracle's residual (TFModel.py:743-754 restated) and against the per-point kernel it replaces."""
+    """vn_residual of the 8-wave family (vn_taylor16.hip / vn_split16.hip: second-order forward mode on the matrix pipe, one pass per
+    coordinate direction) against the fp64 oracle's residual (TFModel.py:743-754 restated) and against the per-point kernel it replaces."""
     from varnet_amd.engine import VNEngine
     rng = np.random.default_rng(17)
     X = rng.uniform(-1.2, 1.2, (n, d_in))
@@ -571,12 +587,22 @@ def test_taylor_residual_parity(d_in, dim, widths, act, n, with_src, with_ddx, m
     scale = max(1.0, float(np.max(np.abs(rref))))
     er = float(np.max(np.abs(r.cpu().numpy() - rref[:, 0]))) / scale
     eu = float(np.max(np.abs(u.cpu().numpy() - uref[:, 0]))) / max(1.0, float(np.max(np.abs(uref))))
-    monkeypatch.setenv('VN_RESIDUAL_POINTWISE', '1')              # the per-point kernel, same inputs
+    eng.debug_point_route(True)              # the per-point kernel, same inputs
     u_p, r_p = eng.residual(X32, diff, vel, src, ddx, fp64=False)
     torch.cuda.synchronize()
-    monkeypatch.delenv('VN_RESIDUAL_POINTWISE')
+    eng.debug_point_route(False)
     ep = float(np.max(np.abs(r_p.cpu().numpy() - rref[:, 0]))) / scale
-    ERRORS['taylor_residual %s %s' % (widths, act)] = {'res': er, 'u': eu, 'res_pointwise_kernel': ep}
+    # hidden widths 33..64 (2..7 layers) run the bf16-piece kernel (vn_split16.hip); route 2 = the f32-MFMA kernel vn_taylor16 on the
+    # same inputs: same bar, both errors recorded side by side (the bar must not move)
+    eng.debug_point_route(2)
+    u_f, r_f = eng.residual(X32, diff, vel, src, ddx, fp64=False)
+    torch.cuda.synchronize()
+    eng.debug_point_route(0)
+    er32 = float(np.max(np.abs(r_f.cpu().numpy() - rref[:, 0]))) / scale
+    eu32 = float(np.max(np.abs(u_f.cpu().numpy() - uref[:, 0]))) / max(1.0, float(np.max(np.abs(uref))))
+    ERRORS['taylor_residual %s %s' % (widths, act)] = {'res': er, 'u': eu, 'res_pointwise_kernel': ep, 'res_f32_mfma_kernel': er32,
+                                                      'u_f32_mfma_kernel': eu32}
+    assert er32 <= 5e-5 and eu32 <= 2e-6, (er32, eu32)
     assert er <= 5e-5 and eu <= 2e-6, (er, eu, ep)                # the bar of test_forward_and_residual_parity
     assert float(np.max(np.abs(r.cpu().numpy() - r_p.cpu().numpy()))) / scale <= 5e-5
     u2, r2 = eng.residual(X32, diff, vel, src, ddx, fp64=False)

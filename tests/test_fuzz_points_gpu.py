@@ -54,9 +54,9 @@ def test_point_kernels_against_the_oracle(seed, monkeypatch):
         u, g = eng.forward_grad(X32)
         uf = eng.forward(X32)
         _, r = eng.residual(X32, diff, vel, src, ddx, fp64=False)
-        monkeypatch.setenv('VN_RESIDUAL_POINTWISE', '1')
+        eng.debug_point_route(True)
         _, rp = eng.residual(X32, diff, vel, src, ddx, fp64=False)
-        monkeypatch.delenv('VN_RESIDUAL_POINTWISE')
+        eng.debug_point_route(False)
         # fp64 entry points (the fp64 matrix pipe, vn_taylor16d.hip, where the double-precision images fit the LDS; else per thread)
         u64 = eng.forward_f64(X)
         u64r, r64 = eng.residual(X, diff, vel, src, ddx, fp64=True)

@@ -78,16 +78,32 @@ elif case == 'cfg1':
     width = eval(sys.argv[4]) if len(sys.argv) > 4 else [20, 20, 20]
     pde = ADPDE(Domain1D(), diff=0.1 / pi, vel=1.0, timeDependent=True, tInterval=[0, 2.0], IC=lambda x: -np.sin(pi * x), cEx=cExact)
     vn = VarNet(pde, layerWidth=width, discNum=20, bDiscNum=None, tDiscNum=300)
-    sf = 10000
+    # round 6: saveFreq is an argument -- the script trains with train()'s DEFAULTS (Operator_1Dt.py:170: saveFreq=100,
+    # trainUpdelay=2e4, tolUpd=0.01, VarNet.py:1198-1200), and the convergence test that re-draws the training set
+    # (VarNet.py:1385-1421) looks at the last five losses SAMPLED EVERY saveFreq EPOCHS: at saveFreq=10000 it never fires
+    sf = int(sys.argv[5]) if len(sys.argv) > 5 else 10000
+    every = max(1, 10000 // sf)
     t0 = time.time()
+    seen = [0]
 
     def mon(i):
-        say('epoch %7d  %6.0f s  l2Err(fixData.cEx, evaluate()) %.5f' % (i * sf, time.time() - t0, uf.l2Err(vn.fixData.cEx, vn.evaluate())))
+        tr = getattr(vn, 'trainRes', None)
+        n_upd = len(tr.inpIter) if tr is not None else 0
+        if n_upd != seen[0]:
+            seen[0] = n_upd
+            say('   training set re-drawn at epochs %s (rows now %d)' % (list(tr.inpIter), vn.tData.mor[0]['Input'].shape[0]))
+        if i % every == 0:
+            say('epoch %7d  %6.0f s  l2Err(fixData.cEx, evaluate()) %.5f' % (i * sf, time.time() - t0, uf.l2Err(vn.fixData.cEx, vn.evaluate())))
     hook(vn, mon)
     np.random.seed(0)
+    kw = {}
+    if len(sys.argv) > 6:
+        kw['trainUpdelay'] = float(sys.argv[6])
+    if len(sys.argv) > 7:
+        kw['tolUpd'] = float(sys.argv[7])
     with tempfile.TemporaryDirectory() as tmp:
         res = vn.train(tmp, weight=[10., 10., 1.], smpScheme=scheme, adjustWeight=True, epochNum=epochs, saveFreq=sf, verbose=False,
-                       lossLag=32)
+                       lossLag=32, **kw)
     say('done %s %s: %d epochs in %.0f s, loss %.4e -> %.4e, training sets %s' % (scheme, width, len(res.lossAll), time.time() - t0,
                                                                                res.lossAll[0], res.lossAll[-1], res.inpIter))
 

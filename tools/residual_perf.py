@@ -25,6 +25,18 @@ u32, r32 = torch.empty(n, device='cuda'), torch.empty(n, device='cuda')
 X64, diff64, vel64 = X.double(), diff.double(), vel.double()
 u64, r64 = torch.empty(n, device='cuda', dtype=torch.float64), torch.empty(n, device='cuda', dtype=torch.float64)
 a = t(lambda: e._ck(e.lib.vn_residual(e.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, n, _ptr(u32), _ptr(r32))))
+# round 6: hidden widths 33..64 run the bf16-piece kernels (vn_split16.hip); route 2 = the f32-MFMA kernels on the same inputs
+r_split, u_split = r32.clone(), u32.clone()
+e.debug_point_route(2)
+a32 = t(lambda: e._ck(e.lib.vn_residual(e.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, n, _ptr(u32), _ptr(r32))))
+d32 = t(lambda: e.forward(X))
+uf32 = e.forward(X)
+e.debug_point_route(0)
+uf = e.forward(X)
+torch.cuda.synchronize()
+print('bf16-piece kernels against the f32-MFMA kernels on the same inputs: residual max |diff| / max |res| %.2e, forward %.2e'
+      % (float((r_split - r32).abs().max() / r32.abs().max()), float((uf - uf32).abs().max() / uf32.abs().max())))
+print('vn_residual      fp32, f32-MFMA kernel (vn_taylor16) %8.3f ms   vn_forward, f32-MFMA kernel (vn_pgrad16 value sweep) %8.3f ms' % (a32 * 1e3, d32 * 1e3))
 b = t(lambda: e._ck(e.lib.vn_residual_f64(e.h, _ptr(X64), _ptr(diff64), _ptr(vel64), None, None, n, _ptr(u64), _ptr(r64))))
 c = t(lambda: e.forward_f64(X64))
 d = t(lambda: e.forward(X))

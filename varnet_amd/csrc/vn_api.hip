@@ -4,6 +4,9 @@
 #include "vn_dedup.h"
 #include "vn_pgrad16.h"
 #include "vn_taylor16.h"
+#include "vn_split16.h"
+
+hipError_t vn_calibrate_f64(int ncu, hipStream_t s, double ghz, double out[3]);      // vn_calib.hip (fp64 MFMA loop)
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen'ed by vn_comm_*, never linked
@@ -74,7 +77,21 @@ struct Batch {
 
 constexpr int PROF_CAP = 4096;
 
+#ifdef VN_WITH_FUSED32
+constexpr bool kWithFused32 = true;
+#else
+constexpr bool kWithFused32 = false;
+#endif
+
 }  // namespace
+
+#ifndef VN_WITH_FUSED32
+// Product build: the 4-wave geometry (vn_fused.hip) is not linked -- it serves no automatic route (every network it takes is
+// one of the 8-wave kernel's).  It lives in the tests' cross-check library (make xcheck: -DVN_WITH_FUSED32 + vn_fused.o).
+bool vn_fused_supported(const VnNet&, int) { return false; }
+hipError_t vn_fused_launch(const VnFusedArgs&, int, hipStream_t) { return hipErrorInvalidValue; }
+#endif
+
 
 struct vn_engine {
   vn_config cfg{};
@@ -121,6 +138,8 @@ struct vn_engine {
   float *dd_uv = nullptr, *dd_ug = nullptr, *dd_su = nullptr, *dd_sg = nullptr, *dd_partial = nullptr,
         *dd_losspart = nullptr;
   long dd_capU = 0, dd_cap_lp = 0;
+  bool point_kernels = false;  // vn_debug_point_route(1): vn_residual / vn_*_f64 on the per-thread kernels (the tests' cross-check)
+  bool no_split = false;       // vn_debug_point_route(2): the f32-MFMA point kernels where the bf16-piece kernels (vn_split16.hip) would run
   int pgrad_wgs = 0;           // workgroups per CU of vn_pgrad16: 0 = what fits, at most 2 (diagnostic override: $VN_PGRAD_WGS = 1..4)
 
   // tower gradient SUM over RCCL (vn_comm_init); nullptr = single process or host-side collective
@@ -538,7 +557,9 @@ int vn_create(const vn_config* cfg, vn_engine** out) {
   }
   if (cfg->kernel == VN_KERNEL_FUSED && !vn_fused_supported(net, cfg->integ_num)) {
     vn_destroy(h);
-    return fail(VN_EUNSUPPORTED, "fused kernel unsupported for this network / integ_num");
+    return fail(VN_EUNSUPPORTED, kWithFused32 ? "fused kernel unsupported for this network / integ_num"
+                                              : "VN_KERNEL_FUSED (the 4-wave geometry) is not part of the product library: it lives in the "
+                                                "tests' cross-check build, libvarnet_hip_xcheck.so (make -C varnet_amd/csrc xcheck)");
   }
   const bool tp_ok = cfg->integ_num > 128 && vn_fused16_net_supported(net);
   if (cfg->kernel == VN_KERNEL_FUSED16 && !vn_fused16_supported(net, cfg->integ_num) && !tp_ok) {
@@ -1031,7 +1052,9 @@ int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
   // networks of the 8-wave family: the value-only sweep of vn_pgrad16 (F_pt per point; the fused kernel's forward-only mode
   // would carry a tangent stream of zeros through every layer)
   if (h->use_fused16 || h->two_pass) {
-    HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, nullptr, nullptr, h->ncu, h->pgrad_wgs, h->stream));
+    // hidden widths 33..64: the products as six bf16-piece MFMAs, fp32-class (vn_split16.hip)
+    if (!h->no_split && vn_split16_supported(h->net, 0)) HIPCHK(vn_split16_forward(h->net, h->theta, X, n, u, h->ncu, h->stream));
+    else HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, nullptr, nullptr, h->ncu, h->pgrad_wgs, h->stream));
     return VN_OK;
   }
   if (h->fused_only) return fused_forward(h, X, nullptr, n, u, nullptr);
@@ -1061,7 +1084,7 @@ int vn_forward_f64(vn_engine* h, const double* X, int64_t n, double* u) {
     return VN_OK;
   }
   // networks of the 8-wave family whose fp64 images fit the LDS: the fp64 matrix pipe (vn_taylor16d.hip); else per thread
-  if ((h->use_fused16 || h->two_pass) && vn_taylor16d_supported(h->net) && !getenv("VN_RESIDUAL_POINTWISE")) {
+  if ((h->use_fused16 || h->two_pass) && vn_taylor16d_supported(h->net) && !h->point_kernels) {
     HIPCHK(vn_taylor16d_launch(h->net, h->theta64, X, nullptr, nullptr, nullptr, nullptr, h->cfg.time_dependent, n, u, nullptr, h->ncu, h->stream));
     return VN_OK;
   }
@@ -1081,8 +1104,11 @@ int vn_residual(vn_engine* h, const float* X, const float* diff, const float* ve
   }
   // networks of the 8-wave family: second-order forward mode on the matrix pipe (vn_taylor16.hip); the per-point kernel keeps
   // the generic / 4-wave requests (and is what the new kernel is cross-checked against)
-  if ((h->use_fused16 || h->two_pass) && !getenv("VN_RESIDUAL_POINTWISE")) {
-    HIPCHK(vn_taylor16_residual(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->ncu, h->stream));
+  if ((h->use_fused16 || h->two_pass) && vn_taylor16_supported(h->net, h->cfg.time_dependent) && !h->point_kernels) {
+    if (!h->no_split && vn_split16_supported(h->net, h->cfg.time_dependent))
+      HIPCHK(vn_split16_residual(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->ncu, h->stream));
+    else
+      HIPCHK(vn_taylor16_residual(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->ncu, h->stream));
     return VN_OK;
   }
   HIPCHK(vn_pointwise_residual_f32(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res,
@@ -1101,7 +1127,7 @@ int vn_residual_f64(vn_engine* h, const double* X, const double* diff, const dou
                                    lerr_, sizeof lerr_));
     return VN_OK;
   }
-  if ((h->use_fused16 || h->two_pass) && vn_taylor16d_supported(h->net) && !getenv("VN_RESIDUAL_POINTWISE")) {
+  if ((h->use_fused16 || h->two_pass) && vn_taylor16d_supported(h->net) && !h->point_kernels) {
     HIPCHK(vn_taylor16d_launch(h->net, h->theta64, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->ncu, h->stream));
     return VN_OK;
   }
@@ -1235,6 +1261,21 @@ int vn_debug_calibrate(vn_engine* h, double out[5]) {
   (void)hipGetLastError();
   HIPCHK(hipSetDevice(h->cfg.device));
   HIPCHK(vn_calibrate(h->ncu, h->stream, out));
+  return VN_OK;
+}
+
+int vn_debug_calibrate_f64(vn_engine* h, double ghz, double out[3]) {
+  if (!h || !out) return fail(VN_EINVAL, "null argument");
+  (void)hipGetLastError();
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(vn_calibrate_f64(h->ncu, h->stream, ghz, out));
+  return VN_OK;
+}
+
+int vn_debug_point_route(vn_engine* h, int32_t per_thread) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  h->point_kernels = per_thread == 1;
+  h->no_split = per_thread == 2;
   return VN_OK;
 }
 

@@ -14,8 +14,24 @@ constexpr int CAL_THREADS = 512;          // 8 waves = 2 per SIMD
 constexpr int CAL_MFMA = 64;              // MFMAs per wave and iteration
 constexpr int CAL_VALU = 128;             // v_fma_f32 per wave and iteration
 
-template <int KIND>                       // 0: MFMA loop, 1: VALU loop
+typedef double f64x4c __attribute__((ext_vector_type(4)));
+
+template <int KIND>                       // 0: fp32 MFMA loop, 1: VALU loop, 2: fp64 MFMA loop
 __global__ __launch_bounds__(CAL_THREADS) void vn_calib_kernel(float* out, int iters) {
+  if (KIND == 2) {
+    // independent v_mfma_f64_16x16x4_f64 chains (the instruction of vn_taylor16d.hip / vn_dgemm_nn), two waves per SIMD
+    f64x4c dacc[4];
+    for (int i = 0; i < 4; ++i) dacc[i] = f64x4c{0., 0., 0., 0.};
+    const double da = threadIdx.x * 1e-3, db = 1.0 + threadIdx.x * 1e-4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < CAL_MFMA; ++i) dacc[i & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, dacc[i & 3], 0, 0, 0);
+    }
+    double ds = 0.;
+    for (int i = 0; i < 4; ++i) ds += dacc[i][0] + dacc[i][1] + dacc[i][2] + dacc[i][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = (float)ds;
+    return;
+  }
   f32x4c acc[4];
   float v[8];
   for (int i = 0; i < 4; ++i) acc[i] = f32x4c{0.f, 0.f, 0.f, 0.f};
@@ -84,5 +100,24 @@ hipError_t vn_calibrate(int ncu, hipStream_t s, double out[5]) {
   out[2] = (ms_v * 1e-3) * ghz * 1e9 / valu_per_simd;
   out[3] = ghz;
   out[4] = ms_v;
+  return hipSuccess;
+}
+
+// out[0] fp64 MFMA TFLOP/s sustained by a loop of independent v_mfma_f64_16x16x4_f64 (2 * 16 * 16 * 4 FLOP each), two waves
+// per SIMD on every SIMD; out[1] ms of the best launch; out[2] cycles one such MFMA occupies a SIMD at `ghz` (the clock the
+// fp32 loop of vn_calibrate implied in the same process; pass 0 to skip)
+hipError_t vn_calibrate_f64(int ncu, hipStream_t s, double ghz, double out[3]) {
+  float* buf = nullptr;
+  hipError_t e = hipMalloc((void**)&buf, (size_t)ncu * CAL_THREADS * sizeof(float));
+  if (e != hipSuccess) return e;
+  const int it_d = 1500;                             // ~5 ms per launch
+  double ms_d = 0.0;
+  e = time_one<2>(buf, ncu, it_d, s, &ms_d);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return e;
+  const double waves = (double)ncu * (CAL_THREADS / 64);
+  out[0] = waves * it_d * CAL_MFMA * 2.0 * 16 * 16 * 4 / (ms_d * 1e-3) / 1e12;
+  out[1] = ms_d;
+  out[2] = ghz > 0 ? (ms_d * 1e-3) * ghz * 1e9 / (2.0 * it_d * CAL_MFMA) : 0.0;
   return hipSuccess;
 }

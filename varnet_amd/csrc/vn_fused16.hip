@@ -132,59 +132,7 @@ struct WG {
   static_assert(NT < NW || NTB % TPW == 0, "a wave's tiles must share a row tile");
 };
 
-#ifdef VN_FIXSTAMPS
-// Diagnostic build only (-DVN_FIXSTAMPS): s_memtime at entry / after the prologue / after the tile loop / after the
-// accumulator flush / at the end, workgroup 0 wave 0 -> A.stamps[0..4] (tools/fixed_cost.py)
-#define FIXSTAMP(i)                                                                  \
-  do {                                                                               \
-    unsigned long long t_;                                                           \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-    if (A.stamps && blockIdx.x == 0 && threadIdx.x == 0) A.stamps[i] = t_;           \
-  } while (0)
-#else
-#define FIXSTAMP(i) do {} while (0)
-#endif
 
-#ifdef VN_STAMPS
-// Diagnostic build only (-DVN_STAMPS=1: phases of the tile loop; =2: inside the cooperative weight
-// gradient: 0 inputs+forward, 1 epilogue, 2 publish, 3 wait at the publish barrier, 4 contraction,
-// 5 wait at the release barrier, 6 backward GEMMs + zbar).
-#define STAMP_RAW(i)                                                      \
-  do {                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-    unsigned long long t_;                                                \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-    stamp_acc[i] += t_ - stamp_prev;                                      \
-    stamp_prev = t_;                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                    \
-  } while (0)
-#if VN_STAMPS == 2
-#define STAMP(i) STAMP_RAW(((i) <= 1 ? 0 : (i) == 2 ? 1 : 6))
-#define WSTAMP(i) STAMP_RAW(i)
-#define ESTAMP(i) do {} while (0)
-#elif VN_STAMPS == 3
-// epilogue detail: 0 inputs+forward, 1 output layer + int1, 2 wait barrier 1, 3 R_k, 4 wait barrier 2,
-// 5 seeds, 6 zbar_L, 7 rest of the reverse pass
-#define STAMP(i) STAMP_RAW(((i) <= 1 ? 0 : (i) == 2 ? 5 : (i) == 3 ? 6 : 7))
-#define WSTAMP(i) do {} while (0)
-#define ESTAMP(i) STAMP_RAW(i)
-#else
-#define STAMP(i) STAMP_RAW(i)
-#define WSTAMP(i) do {} while (0)
-#define ESTAMP(i) do {} while (0)
-#endif
-#ifndef VN_STAMP_WAVE
-#define VN_STAMP_WAVE 0                    // which wave of block 0 reports
-#endif
-#define STAMP_PARAMS , unsigned long long (&stamp_acc)[8], unsigned long long& stamp_prev
-#define STAMP_ARGS , stamp_acc, stamp_prev
-#else
-#define STAMP(i) do {} while (0)
-#define WSTAMP(i) do {} while (0)
-#define ESTAMP(i) do {} while (0)
-#define STAMP_PARAMS
-#define STAMP_ARGS
-#endif
 
 // store of one published value: lane (c, g) owns row vpos(ks,0)+4g, column wave*16+c
 template <int KS>
@@ -203,7 +151,7 @@ __device__ __forceinline__ void t_write(float* T, const LaneC& lc, int ks, float
 // (always, except for a 64-wide input side at KS == 16: then the bias gradient comes from thin_bias below).
 template <int KSA, int KSB, bool RAWA, bool TANH, bool MERGE, int NACC, class AV, class BV>
 __device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const BV& bv, const BV& bt, float* TA,
-                                            float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC], bool ones_row STAMP_PARAMS) {
+                                            float* TB, const LaneC& lc, int wave, f32x4 (&acc)[NACC], bool ones_row) {
   using W = WG<KSA, KSB>;
   static_assert(NACC == W::TPW, "accumulator count");
   const int t0 = (W::NT >= NW) ? wave * W::TPW : wave % W::NT;
@@ -268,14 +216,10 @@ __device__ __forceinline__ void wgrad_layer(const AV& av, const AV& azd, const B
 #pragma unroll
     for (int ks = 0; ks < KSB; ++ks) t_write<KSB>(TBh, lc, ks, (half == 0) ? bv[ks] : bt[ks]);
     if (MERGE && half == 0) continue;
-    WSTAMP(2);
     __syncthreads();
-    WSTAMP(3);
     if (MERGE) contract(TA, TB);
     contract(TAh, TBh);
-    WSTAMP(4);
     __syncthreads();
-    WSTAMP(5);
   }
 }
 
@@ -568,31 +512,17 @@ struct H13Pub {      // unrolled stores with compile-time offsets (inline-asm im
 template <bool TANH>
 __device__ __forceinline__ void h13_wgrad_layer(const PA<13>& av, const PA<13>& azd, const PA<13>& bv,
                                                 const PA<13>& bt, float* TA, const LaneC& lc, int wave, int lane,
-                                                unsigned t_base_bytes, f32x4 (&acc)[2] STAMP_PARAMS) {
+                                                unsigned t_base_bytes, f32x4 (&acc)[2]) {
   const float* TB = TA + H13::TA_ROWS * H13::RS;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    // (-DVN_ABL_NOPUB / -DVN_ABL_NOBAR / -DVN_ABL_NOCONTRACT: diagnostic ablations, results wrong: what the publish
-    // stores, the two workgroup barriers and the contraction of a round cost; profiles/r2_round_ablation.txt)
-#ifndef VN_ABL_NOPUB
     addtid_base(t_base_bytes);
     H13Pub<13, 0, TANH>::run(half, av, azd, bv, bt);
     addtid_store<13 * H13::RS * 4>((half == 0 && lc.g == 0) ? 1.f : 0.f);      // bias row | zeros
     addtid_drain();
-#endif
-    WSTAMP(2);
-#ifndef VN_ABL_NOBAR
     __syncthreads();
-#endif
-    WSTAMP(3);
-#ifndef VN_ABL_NOCONTRACT
     h13_contract(TA, TB, lc, wave, lane, acc);
-#endif
-    WSTAMP(4);
-#ifndef VN_ABL_NOBAR
     __syncthreads();
-#endif
-    WSTAMP(5);
   }
 }
 
@@ -730,7 +660,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   const unsigned t_base_bytes = (unsigned)((LY::T_OFF + wave * 64) * 4);      // lane-major images: this wave's columns
   float* Gacc = lds + LY::G_OFF;
 
-  FIXSTAMP(0);
   // lane constants that come from global memory are requested first, so that their latency hides under the prologue:
   // the quadrature index of this lane's point is the same in every interior tile (tiles start at whole test functions),
   // so the periodic FE table entries are lane constants
@@ -799,7 +728,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   }
   __syncthreads();
 
-  FIXSTAMP(1);
   LaneC lc;
   lc.g = lane >> 4;
   lc.c = lane & 15;
@@ -807,15 +735,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   static_assert(16 * MTM <= LY::HP, "backward fragment rows stay inside the weight image");
   static_assert(vfeat(16 + 5) == 16 + vfeat(5), "row tile m holds features fin(c) + 16m");
   lc.offB0 = vfeat(lc.c) * WS + 4 * lc.g;
-  // Diagnostic ablations (-DVN_ABL_FWD_W / -DVN_ABL_BWD_W; results are WRONG, only counters and time matter):
-  // the weight-fragment reads of the forward / backward GEMMs become bank-conflict-free (32 lanes of a half on
-  // 32 distinct banks), to attribute SQ_LDS_BANK_CONFLICT (profiles/r2_lds_conflict_ablation.md).
-#ifdef VN_ABL_FWD_W
-  lc.offF = (lane & 31);
-#endif
-#ifdef VN_ABL_BWD_W
-  lc.offB0 = (lane & 31);
-#endif
   lc.twr = 4 * lc.g * TSW + wave * CW + lc.c;
 
   // persistent weight-gradient accumulators
@@ -856,10 +775,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
   const float cb = A.bDof > 0 ? 2.f * A.w0 * A.biDimVal / (float)A.bDof : 0.f;
   const float ci = nI > 0 ? 2.f * A.w1 * A.biDimVal / (float)nI : 0.f;
 
-#ifdef VN_STAMPS
-  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = 0;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     asm volatile("" ::: "memory");                 // keep LDS fragment loads inside the loop
     const bool interior = tile < ntiles_i;
@@ -875,19 +790,12 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
 #pragma unroll
       for (int s = 0; s < KS0; ++s) {
         const int f = 4 * s + lc.g;
-#ifdef VN_ABL_NOINPUT   // diagnostic: no global input loads (results wrong) -> upper bound of what hiding their latency can buy
-        xin[s] = (valid && f < net.d_in) ? 0.001f * (float)(row & 1023) : 0.f;
-        gin[s] = (valid && interior && f < net.dim) ? 0.01f * (float)(f + 1) : 0.f;
-        (void)Xp;
-#else
         xin[s] = (valid && f < net.d_in) ? Xp[row * net.d_in + f] : 0.f;
         if (A.dir >= 0) gin[s] = (valid && interior && f == A.dir) ? 1.f : 0.f;
         else gin[s] = (valid && interior && f < net.dim) ? A.G[row * net.dim + f] : 0.f;
-#endif
       }
     }
 
-    STAMP(0);
     PA<KS> a[L], zd[L];
 
     // ---------------------------------------------------------------- layer 1 (also recomputed late)
@@ -1007,7 +915,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       a[L - 1].p[j] = act_fin2<TANH>(act_exp2<TANH>(pairOf(pv, j)));
       zd[L - 1].p[j] = pairOf(ptn, j);
     }
-    STAMP(1);
     // output layer (VALU)
     float u = 0.f, ud = 0.f;
     {
@@ -1068,11 +975,7 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       } else if (lc.g == 0) {
         sInt[pt] = t;                                                 // q does not divide the tile: serial sum
       }
-      ESTAMP(1);
-#ifndef VN_ABL_NOEPIBAR
       if (!rk_in_wave) { __syncthreads(); epi_barrier = true; }
-#endif
-      ESTAMP(2);
       // every lane sums the partials of its own test function (same order in all lanes, so all
       // agree bit for bit): no second barrier and no serial section
       float R = 0.f;
@@ -1102,8 +1005,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         }
         s = 2.f * A.w2 * dj * R * wq;
       }
-      ESTAMP(3);
-      ESTAMP(4);
       udbar = s;
       ubar = -dnt * s;
     } else {
@@ -1118,7 +1019,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       }
     }
 
-    STAMP(2);
     // ---------------------------------------------------------------- backward
     PA<KS> zb, zdb;
 #pragma unroll
@@ -1131,7 +1031,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       const f32x2 zq = adb * sp;
       zdb.p[j] = zq;
       zb.p[j] = ab * sp + zq * act_d2r_2<TANH>(av) * zd[L - 1].p[j];
-#ifndef VN_ABL_NOTHIN
       // Output-layer weight gradient, no LDS, no MFMA, no barrier: d w_o[f] = sum_p (a[f][p] ubar[p] + adot[f][p] udbar[p]).
       // Both seeds are per-point scalars, so the products are combined per element in registers and summed over the 16
       // lanes of a row (= the wave's 16 points of feature 4 ks + g) with DPP moves; lane c == ks of each row keeps the sum
@@ -1144,14 +1043,11 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
         const float s1 = rowsum16(c2[1]);
         woacc += (lc.c == 2 * j + 1) ? s1 : 0.f;
       }
-#endif
     }
     boacc += rowsum16(ubar);                 // d loss / d b_o = sum_p ubar_p (every lane of the wave holds the wave's sum)
-    STAMP(3);
     // The lane-major images of the hidden layers overlap other waves' columns of the per-wave (input-layer) transposition
     // at the end of the previous tile: a tile whose epilogue had its own workgroup barrier is already past it.
     if constexpr (HID13) { if (!epi_barrier) __syncthreads(); }
-    STAMP(4);
 #pragma unroll
     for (int l = L; l >= 2; --l) {
       if (l == 2 && L > 2) {                                 // bring layer-1 activations back
@@ -1169,28 +1065,27 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
       if constexpr (HID13) {
         if (l - 2 < LY::NST) {
           f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
-          h13_wgrad_layer<TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, acc2 STAMP_ARGS);
+          h13_wgrad_layer<TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, acc2);
           stash[(l - 2) * ST_L] = acc2[0];
           stash[(l - 2) * ST_L + 64] = acc2[1];
         } else {
-          h13_wgrad_layer<TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, wacch[l - 2] STAMP_ARGS);
+          h13_wgrad_layer<TANH>(a[l - 2], zd[l - 2], zb, zdb, TA, lc, wave, lane, t_base_bytes, wacch[l - 2]);
         }
       }
       else if constexpr (NHACC == 2) {
         if (l - 2 < LY::NST) {               // accumulators of this layer live in the LDS stash between tiles
           f32x4 acc2[2] = {stash[(l - 2) * ST_L], stash[(l - 2) * ST_L + 64]};
-          wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, acc2, ones_h[l - 2] STAMP_ARGS);
+          wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, acc2, ones_h[l - 2]);
           stash[(l - 2) * ST_L] = acc2[0];
           stash[(l - 2) * ST_L + 64] = acc2[1];
         } else {
-          wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
+          wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2]);
         }
       }
-      else wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2] STAMP_ARGS);
+      else wgrad_layer<KS, KS, false, TANH, LY::MERGE>(a[l - 2], zd[l - 2], zb, zdb, TA, TB, lc, wave, wacch[l - 2], ones_h[l - 2]);
       if constexpr (fullpos(KS)) {
         if (!ones_h[l - 2]) thin_bias<KS>(zb, TA, TB, lc, wave, lane, bsum_h[l - 2]);
       }
-      STAMP(5);
       const float* Wl = WH + (l - 2) * LY::HPWS;
       int k_out = (net.H[l] + 3) >> 2, m_in = (net.H[l - 1] + 15) >> 4;
       f32x4 accv[MT], acct[MT];
@@ -1256,23 +1151,12 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
           zb.set(ks, ab * sp + adb * sp * act_d2r<TANH>(av) * zd[l - 2][ks]);
         }
       }
-      STAMP(6);
     }
-#ifndef VN_ABL_NOTHIN
     if (thin_in) thin_wgrad_in<KS>(xin, gin, zb, zdb, TA, TB, lc, wave, lane, wacc1[0]);
-#else
-    if (0) {}
-#endif
-    else wgrad_layer<KS0, KS, true, TANH, LY::MERGE>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1, true STAMP_ARGS);
-    STAMP(7);
+    else wgrad_layer<KS0, KS, true, TANH, LY::MERGE>(xin, gin, zb, zdb, TA, TB, lc, wave, wacc1, true);
   }
 
-  FIXSTAMP(2);
   // ------------------------------------------------------------------ epilogue
-#ifdef VN_STAMPS
-  if (A.stamps && blockIdx.x == 0 && tid == 64 * VN_STAMP_WAVE)
-    for (int i = 0; i < 8; ++i) A.stamps[i] = stamp_acc[i];
-#endif
   __syncthreads();
   for (int i = tid; i < (LY::G_LOW ? LY::G_SZ : LY::T_SZ); i += NTHREADS) lds[LY::G_OFF + i] = 0.f;
   __syncthreads();
@@ -1357,7 +1241,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     }
     if (nr == 0) __syncthreads();                    // the slots must be visible to the store phase
   }
-  FIXSTAMP(3);
   float* out = A.partial + (long)blockIdx.x * P;
 #pragma unroll
   for (int l = 1; l <= L + 1; ++l) {
@@ -1400,7 +1283,6 @@ __global__ __launch_bounds__(NTHREADS, 2) VN_NO_LDS_PAIRING void vn_fused16_kern
     for (int w = 0; w < NW; ++w) s += sInt[w * 3 + tid];
     A.losspart[blockIdx.x * 3 + tid] = s;
   }
-  FIXSTAMP(4);
 }
 
 template <int L, int KS, bool TANH>

@@ -5,6 +5,8 @@
 // res = -u_t + diff Lap(u) - (vel - ddx) . grad(u) + src at n points (TFModel.py:743-754), second-order forward mode on the
 // matrix pipe; u may be nullptr.  Networks the 8-wave fused kernel serves (vn_fused16_net_supported), dim <= 3;
 // hipErrorInvalidValue otherwise.  src, ddx may be nullptr.  ncu = CUs of the device.
+// what vn_taylor16_residual takes (the caller routes everything else to the per-thread kernel of vn_pointwise.hip)
+inline bool vn_taylor16_supported(const VnNet& net, int td) { return net.dim <= 3 && net.d_in <= 8 && net.dim + (td ? 1 : 0) <= net.d_in; }
 hipError_t vn_taylor16_residual(const VnNet& net, const float* theta, const float* X, const float* diff, const float* vel,
                                 const float* src, const float* ddx, int td, long n, float* u, float* res, int ncu, hipStream_t s);
 

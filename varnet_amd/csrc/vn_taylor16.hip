@@ -277,7 +277,8 @@ hipError_t launch_one(const VnTaylorArgsD& a, int ncu, hipStream_t s) {
 hipError_t vn_taylor16_residual(const VnNet& net, const float* theta, const float* X, const float* diff, const float* vel,
                                 const float* src, const float* ddx, int td, long n, float* u, float* res, int ncu, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  if (net.dim > 3 || net.d_in > 4 * KS0 || net.dim + (td ? 1 : 0) > net.d_in) return hipErrorInvalidValue;
+  static_assert(4 * KS0 == 8, "vn_taylor16_supported states the input width");
+  if (!vn_taylor16_supported(net, td)) return hipErrorInvalidValue;
   VnTaylorArgsD a;
   a.net = net; a.theta = theta; a.X = X; a.diff = diff; a.vel = vel; a.src = src; a.ddx = ddx; a.td = td; a.n = n; a.u = u; a.res = res;
   const int ks = vn_fused16_ks(net);

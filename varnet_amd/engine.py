@@ -14,6 +14,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VARNET_HIP_LIB selects a diagnostic build of the same ABI (tools/): never a different backend
 LIB_PATH = os.environ.get('VARNET_HIP_LIB', os.path.join(_HERE, 'libvarnet_hip.so'))
+# the tests' cross-check build: the product objects + the 4-wave geometry of the fused kernel (VN_KERNEL_FUSED), which serves no
+# automatic route and is therefore not in the product library (varnet_amd/csrc/Makefile, target xcheck)
+XCHECK_LIB_PATH = os.path.join(_HERE, 'libvarnet_hip_xcheck.so')
+_xlib = None
 
 VN_MAX_LAYERS = 16          # what a vn_config may describe (include/varnet_hip.h); beyond the kernels' own range
 VN_MAX_WIDTH = 2048         # (6 layers x 64 wide, 8 inputs) the engine runs layer by layer (VN_KERNEL_LAYERED)
@@ -80,6 +84,8 @@ _SIGS = {
     'vn_profile_comm': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'vn_kernel_path': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'vn_debug_stamps': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    'vn_debug_point_route': (C.c_int, [C.c_void_p, C.c_int32]),
+    'vn_debug_calibrate_f64': (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_double)]),
     'vn_profile_begin': (C.c_int, [C.c_void_p]),
     'vn_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                  C.c_char_p, C.c_int32]),
@@ -178,7 +184,13 @@ class VNEngine:
                  optimizer_name='adam', kernel=VN_KERNEL_AUTO):
         import torch
         self.torch = torch
-        self.lib = load_library()
+        if kernel == VN_KERNEL_FUSED:
+            global _xlib
+            if _xlib is None:
+                _xlib = load_library(XCHECK_LIB_PATH)
+            self.lib = _xlib
+        else:
+            self.lib = load_library()
         if not torch.cuda.is_available():
             raise VNError('no GPU visible: the VarNet HIP engine has no CPU fallback')
         # a name for all hidden layers, a one-entry list, or one entry per layer (TFModel.py:113-119)
@@ -669,6 +681,17 @@ class VNEngine:
         self._ck(self.lib.vn_debug_calibrate(self.h, out))
         return {"mfma_f32_tflops": out[0], "mfma_launch_ms": out[1], "cycles_per_vector_instruction_2_waves_per_simd": out[2],
                 "clock_ghz_implied_by_the_mfma_loop": out[3], "valu_launch_ms": out[4]}
+
+    def calibrate_f64(self, ghz=0.0):
+        """Sustained fp64 MFMA rate of this GPU (v_mfma_f64_16x16x4_f64 loop, vn_calib.hip): dict for bench.py."""
+        out = (C.c_double * 3)()
+        self._ck(self.lib.vn_debug_calibrate_f64(self.h, float(ghz), out))
+        return {"mfma_f64_tflops": out[0], "launch_ms": out[1], "cycles_per_mfma_f64_16x16x4": out[2]}
+
+    def debug_point_route(self, route):
+        """Test aid: residual / fp64 entry points of this engine on the per-thread kernels (True / 1), forward / residual on the
+        f32-MFMA kernels where the bf16-piece kernels would run (2), or the automatic route (False / 0)."""
+        self._ck(self.lib.vn_debug_point_route(self.h, int(route)))
 
     def debug_stamps(self):
         out = (C.c_uint64 * 8)()
