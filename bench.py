@@ -470,6 +470,10 @@ def inference_line(vn, tdata, eng, F_pt):
     tf = t(lambda: eng._ck(eng.lib.vn_forward(eng.h, _ptr(X), n, _ptr(u))))
     tr = t(lambda: eng._ck(eng.lib.vn_residual(eng.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, m, _ptr(u), _ptr(r))))
     nd = 3 * dim + 2
+    # which matrix-pipe form serves these two calls (labels only; the engine decides: vn_api.hip, vn_split16_supported): hidden
+    # widths 33..64 with 2..7 hidden layers (6 beyond 50 wide) run on the bf16 pipe as six products of exact bf16 pieces
+    Wd = list(vn.layerWidth)
+    split = 33 <= max(Wd) <= 64 and 2 <= len(Wd) <= (7 if max(Wd) <= 50 else 6)
     # the fp64 checking path (BASELINE config 5's fp64 residual check runs these entry points): vn_taylor16d on the fp64 matrix pipe.
     # Kernel time from events on the engine's stream (= torch's current stream, VNEngine.use_current_stream); priced against the
     # fp64 MFMA rate THIS box sustains (vn_debug_calibrate_f64: the guide quotes no fp64 matrix peak), FLOPs stated both ways.
@@ -506,10 +510,13 @@ def inference_line(vn, tdata, eng, F_pt):
            "note": "peak = what a loop of independent v_mfma_f64_16x16x4_f64 sustains on this box in this process (two waves per SIMD); "
                    "(3 dim + 2) F_pt per residual point as in fp32; `issued` counts the padded 16-row tiles the kernel really runs"}
     return {"fp64": f64, "forward": {"points": n, "ms": tf * 1e3, "points_per_s": n / tf, "tflops_of_F_pt": F_pt * n / tf / 1e12,
-                        "frac_of_peak": F_pt * n / tf / 1e12 / PEAK_FP32_MFMA_TFLOPS, "kernel": "vn_pgrad16_kernel (value-only sweep)"},
+                        "frac_of_peak": F_pt * n / tf / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                        "kernel": "vn_split16_kernel<NS = 1> (hidden layers as six v_mfma_f32_16x16x32_bf16 products of exact bf16 pieces; "
+                                  "priced against the f32 MFMA peak for comparison with rounds 1-5)" if split else "vn_pgrad16_kernel (value-only sweep)"},
             "residual": {"points": m, "ms": tr * 1e3, "points_per_s": m / tr, "tflops_executed": nd * F_pt * m / tr / 1e12,
                          "frac_of_peak": nd * F_pt * m / tr / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "kernel": "vn_taylor16_kernel: (3 dim + 2) F_pt per point, one pass of three chained streams per coordinate direction"},
+                         "kernel": ("vn_split16_kernel<NS = 3> (bf16 pieces)" if split else "vn_taylor16_kernel") +
+                                   ": (3 dim + 2) F_pt per point, one pass of three chained streams per coordinate direction"},
             "note": "vn_forward = VarNet.evaluate; vn_residual = TFModel.py:743-754, what every training monitor (VarNet.py:1363) and the "
                     "residual-driven re-sampling (VarNet.py:1696-1868) call; profiles/r5_forward_perf.txt, r5_residual_perf.txt"}
 

@@ -70,7 +70,7 @@ MOR_SENS_BAR = 0.9          # l2Err((d3 - d4), u(kappa0) - u(kappa1)) on the poi
                             # 0.48-0.69 from epoch 18 000 to 120 000
 # BASELINE config 1 = Operator_1Dt at D = 0.1/pi with the 3x20 net, the script's settings, 100 000 epochs
 CFG1_EPOCHS = 100000
-CFG1_BAR = 0.05             # l2Err(fixData.cEx, evaluate()) (Operator_1Dt.py:177-186); exploration: 0.008-0.028 from epoch 20 000 to 300 000
+CFG1_BAR = 0.05             # l2Err(fixData.cEx, evaluate()) (Operator_1Dt.py:177-186); exploration: 0.008-0.028 from epoch 20 000 to 300 000 (uniform throughout, rounds 4-5); round 6, with the script's saveFreq and its one re-draw at epoch 27 800: 0.0062 at epoch 100 000
 # Operator_2Dt problem, [40,20] x 40 grid (2.05 M training points), the script's net and weights, 20 000 epochs
 OP2_EPOCHS = 20000
 OP2_ALL_BAR = 0.20          # the script's metric over ALL 151 time nodes (Operator_2Dt.py:174-183); exploration: plateau 0.133-0.140 on the
@@ -224,9 +224,15 @@ def _config1_problem(engine=True):
 
 @pytest.mark.gpu
 def test_config1_converged_run_against_cexact(tmp_path):
-    """BASELINE config 1 trained as the script trains it (Operator_1Dt.py:170: smpScheme='optimal', adjustWeight=True),
+    """BASELINE config 1 trained as the script trains it (Operator_1Dt.py:170: smpScheme='optimal', adjustWeight=True, every
+    other argument at train()'s default -- saveFreq=100, trainUpdelay=2e4, tolUpd=0.01, reinitrain=True, VarNet.py:1198-1200),
     bounded to 100 000 epochs, then the script's acceptance metric l2Err(fixData.cEx, evaluate()) (:177-186) against the
-    reference-generated fixture of its own `cExact`; then the oracle leg at the converged theta*."""
+    reference-generated fixture of its own `cExact`; then the oracle leg at the converged theta*.
+    Round 6: through round 5 this test passed saveFreq=10000, and the convergence test that re-draws the
+    training set (VarNet.py:1385-1421) looks at the last five losses SAMPLED EVERY saveFreq EPOCHS -- at 10 000 it never fired and
+    the "optimal" run was a uniform run.  With the script's own saveFreq the set is re-drawn once (exploration committed before
+    this test's first run, profiles/r6_explore_cfg1_optimal_savefreq100.txt: epoch 27 800, then 0.0062 at epoch 100 000): residual-
+    driven points ADDED (96 000 -> 144 000 rows), trainable variables re-initialised, BC/IC weights x 5 -- all asserted below."""
     g = np.load(GOLD_CEX)
     vn = _config1_problem()
     fd, eng = vn.fixData, vn.engine
@@ -234,7 +240,13 @@ def test_config1_converged_run_against_cexact(tmp_path):
     np.testing.assert_allclose(fd.cEx, g['c_uniform'], rtol=1e-12, atol=1e-14)      # the metric's cEx IS the reference's output
     np.random.seed(0)
     res = vn.train(str(tmp_path), weight=[10., 10., 1.], smpScheme='optimal', adjustWeight=True, epochNum=CFG1_EPOCHS,
-                   saveFreq=10000, verbose=False)
+                   verbose=False)
+    # the branch of VarNet.py:1385-1421 ran: one re-draw (multiTrainUpd=False) after trainUpdelay, points added, weights x 5
+    assert len(res.inpIter) == 1 and res.inpIter[0] >= 20000 - 1, res.inpIter
+    assert vn.tData.mor[0]['Input'].shape[0] == 144000 and vn.fixData.nt == 9000          # ceil(0.5 nt) test functions added
+    cd = open(os.path.join(str(tmp_path), 'caseData.txt')).read()
+    assert 'Training points updated.' in cd and 'trainable variables reinitialized.' in cd
+    w_after = np.asarray(res.trainWeight, dtype=float)
     u = vn.evaluate()                                                                # Operator_1Dt.py:179
     e_hip = float(uf.l2Err(g['c_uniform'], u))
     # oracle leg at theta*
@@ -243,7 +255,7 @@ def test_config1_converged_run_against_cexact(tmp_path):
     e_orc = float(uf.l2Err(g['c_uniform'], u_o))
     fdiff = float(np.max(np.abs(u - u_o)))
     from tests.test_operator_parity_gpu import oracle_kwargs
-    td = vn._build_tdata()
+    td = vn.tData                                    # the run's own (re-drawn, 144 000-row) training set: what theta* was trained on
     td.select_mor(0)
     w = np.array([3.0, 2.0, 5.0])
     eng.set_weights(w)
@@ -252,21 +264,26 @@ def test_config1_converged_run_against_cexact(tmp_path):
     torch.cuda.synchronize()
     gh = gb.cpu().numpy().astype(np.float64)
     kw = oracle_kwargs(vn, td, w)
+    assert kw['Input'].shape[0] == 144000 and kw['intShape'] == [9000, 16]
     kw = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in kw.items()}
     ref, gref = og.loss_and_grad(theta, 2, [20, 20, 20], torch.float64, **kw)
     lerr = abs(gh[eng.P] - ref['loss']) / abs(ref['loss'])
     gerr = float(np.max(np.abs(gh[:eng.P] - gref)) / np.max(np.abs(gref)))
-    gbar, gcond = _grad_bar(theta, 2, [20, 20, 20], kw, gref)
+    # (round 6: the loss at this theta* -- after the re-draw, a sum of 9 000 squared small residuals -- gets the same self-calibrated,
+    # capped bar as the gradient and as the other converged runs' losses: 1.02e-5 measured where the oracle's own fp32 run deviates alike)
+    gbar, gcond, lbar, lcond = _grad_bar(theta, 2, [20, 20, 20], kw, gref, lref=float(ref['loss']))
     record('config1_converged', dict(epochs=len(res.lossAll), l2Err_cExact_hip=e_hip, l2Err_cExact_oracle_at_theta_star=e_orc,
                                      max_field_diff_hip_vs_oracle=fdiff, loss_rel_err_at_theta_star=float(lerr),
                                      grad_rel_err_at_theta_star=gerr, grad_rel_err_of_the_fp32_restatement_itself=gcond, grad_bar=gbar,
+                                     loss_rel_err_of_the_fp32_restatement_itself=lcond, loss_bar=lbar,
                                      loss_first_last=[float(res.lossAll[0]), float(res.lossAll[-1])],
-                                     training_sets_redrawn_at=list(res.inpIter), bar=CFG1_BAR))
+                                     training_sets_redrawn_at=[int(e) for e in res.inpIter], rows_after_the_redraw=144000,
+                                     train_weights_at_the_end=[float(x) for x in w_after], bar=CFG1_BAR))
     print('config 1, %d epochs: l2Err(cExact) hip %.5f oracle %.5f, field diff %.1e, loss/grad err at theta* %.1e / %.1e'
           % (len(res.lossAll), e_hip, e_orc, fdiff, lerr, gerr))
     assert e_hip <= CFG1_BAR and e_orc <= CFG1_BAR
     assert fdiff <= FWD_BAR
-    assert lerr <= 1e-5 and gerr <= gbar, (lerr, gerr, gbar)
+    assert lerr <= lbar and gerr <= gbar, (lerr, lbar, gerr, gbar)
     eng.close()
 
 

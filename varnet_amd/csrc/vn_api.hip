@@ -379,7 +379,8 @@ int run_dedup(vn_engine* h, const Batch& b, float* gradbuf) {
     if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
     HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
   }
-  HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, grid, h->pgrad_wgs, h->stream));
+  if (!h->no_split && vn_split16_supported(h->net, 0)) HIPCHK(vn_split16_pgrad(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, grid, h->stream));
+  else HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, grid, h->pgrad_wgs, h->stream));
   VnDedupArgs a{};
   a.upack = h->dd_uv; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
   a.gcoef = b.gcoef; a.gcoef_csr = b.gcsr; a.source = h->cfg.has_source ? b.source : nullptr;
@@ -1070,7 +1071,8 @@ int vn_forward_grad(vn_engine* h, const float* X, int64_t n, float* u, float* g)
   if (!h->use_fused16 && !h->two_pass) return fail(VN_EUNSUPPORTED, "vn_forward_grad needs a network of the 8-wave fused kernel");
   if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "vn_forward_grad supports dim <= 3");
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, g, nullptr, h->ncu, h->pgrad_wgs, h->stream));
+  if (!h->no_split && vn_split16_supported(h->net, 0)) HIPCHK(vn_split16_pgrad(h->net, h->theta, X, n, u, g, nullptr, h->ncu, h->stream));
+  else HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, g, nullptr, h->ncu, h->pgrad_wgs, h->stream));
   return VN_OK;
 }
 

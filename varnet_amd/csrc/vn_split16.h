@@ -9,3 +9,6 @@ bool vn_split16_supported(const VnNet& net, int td);
 hipError_t vn_split16_forward(const VnNet& net, const float* theta, const float* X, long n, float* u, int ncu, hipStream_t s);
 hipError_t vn_split16_residual(const VnNet& net, const float* theta, const float* X, const float* diff, const float* vel,
                                const float* src, const float* ddx, int td, long n, float* u, float* res, int ncu, hipStream_t s);
+// (u, du/dx_d) in one pass, both sweeps on the bf16 pipe (the outputs of vn_pgrad16_launch: out_u [n], out_g [n, dim], out_pack [n, 4])
+hipError_t vn_split16_pgrad(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g, float* out_pack,
+                            int ncu, hipStream_t s);
