@@ -38,7 +38,16 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), de
 _F16 = ('varnet_amd/csrc/vn_fused16.hip', 'varnet_amd/csrc/vn_fused16_common.h', 'varnet_amd/csrc/vn_internal.h', 'include/varnet_hip.h')
 KERNEL_SOURCES = {'vn_fused16_kernel': _F16,
                   'vn_pgrad16_kernel': ('varnet_amd/csrc/vn_pgrad16.hip', 'varnet_amd/csrc/vn_pgrad16.h', 'varnet_amd/csrc/vn_points16.h') + _F16[1:],
+                  'vn_split16_': ('varnet_amd/csrc/vn_split16.hip', 'varnet_amd/csrc/vn_split16.h', 'varnet_amd/csrc/vn_points16.h') + _F16[1:],
                   'vn_dedup_': ('varnet_amd/csrc/vn_dedup.hip', 'varnet_amd/csrc/vn_dedup.h') + _F16[2:]}
+
+
+def split16_serves(layerWidth):
+    """Labels only (the engine decides: vn_api.hip, vn_split16_supported): hidden widths 33..64 with 2..7 hidden layers (6 beyond 50
+    wide) run their point kernels -- vn_forward, vn_residual, vn_forward_grad / the de-duplicated step's (u, grad u) pass -- on the bf16
+    matrix pipe as six products of exact bf16 pieces (vn_split16.hip); the others on the f32-MFMA kernels."""
+    W = list(layerWidth)
+    return 33 <= max(W) <= 64 and 2 <= len(W) <= (7 if max(W) <= 50 else 6)
 # counter files bench.py may quote `roofline.traffic` from, by --config (tools/collect_profiles.sh + tools/summarise_profiles.py)
 TRAFFIC_FILES = {3: 'pmc_traffic.json', 2: 'pmc_traffic_cfg2.json'}
 DEDUP_TRAFFIC_FILE = 'pmc_traffic_dedup.json'
@@ -358,14 +367,15 @@ def dedup_leg(vn, tdata, eng, step_fn, steps, warmup, nT_total, nB, F_pt, loss_o
         "roofline": {"bound": "mfma", "achieved": flop_dd / (kms * 1e-3) / 1e12 if kms else None, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": flop_dd / (kms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if kms else None,
                      "whole_step_frac": flop_dd / (dtd / steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                     "kernels": ["vn_pgrad16_kernel (u and du/dx_d at the unique points: value forward + value-adjoint sweep, 2 F_pt)",
+                     "kernels": [("vn_split16_pgrad_kernel" if split16_serves(vn.layerWidth) else "vn_pgrad16_kernel") +
+                                 " (u and du/dx_d at the unique points: value forward + value-adjoint sweep, 2 F_pt)",
                                  "vn_dedup_seed_kernel (rows: weak-form integrand, R_k, loss, per-row seeds; HBM-bound)",
                                  "vn_dedup_gather_kernel (unique points: CSR sum of their rows' seeds; HBM-bound)",
                                  "%s, reverse mode with the per-point direction sg and tangent seed 1 (6 F_pt, BC/IC tiles ride along)" % kname],
                      "kernel_sequence_ms": kms, "launches_timed": kl, "formulation_flop_per_step": flop_dd,
                      "traffic": traffic, "traffic_source": traffic_source,
                      "note": "FLOPs of the formulation that ran (8 F_pt per unique point + 3 F_pt per BC/IC point), not of the row-wise "
-                             "one; per-kernel times: profiles/r5_dedup_kernel_stats.csv"},
+                             "one; per-kernel times: profiles/r6_dedup_kernel_stats.csv"},
         "note": "separate speed-up, not the headline: each unique quadrature point is evaluated once instead of once per "
                 "(test function, point) row; same loss and gradient up to fp32 rounding "
                 "(tests/test_engine_gpu.py::test_dedup_formulation_parity)"}
@@ -472,8 +482,7 @@ def inference_line(vn, tdata, eng, F_pt):
     nd = 3 * dim + 2
     # which matrix-pipe form serves these two calls (labels only; the engine decides: vn_api.hip, vn_split16_supported): hidden
     # widths 33..64 with 2..7 hidden layers (6 beyond 50 wide) run on the bf16 pipe as six products of exact bf16 pieces
-    Wd = list(vn.layerWidth)
-    split = 33 <= max(Wd) <= 64 and 2 <= len(Wd) <= (7 if max(Wd) <= 50 else 6)
+    split = split16_serves(vn.layerWidth)
     # the fp64 checking path (BASELINE config 5's fp64 residual check runs these entry points): vn_taylor16d on the fp64 matrix pipe.
     # Kernel time from events on the engine's stream (= torch's current stream, VNEngine.use_current_stream); priced against the
     # fp64 MFMA rate THIS box sustains (vn_debug_calibrate_f64: the guide quotes no fp64 matrix peak), FLOPs stated both ways.

@@ -205,7 +205,9 @@ def test_committed_counter_files_match_the_tree():
     path = os.path.join(ROOT, 'profiles', bench.DEDUP_TRAFFIC_FILE)
     assert os.path.exists(path), 'no counter file for the de-duplicated formulation: run tools/collect_profiles.sh'
     js = json.load(open(path))
-    assert [k['kernel'].split('<')[0] for k in js['kernels']] == ['vn_pgrad16_kernel', 'vn_dedup_seed_kernel', 'vn_dedup_gather_kernel', 'vn_fused16_kernel']
+    names = [k['kernel'].split('<')[0] for k in js['kernels']]
+    assert names[0] in ('vn_split16_pgrad_kernel', 'vn_pgrad16_kernel')      # the (u, grad u) pass: bf16 pieces at hidden widths 33..64
+    assert names[1:] == ['vn_dedup_seed_kernel', 'vn_dedup_gather_kernel', 'vn_fused16_kernel']
     for k in js['kernels']:
         assert k['kernel_source_sha256'] == bench.kernel_source_hash(k['kernel']), '%s predates the code of %s' % (bench.DEDUP_TRAFFIC_FILE, k['kernel'])
     t, src = bench.dedup_traffic(3)
@@ -226,4 +228,4 @@ def test_kernel_hash_ignores_comments_and_layout_only():
     # the headers every object depends on and the compile flags decide the code too
     assert 'include/varnet_hip.h' in bench.KERNEL_SOURCES['vn_fused16_kernel'] and 'varnet_amd/csrc/vn_fused16_common.h' in bench.KERNEL_SOURCES['vn_fused16_kernel']
     assert '-fno-slp-vectorize' in bench.effective_cxxflags() and '--offload-arch=gfx950' in bench.effective_cxxflags()
-    assert len({bench.kernel_source_hash(k) for k in ('vn_fused16_kernel', 'vn_pgrad16_kernel', 'vn_dedup_seed_kernel')}) == 3
+    assert len({bench.kernel_source_hash(k) for k in ('vn_fused16_kernel', 'vn_pgrad16_kernel', 'vn_dedup_seed_kernel', 'vn_split16_pgrad_kernel')}) == 4

@@ -140,11 +140,14 @@ if out2:
 # The bench process runs the row-wise leg first, so the fused kernel's dispatches BEHIND the first vn_pgrad16 dispatch are the
 # formulation's reverse launches.
 def dedup_summary():
-    DD = ('vn_pgrad16_kernel', 'vn_dedup_seed_kernel', 'vn_dedup_gather_kernel', 'vn_fused16_kernel')
+    # the (u, grad u) pass: vn_split16_pgrad_kernel where the net's hidden widths are 33..64 (round 6), else vn_pgrad16_kernel
+    allrows = [r for f in glob.glob(src + '/ddpmc_*/**/p_counter_collection.csv', recursive=True) for r in csv.DictReader(open(f))]
+    PG = 'vn_split16_pgrad_kernel' if any('vn_split16_pgrad_kernel' in r['Kernel_Name'] for r in allrows) else 'vn_pgrad16_kernel'
+    DD = (PG, 'vn_dedup_seed_kernel', 'vn_dedup_gather_kernel', 'vn_fused16_kernel')
     per, names = collections.defaultdict(lambda: collections.defaultdict(list)), {}
     for f in glob.glob(src + '/ddpmc_*/**/p_counter_collection.csv', recursive=True):
         rows = list(csv.DictReader(open(f)))
-        first = min([int(r['Dispatch_Id']) for r in rows if 'vn_pgrad16_kernel' in r['Kernel_Name']] or [1 << 60])
+        first = min([int(r['Dispatch_Id']) for r in rows if PG in r['Kernel_Name']] or [1 << 60])
         for r in rows:
             for kn in DD:
                 if kn in r['Kernel_Name'] and (kn != 'vn_fused16_kernel' or int(r['Dispatch_Id']) > first):
@@ -169,7 +172,7 @@ def dedup_summary():
             'command': 'tools/collect_profiles.sh (rocprofv3 --pmc <group> --kernel-trace, one pass per group) -- python bench.py --steps 3 --warmup 1 '
                        '--no-cpu-baseline --no-extra',
             'note': 'one launch of each kernel per de-duplicated step; vn_fused16_kernel = its reverse-mode launches (dispatches behind the first '
-                    'vn_pgrad16 dispatch)'}
+                    '(u, grad u) dispatch)'}
 
 
 if full:
