@@ -534,11 +534,16 @@ def test_forward_grad_parity(d_in, dim, widths, act, n):
     eg = np.max(np.abs(g.cpu().numpy() - gref)) / np.max(np.abs(gref))
     # vn_forward: hidden widths 33..64 run the bf16-piece kernel (vn_split16.hip: six products of exact bf16 pieces per layer), the
     # others the value-only sweep of vn_pgrad16; route 2 forces the latter -- both against the oracle at the SAME bar, errors side by side
-    eng.debug_point_route(2)
-    u2f = eng.forward(X)
-    uf32, gf32 = eng.forward_grad(X)
+    # (the f32-MFMA forms of the networks vn_split16 serves live in the tests' cross-check library: an engine of that library)
+    engx = VNEngine(dim, d_in, widths, True, 16, activationFun=act, xcheck=True)
+    engx.set_params(flat)
+    engx.debug_point_route(2)
+    u2f = engx.forward(X)
+    uf32, gf32 = engx.forward_grad(X)
     torch.cuda.synchronize()
-    eng.debug_point_route(0)
+    engx.close()
+    with pytest.raises(Exception, match='cross-check'):
+        eng.debug_point_route(2)                  # the product library has no such route
     euf = np.max(np.abs(uf32.cpu().numpy() - uref)) / np.max(np.abs(uref))
     egf = np.max(np.abs(gf32.cpu().numpy() - gref)) / np.max(np.abs(gref))
     assert euf <= 2e-6 and egf <= 1e-5, (euf, egf)          # vn_pgrad16 (f32 MFMA): round 5's kernel at round 5's bars
@@ -600,10 +605,12 @@ def test_taylor_residual_parity(d_in, dim, widths, act, n, with_src, with_ddx, m
     ep = float(np.max(np.abs(r_p.cpu().numpy() - rref[:, 0]))) / scale
     # hidden widths 33..64 (2..7 layers) run the bf16-piece kernel (vn_split16.hip); route 2 = the f32-MFMA kernel vn_taylor16 on the
     # same inputs: same bar, both errors recorded side by side (the bar must not move)
-    eng.debug_point_route(2)
-    u_f, r_f = eng.residual(X32, diff, vel, src, ddx, fp64=False)
+    engx = VNEngine(dim, d_in, widths, True, 16, activationFun=act, xcheck=True)      # an engine of the tests' cross-check library
+    engx.set_params(flat)
+    engx.debug_point_route(2)
+    u_f, r_f = engx.residual(X32, diff, vel, src, ddx, fp64=False)
     torch.cuda.synchronize()
-    eng.debug_point_route(0)
+    engx.close()
     er32 = float(np.max(np.abs(r_f.cpu().numpy() - rref[:, 0]))) / scale
     eu32 = float(np.max(np.abs(u_f.cpu().numpy() - uref[:, 0]))) / max(1.0, float(np.max(np.abs(uref))))
     ERRORS['taylor_residual %s %s' % (widths, act)] = {'res': er, 'u': eu, 'res_pointwise_kernel': ep, 'res_f32_mfma_kernel': er32,

@@ -184,8 +184,12 @@ def test_fullsize_dedup_formulation(cfg3):
     assert not np.array_equal(g1, g_row)                             # ... and it IS another formulation that ran
     gerr = np.max(np.abs(g1[:P] - g_row[:P])) / np.max(np.abs(g_row[:P]))
     assert gerr <= 1e-4, gerr
-    for i in range(P, P + 4):                                        # loss, BC, IC, variational term
+    # loss, BC, IC at the loss bar.  The variational term of this problem at glorot parameters (5.4e-6: 1e5 squared weak residuals,
+    # each the small remainder of cancelling integrand terms) is measured against the fp64 oracle on the sample below, formulation
+    # by formulation; across formulations it gets the bar of the per-test-function loss field it is the sum of (lossVec: 1e-4)
+    for i in range(P, P + 3):
         assert abs(g1[i] - g_row[i]) <= 1e-5 * abs(g_row[i]), (i - P, g1[i], g_row[i])
+    assert abs(g1[P + 3] - g_row[P + 3]) <= 1e-4 * abs(g_row[P + 3]), (g1[P + 3], g_row[P + 3])
     # the fp64 oracle on the first 300 test functions (the sample of test_fullsize_sampled_oracle_check)
     n_s = 300
     rows = n_s * q
@@ -210,14 +214,22 @@ def test_fullsize_dedup_formulation(cfg3):
     lerr = abs(g3[P] - ref['loss']) / abs(ref['loss'])
     gerr3 = np.max(np.abs(g3[:P] - gref)) / np.max(np.abs(gref))
     assert lerr <= 1e-5 and gerr3 <= 1e-4, (lerr, gerr3)
+    # the variational term alone, both formulations against the fp64 oracle (same bar: neither formulation is the worse one)
+    verr_dd = abs(g3[P + 3] - ref['varLoss']) / abs(ref['varLoss'])
+    verr_row = abs(g_row3[P + 3] - ref['varLoss']) / abs(ref['varLoss'])
+    assert verr_dd <= 1e-4 and verr_row <= 1e-4, (verr_dd, verr_row)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     try:
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, 'dedup_fullsize_parity.json'), 'w') as f:
             json.dump({'rows': int(fd.nT), 'unique_points': int(U), 'grad_err_vs_rowwise': float(gerr),
                        'loss_err_vs_rowwise': float(abs(g1[P] - g_row[P]) / abs(g_row[P])),
+                       'var_term_err_vs_rowwise': float(abs(g1[P + 3] - g_row[P + 3]) / abs(g_row[P + 3])),
+                       'var_term': float(g_row[P + 3]),
                        'sample_300_test_functions': {'unique_points': int(len(first)), 'loss_err_vs_fp64_oracle': float(lerr),
                                                      'grad_err_vs_fp64_oracle': float(gerr3),
+                                                     'var_term_err_vs_fp64_oracle': float(verr_dd),
+                                                     'rowwise_var_term_err_vs_fp64_oracle': float(verr_row),
                                                      'rowwise_grad_err_vs_fp64_oracle':
                                                          float(np.max(np.abs(g_row3[:P] - gref)) / np.max(np.abs(gref)))}}, f, indent=1)
     except OSError:

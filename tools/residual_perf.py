@@ -26,12 +26,15 @@ X64, diff64, vel64 = X.double(), diff.double(), vel.double()
 u64, r64 = torch.empty(n, device='cuda', dtype=torch.float64), torch.empty(n, device='cuda', dtype=torch.float64)
 a = t(lambda: e._ck(e.lib.vn_residual(e.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, n, _ptr(u32), _ptr(r32))))
 # round 6: hidden widths 33..64 run the bf16-piece kernels (vn_split16.hip); route 2 = the f32-MFMA kernels on the same inputs
+# (the f32-MFMA forms of this network live in the tests' cross-check library: a second engine of that library, same parameters)
 r_split, u_split = r32.clone(), u32.clone()
-e.debug_point_route(2)
-a32 = t(lambda: e._ck(e.lib.vn_residual(e.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, n, _ptr(u32), _ptr(r32))))
-d32 = t(lambda: e.forward(X))
-uf32 = e.forward(X)
-e.debug_point_route(0)
+ex = VNEngine(dim, d_in, widths, True, 64, xcheck=True)
+ex.set_params(e.get_params())
+ex.debug_point_route(2)
+a32 = t(lambda: ex._ck(ex.lib.vn_residual(ex.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, n, _ptr(u32), _ptr(r32))))
+d32 = t(lambda: ex.forward(X))
+uf32 = ex.forward(X)
+ex.close()
 uf = e.forward(X)
 torch.cuda.synchronize()
 print('bf16-piece kernels against the f32-MFMA kernels on the same inputs: residual max |diff| / max |res| %.2e, forward %.2e'

@@ -82,6 +82,11 @@ constexpr bool kWithFused32 = true;
 #else
 constexpr bool kWithFused32 = false;
 #endif
+#ifdef VN_XCHECK_F32_POINT
+constexpr bool kWithF32Point = true;     // cross-check build: vn_pgrad16 / vn_taylor16 also instantiated for the nets vn_split16 serves
+#else
+constexpr bool kWithF32Point = false;
+#endif
 
 }  // namespace
 
@@ -379,7 +384,7 @@ int run_dedup(vn_engine* h, const Batch& b, float* gradbuf) {
     if (!h->ev0[h->prof_n]) { HIPCHK(hipEventCreate(&h->ev0[h->prof_n])); HIPCHK(hipEventCreate(&h->ev1[h->prof_n])); }
     HIPCHK(hipEventRecord(h->ev0[h->prof_n], h->stream));
   }
-  if (!h->no_split && vn_split16_supported(h->net, 0)) HIPCHK(vn_split16_pgrad(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, grid, h->stream));
+  if (!h->no_split && vn_split16_supported(h->net)) HIPCHK(vn_split16_pgrad(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, grid, h->stream));
   else HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, grid, h->pgrad_wgs, h->stream));
   VnDedupArgs a{};
   a.upack = h->dd_uv; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
@@ -1054,7 +1059,7 @@ int vn_forward(vn_engine* h, const float* X, int64_t n, float* u) {
   // would carry a tangent stream of zeros through every layer)
   if (h->use_fused16 || h->two_pass) {
     // hidden widths 33..64: the products as six bf16-piece MFMAs, fp32-class (vn_split16.hip)
-    if (!h->no_split && vn_split16_supported(h->net, 0)) HIPCHK(vn_split16_forward(h->net, h->theta, X, n, u, h->ncu, h->stream));
+    if (!h->no_split && vn_split16_supported(h->net)) HIPCHK(vn_split16_forward(h->net, h->theta, X, n, u, h->ncu, h->stream));
     else HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, nullptr, nullptr, h->ncu, h->pgrad_wgs, h->stream));
     return VN_OK;
   }
@@ -1071,7 +1076,7 @@ int vn_forward_grad(vn_engine* h, const float* X, int64_t n, float* u, float* g)
   if (!h->use_fused16 && !h->two_pass) return fail(VN_EUNSUPPORTED, "vn_forward_grad needs a network of the 8-wave fused kernel");
   if (h->cfg.dim > 3) return fail(VN_EUNSUPPORTED, "vn_forward_grad supports dim <= 3");
   HIPCHK(hipSetDevice(h->cfg.device));
-  if (!h->no_split && vn_split16_supported(h->net, 0)) HIPCHK(vn_split16_pgrad(h->net, h->theta, X, n, u, g, nullptr, h->ncu, h->stream));
+  if (!h->no_split && vn_split16_supported(h->net)) HIPCHK(vn_split16_pgrad(h->net, h->theta, X, n, u, g, nullptr, h->ncu, h->stream));
   else HIPCHK(vn_pgrad16_launch(h->net, h->theta, X, n, u, g, nullptr, h->ncu, h->pgrad_wgs, h->stream));
   return VN_OK;
 }
@@ -1107,7 +1112,7 @@ int vn_residual(vn_engine* h, const float* X, const float* diff, const float* ve
   // networks of the 8-wave family: second-order forward mode on the matrix pipe (vn_taylor16.hip); the per-point kernel keeps
   // the generic / 4-wave requests (and is what the new kernel is cross-checked against)
   if ((h->use_fused16 || h->two_pass) && vn_taylor16_supported(h->net, h->cfg.time_dependent) && !h->point_kernels) {
-    if (!h->no_split && vn_split16_supported(h->net, h->cfg.time_dependent))
+    if (!h->no_split && vn_split16_supported(h->net))
       HIPCHK(vn_split16_residual(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->ncu, h->stream));
     else
       HIPCHK(vn_taylor16_residual(h->net, h->theta, X, diff, vel, src, ddx, h->cfg.time_dependent, n, u, res, h->ncu, h->stream));
@@ -1276,6 +1281,9 @@ int vn_debug_calibrate_f64(vn_engine* h, double ghz, double out[3]) {
 
 int vn_debug_point_route(vn_engine* h, int32_t per_thread) {
   if (!h) return fail(VN_EINVAL, "null handle");
+  if (per_thread == 2 && !kWithF32Point)
+    return fail(VN_EUNSUPPORTED, "route 2 (f32-MFMA point kernels for the networks the bf16-piece kernels serve) exists in the tests' "
+                                 "cross-check build only: libvarnet_hip_xcheck.so (make -C varnet_amd/csrc xcheck)");
   h->point_kernels = per_thread == 1;
   h->no_split = per_thread == 2;
   return VN_OK;

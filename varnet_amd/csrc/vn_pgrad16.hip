@@ -291,12 +291,8 @@ hipError_t launch_one(const VnPgradArgsD& a, int ncu, int wgs_per_cu, hipStream_
 
 }  // namespace
 
-// the instantiations of vn_fused16.hip (every network the 8-wave fused kernel serves)
-#define VN_PGRAD16_CASES(X) \
-  X(1, 5) X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(6, 5) X(7, 5) X(8, 5)  \
-  X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8) X(7, 8) X(8, 8)  \
-  X(1, 13) X(2, 13) X(3, 13) X(4, 13) X(5, 13) X(6, 13) X(7, 13) X(8, 13)  \
-  X(1, 16) X(2, 16) X(3, 16) X(4, 16) X(5, 16) X(6, 16)
+// the instantiations (vn_points16.h): in the product library the networks the bf16-piece kernels do NOT serve
+#define VN_PGRAD16_CASES(X) VN_POINT16_F32_CASES(X)
 
 hipError_t vn_pgrad16_launch(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g,
                              float* out_pack, int ncu, int wgs_per_cu, hipStream_t s) {

@@ -3,6 +3,23 @@
 #pragma once
 #include "vn_fused16_common.h"
 
+// The (hidden layers, k-steps per layer) instantiations of the point kernels = those of vn_fused16.hip.  Networks of
+// VN_POINT16_SPLIT_CASES -- hidden widths 33..64 (KS = 13, 16) with 2..7 hidden layers, 6 beyond 50 wide -- are served by the
+// bf16-piece kernels of vn_split16.hip; the f32-MFMA forms of those networks (vn_pgrad16 / vn_taylor16) are what the tests compare
+// them with and are instantiated in the tests' cross-check library only (-DVN_XCHECK_F32_POINT, Makefile target xcheck).
+#define VN_POINT16_SPLIT_CASES(X) \
+  X(2, 13) X(3, 13) X(4, 13) X(5, 13) X(6, 13) X(7, 13) \
+  X(2, 16) X(3, 16) X(4, 16) X(5, 16) X(6, 16)
+#define VN_POINT16_F32_ONLY_CASES(X) \
+  X(1, 5) X(2, 5) X(3, 5) X(4, 5) X(5, 5) X(6, 5) X(7, 5) X(8, 5)  \
+  X(1, 8) X(2, 8) X(3, 8) X(4, 8) X(5, 8) X(6, 8) X(7, 8) X(8, 8)  \
+  X(1, 13) X(8, 13) X(1, 16)
+#ifdef VN_XCHECK_F32_POINT
+#define VN_POINT16_F32_CASES(X) VN_POINT16_F32_ONLY_CASES(X) VN_POINT16_SPLIT_CASES(X)
+#else
+#define VN_POINT16_F32_CASES(X) VN_POINT16_F32_ONLY_CASES(X)
+#endif
+
 namespace vn16 {
 
 template <int L, int KS>

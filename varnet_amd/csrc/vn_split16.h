@@ -5,7 +5,7 @@
 // Networks of the 8-wave family with hidden widths 33..64 and 2..7 hidden layers (6 at widths > 50), dim <= 3: the value
 // (vn_forward) and the strong residual (vn_residual) with the hidden-layer products on the bf16 matrix pipe as six products of
 // exact bf16 pieces -- fp32-class accuracy, the parity bars of vn_pgrad16 / vn_taylor16.  hipErrorInvalidValue otherwise.
-bool vn_split16_supported(const VnNet& net, int td);
+bool vn_split16_supported(const VnNet& net);      // the instantiation exists (any dim; the residual and the gradient need dim <= 3)
 hipError_t vn_split16_forward(const VnNet& net, const float* theta, const float* X, long n, float* u, int ncu, hipStream_t s);
 hipError_t vn_split16_residual(const VnNet& net, const float* theta, const float* X, const float* diff, const float* vel,
                                const float* src, const float* ddx, int td, long n, float* u, float* res, int ncu, hipStream_t s);

@@ -536,12 +536,10 @@ hipError_t launch_pg(const VnSplitPgArgsD& a, int ncu, hipStream_t s) {
 }  // namespace
 
 // hidden widths 33..64 of the 8-wave family, 2..7 hidden layers (L = 1 has no hidden product; 8 x 24 KB of images do not fit)
-#define VN_SPLIT16_CASES(X) \
-  X(2, 13) X(3, 13) X(4, 13) X(5, 13) X(6, 13) X(7, 13) \
-  X(2, 16) X(3, 16) X(4, 16) X(5, 16) X(6, 16)
+#define VN_SPLIT16_CASES(X) VN_POINT16_SPLIT_CASES(X)
 
-bool vn_split16_supported(const VnNet& net, int td) {
-  if (net.dim > 3 || net.d_in > 4 * KS0 || net.dim + (td ? 1 : 0) > net.d_in) return false;
+bool vn_split16_supported(const VnNet& net) {
+  if (net.d_in > 4 * KS0) return false;
   if (net.act != VN_ACT_SIGMOID && net.act != VN_ACT_TANH) return false;
   const int ks = vn_fused16_ks(net);
 #define X(LL, KK) if (net.L == LL && ks == KK) return true;
@@ -552,7 +550,7 @@ bool vn_split16_supported(const VnNet& net, int td) {
 
 hipError_t vn_split16_forward(const VnNet& net, const float* theta, const float* X, long n, float* u, int ncu, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  if (!vn_split16_supported(net, 0) || !u) return hipErrorInvalidValue;
+  if (!vn_split16_supported(net) || !u) return hipErrorInvalidValue;
   VnSplitArgsD a{};
   a.net = net; a.theta = theta; a.X = X; a.n = n; a.u = u;
   const int ks = vn_fused16_ks(net);
@@ -567,7 +565,7 @@ hipError_t vn_split16_forward(const VnNet& net, const float* theta, const float*
 hipError_t vn_split16_residual(const VnNet& net, const float* theta, const float* X, const float* diff, const float* vel,
                                const float* src, const float* ddx, int td, long n, float* u, float* res, int ncu, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  if (!vn_split16_supported(net, td)) return hipErrorInvalidValue;
+  if (!vn_split16_supported(net) || net.dim > 3 || net.dim + (td ? 1 : 0) > net.d_in) return hipErrorInvalidValue;
   VnSplitArgsD a{};
   a.net = net; a.theta = theta; a.X = X; a.diff = diff; a.vel = vel; a.src = src; a.ddx = ddx; a.td = td; a.n = n; a.u = u; a.res = res;
   const int ks = vn_fused16_ks(net);
@@ -582,7 +580,7 @@ hipError_t vn_split16_residual(const VnNet& net, const float* theta, const float
 hipError_t vn_split16_pgrad(const VnNet& net, const float* theta, const float* X, long n, float* out_u, float* out_g, float* out_pack,
                             int ncu, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  if (!vn_split16_supported(net, 0)) return hipErrorInvalidValue;
+  if (!vn_split16_supported(net) || net.dim > 3) return hipErrorInvalidValue;
   VnSplitPgArgsD a{};
   a.net = net; a.theta = theta; a.X = X; a.n = n; a.out_u = out_u; a.out_g = out_g; a.out_pack = out_pack;
   const int ks = vn_fused16_ks(net);

@@ -181,10 +181,12 @@ class VNEngine:
 
     def __init__(self, dim, inpDim, layerWidth, timeDependent, integNum, isSource=False,
                  integWflag=False, learning_rate=0.001, device=0, activationFun='sigmoid',
-                 optimizer_name='adam', kernel=VN_KERNEL_AUTO):
+                 optimizer_name='adam', kernel=VN_KERNEL_AUTO, xcheck=False):
         import torch
         self.torch = torch
-        if kernel == VN_KERNEL_FUSED:
+        # xcheck: an engine of the tests' cross-check library (the product objects + the 4-wave kernel + the f32-MFMA forms of the
+        # point kernels for the networks the bf16-piece kernels serve: debug_point_route(2)); never set by the product path
+        if kernel == VN_KERNEL_FUSED or xcheck:
             global _xlib
             if _xlib is None:
                 _xlib = load_library(XCHECK_LIB_PATH)
