@@ -479,10 +479,13 @@ def inference_line(vn, tdata, eng, F_pt):
         return (time.perf_counter() - t0) / reps
     tf = t(lambda: eng._ck(eng.lib.vn_forward(eng.h, _ptr(X), n, _ptr(u))))
     tr = t(lambda: eng._ck(eng.lib.vn_residual(eng.h, _ptr(X), _ptr(diff), _ptr(vel), None, None, m, _ptr(u), _ptr(r))))
-    nd = 3 * dim + 2
+    # streams of F_pt a residual point costs: vn_taylor16 runs dim + 1 passes (3 streams per spatial direction, 2 for time); the
+    # bf16-piece kernel lets the time tangent ride in pass 0 (3 dim + 1 streams, vn_split16.hip)
     # which matrix-pipe form serves these two calls (labels only; the engine decides: vn_api.hip, vn_split16_supported): hidden
     # widths 33..64 with 2..7 hidden layers (6 beyond 50 wide) run on the bf16 pipe as six products of exact bf16 pieces
     split = split16_serves(vn.layerWidth)
+    td = 1 if vn.PDE.timeDependent else 0
+    nd = (3 * dim + td) if split else (3 * dim + 2 * td)
     # the fp64 checking path (BASELINE config 5's fp64 residual check runs these entry points): vn_taylor16d on the fp64 matrix pipe.
     # Kernel time from events on the engine's stream (= torch's current stream, VNEngine.use_current_stream); priced against the
     # fp64 MFMA rate THIS box sustains (vn_debug_calibrate_f64: the guide quotes no fp64 matrix peak), FLOPs stated both ways.
@@ -506,26 +509,31 @@ def inference_line(vn, tdata, eng, F_pt):
     # matrix-pipe FLOPs vn_taylor16d issues per point and stream: every layer padded to 4*ks inputs x 16*mt outputs (no padding branches)
     Fx_pt = 2.0 * 16 * mt * (4 * (-(-vn.inpDim // 4)) + (len(W) - 1) * 4 * ks)
     on_pipe = max(W) <= 64 and len(W) <= 8
+    nd64 = 3 * dim + 2 * td                            # vn_taylor16d keeps a pass of its own for the time direction
     f64 = {"peak_measured_tflops": pk64, "calibration": cal64,
            "forward_f64": {"points": m, "kernel_ms": tf64 * 1e3, "points_per_s": m / tf64, "flop_algorithmic": F_pt * m,
                            "flop_issued_on_the_matrix_pipe": Fx_pt * m, "tflops_algorithmic": F_pt * m / tf64 / 1e12,
                            "frac_of_peak_measured": F_pt * m / tf64 / 1e12 / pk64,
                            "frac_of_peak_measured_issued": Fx_pt * m / tf64 / 1e12 / pk64},
-           "residual_f64": {"points": m, "kernel_ms": tr64 * 1e3, "points_per_s": m / tr64, "flop_algorithmic": nd * F_pt * m,
-                            "flop_issued_on_the_matrix_pipe": nd * Fx_pt * m, "tflops_algorithmic": nd * F_pt * m / tr64 / 1e12,
-                            "frac_of_peak_measured": nd * F_pt * m / tr64 / 1e12 / pk64,
-                            "frac_of_peak_measured_issued": nd * Fx_pt * m / tr64 / 1e12 / pk64},
+           "residual_f64": {"points": m, "kernel_ms": tr64 * 1e3, "points_per_s": m / tr64, "flop_algorithmic": nd64 * F_pt * m,
+                            "flop_issued_on_the_matrix_pipe": nd64 * Fx_pt * m, "tflops_algorithmic": nd64 * F_pt * m / tr64 / 1e12,
+                            "frac_of_peak_measured": nd64 * F_pt * m / tr64 / 1e12 / pk64,
+                            "frac_of_peak_measured_issued": nd64 * Fx_pt * m / tr64 / 1e12 / pk64},
            "kernel": "vn_taylor16d_kernel (v_mfma_f64_16x16x4_f64; libm exp / tanh, true division)" if on_pipe else "per-thread kernels",
            "note": "peak = what a loop of independent v_mfma_f64_16x16x4_f64 sustains on this box in this process (two waves per SIMD); "
-                   "(3 dim + 2) F_pt per residual point as in fp32; `issued` counts the padded 16-row tiles the kernel really runs"}
+                   "(3 dim + 2) F_pt per residual point (a pass of its own for the time direction); `issued` counts the padded 16-row tiles the kernel really runs"}
     return {"fp64": f64, "forward": {"points": n, "ms": tf * 1e3, "points_per_s": n / tf, "tflops_of_F_pt": F_pt * n / tf / 1e12,
                         "frac_of_peak": F_pt * n / tf / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                         "kernel": "vn_split16_kernel<NS = 1> (hidden layers as six v_mfma_f32_16x16x32_bf16 products of exact bf16 pieces; "
                                   "priced against the f32 MFMA peak for comparison with rounds 1-5)" if split else "vn_pgrad16_kernel (value-only sweep)"},
             "residual": {"points": m, "ms": tr * 1e3, "points_per_s": m / tr, "tflops_executed": nd * F_pt * m / tr / 1e12,
                          "frac_of_peak": nd * F_pt * m / tr / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "kernel": ("vn_split16_kernel<NS = 3> (bf16 pieces)" if split else "vn_taylor16_kernel") +
-                                   ": (3 dim + 2) F_pt per point, one pass of three chained streams per coordinate direction"},
+                         "streams_of_F_pt_per_point": nd,
+                         "kernel": ("vn_split16_kernel<NS = 3> (bf16 pieces; six v_mfma_f32_16x16x32_bf16 products per layer product: `frac_of_peak` "
+                                    "prices the algorithmic f32 FLOPs against the f32 MFMA peak for comparison with round 5, the kernel itself "
+                                    "runs on the bf16 pipe): (3 dim + 1) F_pt per point, dim passes of three chained streams, the time tangent a "
+                                    "fourth stream of pass 0" if split else
+                                    "vn_taylor16_kernel: (3 dim + 2) F_pt per point, one pass of three chained streams per coordinate direction")},
             "note": "vn_forward = VarNet.evaluate; vn_residual = TFModel.py:743-754, what every training monitor (VarNet.py:1363) and the "
                     "residual-driven re-sampling (VarNet.py:1696-1868) call; profiles/r5_forward_perf.txt, r5_residual_perf.txt"}
 
