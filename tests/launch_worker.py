@@ -72,8 +72,9 @@ if mode == 'step_fail':
         except VNError as e:
             print(json.dumps({"error": str(e), "rank": rank}), flush=True)
             sys.exit(3)
-    t = torch.zeros(4)
-    dist.all_reduce(t)                                # never completes: rank 1 is gone
+    # rank 0 "sits in the step's all-reduce": over RCCL a collective whose peer is gone does not return (gloo would raise on the closed
+    # socket and race the launcher's poll), so the blocked rank is modelled by a sleep -- the launcher must end it by PID
+    time.sleep(600)
     sys.exit(0)
 
 if mode == 'bootstrap':
