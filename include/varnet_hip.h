@@ -99,7 +99,7 @@ int  vn_abi_version(void);   /* 2: towers (vn_comm_*), tanh, empty feeds, vn_ker
                                 * 4: vn_comm_available, Adam hyper-parameters validated (no silent NaN from a zeroed config);
                                 * 5: vn_comm_version;
                                 * 6: vn_forward_grad, vn_debug_calibrate
-                                * 7: vn_comm_abandon, vn_debug_point_route, vn_debug_calibrate_f64 */
+                                * 7: vn_comm_abandon, vn_debug_point_route, vn_debug_calibrate_f64, vn_state_snapshot / vn_state_rollback */
 #define VN_ABI_VERSION 7     /* what this header describes: a binding must refuse a library that reports another number */
 
 /* TFNN.__init__ / graph + session construction (TFModel.py:85-191, 293-338). */
@@ -122,6 +122,14 @@ int vn_params_set(vn_engine* h, const float* host, int64_t n);
 int vn_state_size(const vn_engine* h, int64_t* bytes);
 int vn_state_export(vn_engine* h, void* host, int64_t bytes);
 int vn_state_import(vn_engine* h, const void* host, int64_t bytes);
+/* Device-side snapshot of the same state (parameters, both optimizer slots, step counter) in the engine's one snapshot slot, and
+ * the way back to it; on the engine stream, no host copy, no synchronisation (ABI 7).  VarNet.train stands its `lossLag` blocks on
+ * it: k epochs are enqueued before ONE read-back of their losses (the reference reads one loss per epoch, VarNetUtility.py:1044);
+ * when the stopping test `loss < tol` (VarNet.py:1378) fires inside a block, the state is rolled back to the block's start and the
+ * epochs up to the one that met the tolerance are replayed -- the steps are bitwise reproducible -- so the run ends in exactly the
+ * state the one-read-back-per-epoch loop ends in.  vn_state_rollback without a snapshot is VN_ESTATE. */
+int vn_state_snapshot(vn_engine* h);
+int vn_state_rollback(vn_engine* h);
 
 /* Feed of tower.N / tower.dNt / tower.integW (VarNetUtility.py:845-852) for the uniform case,
  * where those nT-row arrays are period-integ_num tables (FiniteElement.py:426-432).

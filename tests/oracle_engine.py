@@ -59,6 +59,13 @@ class OracleEngine:
         a = buf[8:].view(np.float32).astype(self.dtype)
         self.theta, self.adam.m, self.adam.v = a[:P].copy(), a[P:2 * P].copy(), a[2 * P:3 * P].copy()
 
+    def state_snapshot(self):
+        self._snap = (self.theta.copy(), self.adam.m.copy(), self.adam.v.copy(), self.adam.t)
+
+    def state_rollback(self):
+        th, m, v, t = self._snap
+        self.theta, self.adam.m, self.adam.v, self.adam.t = th.copy(), m.copy(), v.copy(), t
+
     @property
     def step(self):
         return self.adam.t

@@ -241,6 +241,32 @@ def test_fullsize_dedup_formulation(cfg3):
     assert np.array_equal(_grad(eng), g_row)
 
 
+def test_loss_lag_blocks_are_exact_on_device(tmp_path):
+    """train()'s read-back schedule on the real engine (round 6: lossLag defaults to 8 on uniform sampling): blocks of epochs behind ONE
+    loss read-back give bit for bit the losses, checkpoints, parameters and step count of the reference's one read-back per epoch --
+    also when the stopping test `loss < tol` (VarNet.py:1378) fires inside a block: vn_state_snapshot at the block's start,
+    vn_state_rollback + replay up to the epoch that met the tolerance."""
+    runs = {}
+    for lag in (0, None, 5):
+        vn = op1dt([20, 20], 10, 12)
+        res = vn.train(str(tmp_path / ('lag%s' % lag)), weight=[10., 10., 1.], epochNum=300, tol=0.9e6, saveFreq=16, verbose=False,
+                       lossLag=lag, dedup=False)
+        runs[lag] = (np.array(res.lossAll), vn.engine.get_params().copy(), vn.engine.step, list(res.iterSmp),
+                     sorted(f for f in os.listdir(str(tmp_path / ('lag%s' % lag))) if f.startswith('best_model')))
+        vn.engine.close()
+    l0, p0, n0, s0, f0 = runs[0]
+    assert 20 < len(l0) < 300 and l0[-1] < 0.9e6 and np.all(l0[:-1] >= 0.9e6)       # stopped by the tolerance, mid-run
+    assert n0 == len(l0)
+    for lag in (None, 5):
+        l, p, n, sm, f = runs[lag]
+        np.testing.assert_array_equal(l, l0)
+        np.testing.assert_array_equal(p, p0)
+        assert n == n0 and sm == s0 and f == f0
+    # the stop must have fallen INSIDE a block of at least one of the two schedules (else the test exercised no rollback)
+    k = len(l0)
+    assert (k % 16 != 0) and (((k - 1) % 16) % 8 != 7 or ((k - 1) % 16) % 5 != 4), k
+
+
 @pytest.mark.parametrize('suppFactor', [1.0, 0.5])
 def test_optimal_sampling_on_device(tmp_path, suppFactor):
     """smpScheme='optimal' end to end on the GPU: residual field from vn_residual, re-drawn set on

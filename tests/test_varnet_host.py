@@ -406,7 +406,8 @@ def test_checkpoint_uses_tf_variable_names_and_round_trips(tmp_path):
 
 def test_loss_lag_is_only_a_readback_schedule(tmp_path):
     """train(..., lossLag=k): k epochs per host read-back.  Same steps, same losses, same checkpoints and monitor epochs
-    as lossLag=0; only the stopping test sees its losses up to k-1 steps late."""
+    as lossLag=0 -- and, since round 6, the same stop: when `loss < tol` fires inside a block the engine rolls back to the
+    block's start and replays up to the epoch that met the tolerance (VarNet.py:1378: the reference stops right there)."""
     runs = []
     for lag in (0, 7):
         np.random.seed(31)                           # shuffles draw from the global NumPy stream, as in the reference
@@ -419,11 +420,19 @@ def test_loss_lag_is_only_a_readback_schedule(tmp_path):
     assert n0 == n1 == 23 * 2 and s0 == s1 == [5, 10, 15, 20] and f0 == f1
     np.testing.assert_array_equal(l1, l0)
     np.testing.assert_array_equal(p1, p0)
-    # the stopping test fires on the delayed value: at most lag-1 extra epochs
-    vn = op1dt(layerWidth=[6, 5], discNum=5, tDiscNum=6)
-    res = vn.train(str(tmp_path / 'stop'), weight=[10., 10., 1.], epochNum=60, tol=0.95e6, saveFreq=100, verbose=False, lossLag=6)
-    assert res.lossAll[-1] < 0.95e6 and all(v >= 0.95e6 for v in res.lossAll[:-1])
-    assert len(res.lossAll) <= vn.engine.step <= len(res.lossAll) + 5
+    # the stopping test: exactly the reference's stop, whatever the read-back schedule (also the default one, lossLag=None)
+    stops = []
+    for lag in (0, 6, None):
+        vn = op1dt(layerWidth=[6, 5], discNum=5, tDiscNum=6)
+        res = vn.train(str(tmp_path / ('stop%s' % lag)), weight=[10., 10., 1.], epochNum=60, tol=0.95e6, saveFreq=100, verbose=False,
+                       lossLag=lag)
+        assert res.lossAll[-1] < 0.95e6 and all(v >= 0.95e6 for v in res.lossAll[:-1])
+        assert vn.engine.step == len(res.lossAll)                 # not one step beyond the epoch that met the tolerance
+        stops.append((np.array(res.lossAll), vn.engine.get_params().copy()))
+    assert 1 < len(stops[0][0]) < 60 and (len(stops[0][0]) - 1) % 6 != 5      # the stop falls INSIDE a block of the lagged runs
+    for l, p in stops[1:]:
+        np.testing.assert_array_equal(l, stops[0][0])
+        np.testing.assert_array_equal(p, stops[0][1])
 
 
 def test_iter_plot_writes_the_reference_files(tmp_path):

@@ -143,6 +143,8 @@ struct vn_engine {
   float *dd_uv = nullptr, *dd_ug = nullptr, *dd_su = nullptr, *dd_sg = nullptr, *dd_partial = nullptr,
         *dd_losspart = nullptr;
   long dd_capU = 0, dd_cap_lp = 0;
+  float* snap = nullptr;       // vn_state_snapshot: device copy of (theta | m | v), 3 P floats
+  int64_t snap_step = -1;      // step counter at the snapshot (-1: none)
   bool point_kernels = false;  // vn_debug_point_route(1): vn_residual / vn_*_f64 on the per-thread kernels (the tests' cross-check)
   bool no_split = false;       // vn_debug_point_route(2): the f32-MFMA point kernels where the bf16-piece kernels (vn_split16.hip) would run
   int pgrad_wgs = 0;           // workgroups per CU of vn_pgrad16: 0 = what fits, at most 2 (diagnostic override: $VN_PGRAD_WGS = 1..4)
@@ -611,7 +613,7 @@ int vn_destroy(vn_engine* h) {
   (void)hipSetDevice(h->cfg.device);
   if (h->layered) { (void)hipStreamSynchronize(h->stream); vn_layered_destroy(h->layered); h->layered = nullptr; }
   if (h->comm && g_rccl.CommDestroy) { (void)hipStreamSynchronize(h->stream); (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
-  void* ptrs[] = {h->theta, h->m, h->v, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
+  void* ptrs[] = {h->theta, h->m, h->v, h->snap, h->theta64, h->gradbuf_int, h->lossbuf, h->partial, h->feN, h->fedNt,
                   h->feW, h->u, h->ud, h->ubar, h->udbar, h->ub, h->ubar_b, h->losspart, h->fused_losspart, h->stamps, h->dd_uv, h->dd_ug, h->dd_su, h->dd_sg, h->dd_partial,
                   h->dd_losspart, h->tp_losspart};
   for (void* p : ptrs)
@@ -704,6 +706,35 @@ int vn_state_export(vn_engine* h, void* host, int64_t bytes) {
   HIPCHK(hipMemcpyAsync(p + nb, h->m, nb, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(p + 2 * nb, h->v, nb, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return VN_OK;
+}
+
+// Device-side snapshot of the optimizer state (parameters, both slots, step counter) and the way back to it: no host copy, no
+// synchronisation -- everything is ordered on the engine stream.  What train()'s lossLag blocks stand on: a block of k epochs is
+// enqueued before ONE read-back of its k losses; when the stopping test fires inside the block, the state is rolled back to the
+// block's start and the epochs up to the one that met the tolerance are replayed (the steps are bitwise reproducible), so the
+// run ends in exactly the state the reference's one-read-back-per-epoch loop ends in (VarNet.py:1346-1383).
+int vn_state_snapshot(vn_engine* h) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t nb = (size_t)h->net.P * sizeof(float);
+  if (!h->snap) HIPCHK(hipMalloc((void**)&h->snap, 3 * nb));
+  HIPCHK(hipMemcpyAsync(h->snap, h->theta, nb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->snap + h->net.P, h->m, nb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->snap + 2 * (size_t)h->net.P, h->v, nb, hipMemcpyDeviceToDevice, h->stream));
+  h->snap_step = h->step;
+  return VN_OK;
+}
+
+int vn_state_rollback(vn_engine* h) {
+  if (!h) return fail(VN_EINVAL, "null handle");
+  if (!h->snap || h->snap_step < 0) return fail(VN_ESTATE, "no snapshot to roll back to (call vn_state_snapshot first)");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t nb = (size_t)h->net.P * sizeof(float);
+  HIPCHK(hipMemcpyAsync(h->theta, h->snap, nb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->m, h->snap + h->net.P, nb, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->v, h->snap + 2 * (size_t)h->net.P, nb, hipMemcpyDeviceToDevice, h->stream));
+  h->step = h->snap_step;
   return VN_OK;
 }
 

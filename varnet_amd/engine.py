@@ -85,6 +85,8 @@ _SIGS = {
     'vn_kernel_path': (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'vn_debug_stamps': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     'vn_debug_point_route': (C.c_int, [C.c_void_p, C.c_int32]),
+    'vn_state_snapshot': (C.c_int, [C.c_void_p]),
+    'vn_state_rollback': (C.c_int, [C.c_void_p]),
     'vn_debug_calibrate_f64': (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_double)]),
     'vn_profile_begin': (C.c_int, [C.c_void_p]),
     'vn_profile_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64),
@@ -305,6 +307,13 @@ class VNEngine:
     def import_state(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         self._ck(self.lib.vn_state_import(self.h, buf.ctypes.data, buf.size))
+
+    def state_snapshot(self):
+        """Device-side snapshot of (parameters, optimizer slots, step counter): no host copy, no synchronisation."""
+        self._ck(self.lib.vn_state_snapshot(self.h))
+
+    def state_rollback(self):
+        self._ck(self.lib.vn_state_rollback(self.h))
 
     @property
     def step(self):

@@ -1302,7 +1302,7 @@ class VarNet:
               addTrainPts=True, suppFactor=1.0, multiTrainUpd=False, trainUpdelay=2e4, tolUpd=0.01,
               reinitrain=True, updateWeights=False, normalizeW=False, adjustWeight=False,
               useOriginalW=False, batchNum=None, batchLen=None, shuffleData=False, shuffleFreq=1,
-              dedup='auto', lossLag=0):
+              dedup='auto', lossLag=None):
         """Training loop of /root/reference/VarNet.py:1197-1421 (uniform, random and residual-driven
         "optimal" sampling with re-initialisation and re-weighting)."""
         if self._towers is not None:                  # controller of forked towers: every tower runs the loop
@@ -1368,12 +1368,18 @@ class VarNet:
         epoch_time = 0.0
         tp_epoch, tp_updates = 1, 0
         resVal = err = lossComp = lossVec = None
-        # `lossLag` (extension, default 0 = the reference's behaviour: the loss is read back after every epoch,
-        # VarNetUtility.py:1044): with lossLag = k > 0 up to k epochs are enqueued before ONE read-back of their k losses,
-        # so small problems (an epoch of 30 us of GPU work behind a 20 us host round trip) keep the GPU busy.  Blocks end
-        # at every epoch that acts on the state (saveFreq monitors / checkpoints, shuffles), so those see exactly the
-        # state the reference would; the stopping test `loss < tol` is evaluated on the delayed values, i.e. up to k-1
-        # further steps may already have been taken when it fires.  Non-uniform sampling keeps k = 0.
+        # `lossLag` (extension): the reference reads the loss back after every epoch (VarNetUtility.py:1044); with lossLag = k > 1
+        # up to k epochs are enqueued before ONE read-back of their k losses, so small problems (an epoch of 30 us of GPU work
+        # behind a 20 us host round trip) keep the GPU busy.  It is a read-back SCHEDULE, not another algorithm: blocks end at
+        # every epoch that acts on the state (saveFreq monitors / checkpoints, shuffles), and since round 6 the stopping test
+        # `loss < tol` is exact too -- the engine snapshots its state on the device at the start of a block, and when the test
+        # fires inside the block the state is rolled back and the epochs up to the one that met the tolerance are replayed (the
+        # steps are bitwise reproducible): same losses, same checkpoints, same final parameters and step count as k = 0
+        # (tests/test_varnet_host.py::test_loss_lag_is_only_a_readback_schedule).  Default (None): 8 on uniform sampling with
+        # an engine that can snapshot, else 0; non-uniform sampling keeps 0 (its re-draw test runs every epoch).
+        can_snap = hasattr(eng, 'state_snapshot')
+        if lossLag is None:
+            lossLag = 8 if can_snap else 0
         lag = 0 if smpScheme != 'uniform' else max(0, int(lossLag))
         loss_buf = torch.zeros(max(lag, 1), dtype=torch.float32, device=eng.device)
         epoch = 1
@@ -1386,6 +1392,8 @@ class VarNet:
                     nblk = min(nblk, shuffleFreq - (epoch - 1) % shuffleFreq)
             t0 = time.perf_counter()
             loss_buf.zero_()
+            if nblk > 1 and can_snap:
+                eng.state_snapshot()                                 # device-side, on the engine's stream, no synchronisation
             for i in range(nblk):
                 for mb in range(fd.MORbatchNum):
                     tData.select_mor(mb)
@@ -1398,6 +1406,17 @@ class VarNet:
             if early_shuffle:
                 tData.shuffleTrainData()
             losses = loss_buf[:nblk].tolist()                        # one host sync per block (per epoch when lossLag = 0)
+            if nblk > 1 and can_snap:
+                hit = next((i for i in range(nblk - 1) if float(losses[i]) < tol), None)
+                if hit is not None:
+                    # the stopping test fires at epoch first + hit, inside the block: back to the block's start, then exactly the
+                    # epochs the reference would have run (their losses are the ones already read)
+                    eng.state_rollback()
+                    scratch = torch.zeros(1, dtype=torch.float32, device=eng.device)
+                    for i in range(hit + 1):
+                        for mb in range(fd.MORbatchNum):
+                            tData.select_mor(mb)
+                            self.optimIter(tData, mb, scratch[0])
             blk_time = time.perf_counter() - t0
             first = epoch
             for i in range(nblk):
