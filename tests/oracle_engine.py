@@ -81,6 +81,7 @@ class OracleEngine:
         getattr(self, 'bbic', {}).pop(batch, None)
 
     def set_bic(self, biInput, biLabel, bDof, biDimVal):
+        self._bic_key = None
         self.bic = (biInput.numpy().copy(), biLabel.numpy().copy(), int(bDof), float(biDimVal))
 
     def set_batch_bic(self, batch, biInput=None, biLabel=None):

@@ -245,6 +245,8 @@ class VNEngine:
         self._ck(self.lib.vn_param_count(self.h, C.byref(n)))
         self.P = n.value
         self._keep = {}            # python references to registered device tensors
+        self._epoch_arrays = {}    # ctypes id arrays of train_epoch, by tuple of batch ids
+        self._bic_key = None       # whose BC/IC rows are registered (ManageTrainData.select_mor's note; any set_bic clears it)
         self.gradbuf = None
         self.use_current_stream()
 
@@ -383,6 +385,7 @@ class VNEngine:
         self._keep[('dd', batch)] = (Xu, uid, rowptr, rowidx)
 
     def set_bic(self, biInput, biLabel, bDof, biDimVal):
+        self._bic_key = None
         if biInput is None or len(biInput) == 0:
             self._keep['bic'] = None
             self._ck(self.lib.vn_set_bic(self.h, None, None, 0, 0, float(biDimVal)))
@@ -428,7 +431,11 @@ class VNEngine:
     def train_epoch(self, batches, loss_acc=None):
         """len(batches) optimizer steps in one host call; each step's pre-update loss is added to the
         device scalar `loss_acc` (VarNetUtility.py:1043-1045)."""
-        arr = (C.c_int32 * len(batches))(*[int(b) for b in batches])
+        arr = self._epoch_arrays.get(batches) if isinstance(batches, tuple) else None       # (a tuple of ids: its ctypes array is kept)
+        if arr is None:
+            arr = (C.c_int32 * len(batches))(*[int(b) for b in batches])
+            if isinstance(batches, tuple) and len(self._epoch_arrays) < 4096:
+                self._epoch_arrays[batches] = arr
         self._ck(self.lib.vn_train_epoch(self.h, arr, len(batches), _ptr(loss_acc)))
 
     def eval_loss(self, batch=0, lossVec=False):

@@ -726,8 +726,17 @@ class ManageTrainData:
         self.dedup_on = False
 
     def select_mor(self, mb):
+        # (called once per epoch and MOR batch: skipped while the engine still holds THIS set's rows of batch mb -- any other
+        # set_bic, from another training set or a direct caller, clears the engine's note)
+        eng = self.vn.engine
+        key = getattr(self, '_bic_token', None)
+        if key is None:
+            key = self._bic_token = object()
+        if getattr(eng, '_bic_key', None) == (key, mb):
+            return
         d = self.mor[mb]
-        self.vn.engine.set_bic(d['biInput'], d['biLabel'], self.bDofsum, self.biDimVal)
+        eng.set_bic(d['biInput'], d['biLabel'], self.bDofsum, self.biDimVal)
+        eng._bic_key = (key, mb)
 
 
 # ======================================================================================
@@ -1256,7 +1265,12 @@ class VarNet:
         if (self.world == 1 or self.comm == 'rccl') and hasattr(eng, 'train_epoch'):
             # the whole pass in one host call (no per-mini-batch Python / launch-queue gaps); with towers the
             # engine's own RCCL communicator sums the gradient between the two kernels
-            eng.train_epoch([tData.engine_batch(mb, bi) for bi in range(tData.batchNum)], loss_acc)
+            ids = tData._epoch_ids.get(mb) if hasattr(tData, '_epoch_ids') else None
+            if ids is None:
+                if not hasattr(tData, '_epoch_ids'):
+                    tData._epoch_ids = {}
+                ids = tData._epoch_ids[mb] = tuple(tData.engine_batch(mb, bi) for bi in range(tData.batchNum))
+            eng.train_epoch(ids, loss_acc)
             return
         gb = eng.bind_grad_buffer()
         for bi in range(tData.batchNum):
@@ -1340,7 +1354,8 @@ class VarNet:
         tData = self._build_tdata(batchNum, batchLen)        # first set is always uniform (VarNet.py:1300)
         trainRes = TrainResult(folderpath if self.rank == 0 else None, fd.cEx is not None, verbose, saveFreq, pltReplace)
         trainRes.initializeCase(self, argDict)
-        self.trainRes = trainRes
+        trainRes._plot_last = time.perf_counter()            # the convergence plots are refreshed at most every `plotEvery` seconds and
+        self.trainRes = trainRes                             # flushed when train() returns: a short run draws them once (1.1 s at 300 dpi)
         # Formulation of the interior term (extension; the arithmetic is the reference's either way, VarNet.py:576-588 and
         # TFModel.py:653-664): 'auto' (default) evaluates the network once per UNIQUE quadrature point wherever that applies
         # and pays, True asks for it and warns when it cannot be had, False keeps one evaluation per (test function, point) row.
