@@ -435,6 +435,28 @@ def test_loss_lag_is_only_a_readback_schedule(tmp_path):
         np.testing.assert_array_equal(p, stops[0][1])
 
 
+def test_loss_lag_blocks_end_where_the_training_set_is_redrawn(tmp_path):
+    """Non-uniform sampling under the read-back schedule (round 6): the re-draw test of VarNet.py:1385-1421 runs after every epoch,
+    but it can first fire only at an epoch known when a block is sized (the monitors' loss samples and the epochs since the last
+    re-draw decide) -- the block ends there, so the re-drawn set, the re-initialised variables and the x 5 weights start at exactly
+    the epoch the reference's loop starts them.  saveFreq 4, trainUpdelay 7: the test fires at epoch 7, inside the block 5..8."""
+    runs = []
+    for lag in (0, None, 3):
+        np.random.seed(77)
+        vn = op1dt(layerWidth=[6, 5], discNum=5, tDiscNum=6, cEx=cExact)
+        res = vn.train(str(tmp_path / ('lag%s' % lag)), weight=[10., 10., 1.], smpScheme='optimal', adjustWeight=True, epochNum=23,
+                       saveFreq=4, trainUpdelay=7, tolUpd=1e9, verbose=False, lossLag=lag)
+        runs.append((np.array(res.lossAll), list(res.inpIter), list(res.iterSmp), vn.engine.get_params().copy(), vn.engine.step,
+                     np.asarray(res.trainWeight, dtype=float), vn.tData.mor[0]['Input'].shape[0]))
+    l0, i0, s0, p0, n0, w0, r0 = runs[0]
+    assert i0 == [7] and r0 > 5 * 6 * 16                       # re-drawn once, mid-block for both lagged schedules, points added
+    for l, i, sm, p, n, w, r in runs[1:]:
+        np.testing.assert_array_equal(l, l0)
+        np.testing.assert_array_equal(p, p0)
+        np.testing.assert_array_equal(w, w0)
+        assert i == i0 and sm == s0 and n == n0 and r == r0
+
+
 def test_iter_plot_writes_the_reference_files(tmp_path):
     """TrainResult.iterPlot (VarNetUtility.py:1634-1756): the five convergence plots under the reference's file names,
     refreshed by iterOutput every 10 * saveFreq epochs; the epoch prefix when pltReplace is False."""

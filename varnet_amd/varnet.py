@@ -1390,12 +1390,28 @@ class VarNet:
         # `loss < tol` is exact too -- the engine snapshots its state on the device at the start of a block, and when the test
         # fires inside the block the state is rolled back and the epochs up to the one that met the tolerance are replayed (the
         # steps are bitwise reproducible): same losses, same checkpoints, same final parameters and step count as k = 0
-        # (tests/test_varnet_host.py::test_loss_lag_is_only_a_readback_schedule).  Default (None): 8 on uniform sampling with
-        # an engine that can snapshot, else 0; non-uniform sampling keeps 0 (its re-draw test runs every epoch).
+        # (tests/test_varnet_host.py::test_loss_lag_is_only_a_readback_schedule).  Default (None): 8 with an engine that can
+        # snapshot, else 0.
         can_snap = hasattr(eng, 'state_snapshot')
         if lossLag is None:
             lossLag = 8 if can_snap else 0
-        lag = 0 if smpScheme != 'uniform' else max(0, int(lossLag))
+        # Non-uniform sampling: the re-draw test of VarNet.py:1385-1421 runs after every epoch, but what it looks at -- the losses
+        # sampled at the monitors, the epochs since the last re-draw -- changes only at monitor epochs (where blocks end anyway) and
+        # with the epoch count, so the first epoch at which it can fire inside a block is known when the block is sized
+        # (`redraw_at` below) and the block ends there.  A schedule without the engine's snapshot cannot make the stop exact: 0.
+        lag = max(0, int(lossLag)) if (smpScheme == 'uniform' or can_snap) else 0
+
+        def redraw_at(e0):
+            """First epoch >= e0 at which the re-draw test fires if no monitor intervenes, or None."""
+            if smpScheme == 'uniform' or not (multiTrainUpd or tp_updates == 0):
+                return None
+            t_loss = np.array(trainRes.loss[-5:])
+            if len(t_loss) == 0:
+                return None
+            conv = t_loss[:-1] - t_loss[1:]
+            if not (np.sum(conv[conv > 0]) / t_loss[-1] < tolUpd):
+                return None
+            return max(e0, int(math.ceil(tp_epoch + trainUpdelay - 1)))
         loss_buf = torch.zeros(max(lag, 1), dtype=torch.float32, device=eng.device)
         epoch = 1
         done = False
@@ -1405,6 +1421,9 @@ class VarNet:
                 nblk = min(lag, epochNum - epoch + 1, saveFreq - (epoch - 1) % saveFreq)
                 if shuffleData:
                     nblk = min(nblk, shuffleFreq - (epoch - 1) % shuffleFreq)
+                e_f = redraw_at(epoch)
+                if e_f is not None:
+                    nblk = max(1, min(nblk, e_f - epoch + 1))
             t0 = time.perf_counter()
             loss_buf.zero_()
             if nblk > 1 and can_snap:
