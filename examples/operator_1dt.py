@@ -49,7 +49,7 @@ def main():
     folder = sys.argv[1] if len(sys.argv) > 1 else 'out_operator_1dt'
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
     scheme = sys.argv[3] if len(sys.argv) > 3 else 'optimal'
-    lag = int(sys.argv[4]) if len(sys.argv) > 4 else None              # lossLag: read-back schedule (None = train()'s default: 8 on uniform sampling, exact; 0 = one read-back per epoch)
+    lag = int(sys.argv[4]) if len(sys.argv) > 4 else None              # lossLag: read-back schedule (None = train()'s default: 8, exact; 0 = one read-back per epoch)
     domain = Domain1D()
     pde = ADPDE(domain, diff=D, vel=u, timeDependent=True, tInterval=[0, T], IC=IC, cEx=cExact)
     vn = VarNet(pde, layerWidth=[20], discNum=20, bDiscNum=None, tDiscNum=300, processors='GPU:0')
