@@ -657,7 +657,10 @@ def _main():
         # `python bench.py --gpus N`: start the N ranks ourselves, as fresh children, BEFORE anything in this
         # process touches the GPU (this parent never imports torch); rank 0 prints the JSON line.
         from varnet_amd import launch
-        rc = launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        # bench.py is a short job by contract: besides the launcher's bootstrap deadline it opts into the overall wall-clock limit
+        # (a collective that wedges in the timed region must still end in ONE JSON line that says `timed`, not at the driver's limit)
+        rc = launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                overall_s=float(os.environ.get('VN_LAUNCH_OVERALL_S', '480')))
         if rc != 0:       # the failing rank has printed its own {"error": ...} line if it got as far as Python
             rep = launch.last_report or {}
             print(json.dumps({"error": "a rank of the %d-rank launch exited with status %d (its peers were ended): %s"
@@ -672,7 +675,8 @@ def _main():
     mark_stage(IMPORTS_DONE)
     # N > 1 under somebody else's launcher (torch.distributed.run): the rank ends itself with a one-line diagnosis
     # (its last stage) instead of sitting in a bootstrap until the caller's limit kills it silently
-    disarm = rank_watchdog(what='bench rank') if args.gpus > 1 else (lambda: None)
+    # (short job by contract: the rank opts into the overall limit as well -- a wedge past the bootstrap still leaves a diagnosis)
+    disarm = rank_watchdog(what='bench rank', overall_s=float(os.environ.get('VN_RANK_OVERALL_S', '420'))) if args.gpus > 1 else (lambda: None)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
