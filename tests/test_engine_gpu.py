@@ -631,7 +631,7 @@ def test_taylor_residual_parity(d_in, dim, widths, act, n, with_src, with_ddx, m
 def test_dedup_periodic_gcoef_table_is_bitwise_the_csr_path(q, dim, d_in, widths, integW, monkeypatch):
     """With constant coefficients gcoef repeats with period integNum along the rows (VarNet.py:837 tiles the tables): vn_set_dedup
     detects that bitwise and the two assembly kernels read the integNum-entry table instead of 8 bytes per row each.  Same bits
-    as the general path (VN_DEDUP_NO_TABLE=1: CSR-ordered copy of gcoef); one perturbed row switches the detection off."""
+    as the general path (vn_debug_point_route | 4: CSR-ordered copy of gcoef); one perturbed row switches the detection off."""
     from varnet_amd.engine import VNEngine
     rng = np.random.default_rng(8)
     n_k, U, nB, bDof = 70, 900, 20, 9
@@ -654,11 +654,9 @@ def test_dedup_periodic_gcoef_table_is_bitwise_the_csr_path(q, dim, d_in, widths
 
     def grad_with(g, no_table):
         eng.set_interior(0, Xu[uid], g, None, n_k=n_k, detJ=0.05)
-        if no_table:
-            monkeypatch.setenv('VN_DEDUP_NO_TABLE', '1')
+        eng.debug_point_route(4 if no_table else 0)      # | 4: keep the CSR-ordered copy of gcoef (a per-engine test argument since round 6)
         eng.set_dedup(0, Xu, uid, rowptr, rowidx)
-        if no_table:
-            monkeypatch.delenv('VN_DEDUP_NO_TABLE')
+        eng.debug_point_route(0)
         eng.grad(0)
         torch.cuda.synchronize()
         return gb.cpu().numpy().copy()

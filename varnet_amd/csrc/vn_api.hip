@@ -146,6 +146,7 @@ struct vn_engine {
   float* snap = nullptr;       // vn_state_snapshot: device copy of (theta | m | v), 3 P floats
   int64_t snap_step = -1;      // step counter at the snapshot (-1: none)
   bool point_kernels = false;  // vn_debug_point_route(1): vn_residual / vn_*_f64 on the per-thread kernels (the tests' cross-check)
+  bool no_gtable = false;      // vn_debug_point_route(route | 4): vn_set_dedup keeps the CSR-ordered copy of gcoef although it is periodic
   bool no_split = false;       // vn_debug_point_route(2): the f32-MFMA point kernels where the bf16-piece kernels (vn_split16.hip) would run
   int pgrad_wgs = 0;           // workgroups per CU of vn_pgrad16: 0 = what fits, at most 2 (diagnostic override: $VN_PGRAD_WGS = 1..4)
 
@@ -871,7 +872,7 @@ int vn_set_dedup(vn_engine* h, int32_t batch, const float* Xu, int64_t U, const 
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(err_dev);
     if (e != hipSuccess) return fail(VN_EHIP, "vn_set_dedup: %s", hipGetErrorString(e));
-    b.gper = bad == 0 && !getenv("VN_DEDUP_NO_TABLE");
+    b.gper = bad == 0 && !h->no_gtable;
   }
   if (!b.gper) {
     if (nT * dim > b.gcsr_cap) {
@@ -1312,6 +1313,8 @@ int vn_debug_calibrate_f64(vn_engine* h, double ghz, double out[3]) {
 
 int vn_debug_point_route(vn_engine* h, int32_t per_thread) {
   if (!h) return fail(VN_EINVAL, "null handle");
+  h->no_gtable = (per_thread & 4) != 0;
+  per_thread &= 3;
   if (per_thread == 2 && !kWithF32Point)
     return fail(VN_EUNSUPPORTED, "route 2 (f32-MFMA point kernels for the networks the bf16-piece kernels serve) exists in the tests' "
                                  "cross-check build only: libvarnet_hip_xcheck.so (make -C varnet_amd/csrc xcheck)");

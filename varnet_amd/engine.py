@@ -708,7 +708,8 @@ class VNEngine:
 
     def debug_point_route(self, route):
         """Test aid: residual / fp64 entry points of this engine on the per-thread kernels (True / 1), forward / residual on the
-        f32-MFMA kernels where the bf16-piece kernels would run (2), or the automatic route (False / 0)."""
+        f32-MFMA kernels where the bf16-piece kernels would run (2: cross-check library only), or the automatic route (False / 0);
+        | 4: vn_set_dedup keeps the CSR-ordered copy of gcoef although it is periodic (the general path of the assembly kernels)."""
         self._ck(self.lib.vn_debug_point_route(self.h, int(route)))
 
     def debug_stamps(self):
