@@ -562,6 +562,29 @@ def test_forward_grad_parity(d_in, dim, widths, act, n):
     eng.close()
 
 
+@pytest.mark.parametrize('widths', [[50, 50, 50], [20, 20]])
+def test_four_space_coordinates_value_runs_and_derivatives_are_refused_cleanly(widths):
+    """networks with dim > 3 (d_in <= 8: still the 8-wave family).  vn_forward needs no coordinate split and must run
+    -- on the bf16-piece kernel at hidden widths 33..64, on the f32-MFMA value sweep below -- while vn_residual / vn_forward_grad, which
+    carry at most three space coordinates, must answer VN_EUNSUPPORTED with a sentence, never a HIP launch error."""
+    from varnet_amd.engine import VNEngine, VNError
+    rng = np.random.default_rng(3)
+    dim, d_in, n = 4, 5, 777
+    eng = VNEngine(dim, d_in, widths, True, 16)
+    eng.init_params(seed=4)
+    flat = eng.get_params()
+    X = rng.uniform(-1, 1, (n, d_in)).astype(np.float32)
+    u = eng.forward(X)
+    torch.cuda.synchronize()
+    uref = og.forward(flat.astype(np.float64), d_in, widths, torch.float64, X.astype(np.float64))[:, 0]
+    assert np.max(np.abs(u.cpu().numpy() - uref)) <= 2e-6 * max(1.0, np.max(np.abs(uref)))
+    with pytest.raises(VNError, match='dim <= 3'):
+        eng.residual(X, np.ones((n, 1)), np.zeros((n, dim)), None, None, fp64=False)
+    with pytest.raises(VNError, match='dim <= 3'):
+        eng.forward_grad(X)
+    eng.close()
+
+
 @pytest.mark.parametrize('d_in,dim,widths,act,n,with_src,with_ddx', [
     (2, 1, [20, 20, 20], 'sigmoid', 1000, True, True),            # <3,5>: edge rows with 4 features; 1D+t
     (3, 2, [50, 50, 50, 50, 50], 'sigmoid', 4099, True, False),   # <5,13>: the bench network; n not a multiple of 16
