@@ -292,7 +292,8 @@ int vn_debug_calibrate_f64(vn_engine* h, double ghz, double out[3]);
  * vn_residual on the f32-MFMA kernels (vn_pgrad16 / vn_taylor16) where the bf16-piece kernels of vn_split16.hip would run
  * (A/B and cross-check of the two matrix-pipe forms; exists in the tests' cross-check library only); 0 restores the automatic choice;
  * | 4: vn_set_dedup keeps the CSR-ordered copy of gcoef although it found it periodic in integ_num (the general path of the two
- * assembly kernels, cross-checked bit for bit against the table path).  (Round 5: an environment variable
+ * assembly kernels, cross-checked bit for bit against the table path); | 8: vn_eval_loss of a batch that carries a de-duplication map
+ * runs the row-wise forward anyway (cross-check of the loss-only form of the de-duplicated assembly).  (Round 5: an environment variable
  * read on every call.) */
 int vn_debug_point_route(vn_engine* h, int32_t route);
 

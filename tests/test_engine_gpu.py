@@ -486,6 +486,21 @@ def test_dedup_formulation_parity(case):
         assert abs(g[P] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
         assert np.max(np.abs(g[:P] - gref)) <= GRAD_RTOL * np.max(np.abs(gref))
     assert np.allclose(g_dd[P + 1:P + 4], g_rows[P + 1:P + 4], rtol=1e-5)
+    # vn_eval_loss (splitLoss: every monitor, trainWeight) of a batch that carries the map: (u, grad u) once per unique point and the
+    # loss-only form of the assembly kernel (round 6) -- loss components and loss field against the fp64 oracle at the suite's bars,
+    # against the row-wise evaluation of the same batch (route | 8), and equal to what the training step itself reports
+    out_dd, lv_dd = eng.eval_loss(0, lossVec=True)
+    eng.debug_point_route(8)
+    out_rw, lv_rw = eng.eval_loss(0, lossVec=True)
+    eng.debug_point_route(0)
+    torch.cuda.synchronize()
+    lvref = np.asarray(ref['lossVec'], dtype=np.float64).reshape(-1)
+    for out, lv in ((out_dd, lv_dd), (out_rw, lv_rw)):
+        assert abs(out[0] - ref['loss']) <= LOSS_RTOL * abs(ref['loss'])
+        assert abs(out[1] - ref['BCloss']) <= LOSS_RTOL * abs(ref['BCloss']) and abs(out[2] - ref['ICloss']) <= LOSS_RTOL * abs(ref['ICloss'])
+        assert abs(out[3] - ref['varLoss']) <= LOSS_RTOL * abs(ref['varLoss'])
+        assert np.max(np.abs(lv.cpu().numpy().astype(np.float64) - lvref)) <= 1e-4 * np.max(np.abs(lvref))
+    assert np.allclose(out_dd, [g_dd[P], g_dd[P + 1], g_dd[P + 2], g_dd[P + 3]], rtol=2e-6)
     # bitwise reproducible, and switching it off restores the row-wise path
     eng.grad(0)
     torch.cuda.synchronize()

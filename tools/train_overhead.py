@@ -40,6 +40,19 @@ step = (time.perf_counter() - t1) / 200
 print('%s' % name)
 print('train(): %d epochs in %.2f s = %.3f ms/epoch; formulation: %s; bare step %.3f ms -> the steps are %.1f %% of train()'
       % (len(res.lossAll), dt, dt / len(res.lossAll) * 1e3, vn.dedup_state, step * 1e3, 100 * step * len(res.lossAll) / dt))
+if vn.dedup_state.get('on'):
+    # a monitor's loss split (splitLoss -> vn_eval_loss with the loss field) on the de-duplicated formulation and row-wise
+    def tsplit():
+        vn.splitLoss(td); torch.cuda.synchronize(); t2 = time.perf_counter()
+        for _ in range(5):
+            vn.splitLoss(td)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t2) / 5
+    a = tsplit()
+    eng.debug_point_route(8)
+    b = tsplit()
+    eng.debug_point_route(0)
+    print('splitLoss of a monitor: %.2f ms on the de-duplicated formulation, %.2f ms row-wise (vn_debug_point_route | 8)' % (a * 1e3, b * 1e3))
 st = pstats.Stats(pr)
 st.sort_stats('cumulative')
 st.print_stats(14)

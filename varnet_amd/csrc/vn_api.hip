@@ -146,6 +146,7 @@ struct vn_engine {
   float* snap = nullptr;       // vn_state_snapshot: device copy of (theta | m | v), 3 P floats
   int64_t snap_step = -1;      // step counter at the snapshot (-1: none)
   bool point_kernels = false;  // vn_debug_point_route(1): vn_residual / vn_*_f64 on the per-thread kernels (the tests' cross-check)
+  bool eval_rowwise = false;   // vn_debug_point_route(route | 8): vn_eval_loss on the row-wise forward although the batch carries a de-duplication map
   bool no_gtable = false;      // vn_debug_point_route(route | 4): vn_set_dedup keeps the CSR-ordered copy of gcoef although it is periodic
   bool no_split = false;       // vn_debug_point_route(2): the f32-MFMA point kernels where the bf16-piece kernels (vn_split16.hip) would run
   int pgrad_wgs = 0;           // workgroups per CU of vn_pgrad16: 0 = what fits, at most 2 (diagnostic override: $VN_PGRAD_WGS = 1..4)
@@ -279,9 +280,47 @@ int fused_forward(vn_engine* h, const float* X, const float* G, long n, float* o
   return VN_OK;
 }
 
+// Loss components and loss field of a batch that carries a de-duplication map (vn_set_dedup), without the row-wise forward: (u, grad u)
+// once per unique point (2 F_pt per POINT where the forward-only mode of the fused kernel costs 2 F_pt per ROW), the assembly kernel of
+// the training step in its loss-only form (R_k, lossVec, variational partials), the BC/IC rows through the forward-only mode and the
+// row-wise seed kernel with an empty interior set.  What every monitor of a run on the de-duplicated formulation calls (splitLoss,
+// VarNet.py:1365): 2.9 -> 0.45 ms on BASELINE config 3.
+int eval_dedup(vn_engine* h, const Batch& b, float* lossVec, float* lossdst) {
+  const int q = h->cfg.integ_num, dim = h->cfg.dim;
+  const int sblk = (int)((b.n_k + VN_DEDUP_TFB - 1) / VN_DEDUP_TFB);
+  const int bgrid = (int)(((h->nB > 0 ? h->nB : 1) + 255) / 256);
+  if (int rc = ensure(&h->losspart, &h->losspart_cap, (long)(sblk + bgrid) * 3)) return rc;
+  if (!h->no_split && vn_split16_supported(h->net)) HIPCHK(vn_split16_pgrad(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, h->ncu, h->stream));
+  else HIPCHK(vn_pgrad16_launch(h->net, h->theta, b.Xu, b.U, nullptr, nullptr, h->dd_uv, h->ncu, h->pgrad_wgs, h->stream));
+  VnDedupArgs a{};
+  a.upack = h->dd_uv; a.uid = b.uid; a.rowptr = b.rowptr; a.rowidx = b.rowidx;
+  a.gcoef = b.gcoef; a.gcoef_csr = b.gcsr; a.source = h->cfg.has_source ? b.source : nullptr;
+  a.feN = h->feN; a.fedNt = h->fedNt; a.feW = (h->cfg.has_integw && h->has_feW) ? h->feW : nullptr;
+  a.detJv = b.detJv; a.detJ = (float)b.detJ; a.n_k = b.n_k; a.U = b.U; a.q = q; a.dim = dim;
+  a.time_dependent = h->cfg.time_dependent; a.w2 = (float)h->w[2]; a.gper = b.gper ? 1 : 0;
+  a.stf = nullptr; a.lossVec = lossVec; a.part = h->losspart;          // loss only: no seeds
+  a.seed_u = nullptr; a.seed_g = nullptr;
+  HIPCHK(vn_dedup_seed_launch(a, sblk, h->stream));
+  if (int rc = fused_forward(h, bi_x(h, b), nullptr, h->nB, h->ub, nullptr)) return rc;
+  VnSeedArgs s{};
+  s.u = h->u; s.ud = h->ud; s.source = nullptr; s.feN = h->feN; s.fedNt = h->fedNt; s.feW = nullptr;
+  s.Nrow = nullptr; s.dNtrow = nullptr; s.detJv = nullptr; s.detJ = (float)b.detJ;
+  s.n_k = 0; s.integ_num = q; s.time_dependent = h->cfg.time_dependent;      // interior set empty: the BC/IC terms alone
+  s.ubar = nullptr; s.udbar = nullptr; s.lossVec = nullptr;
+  s.ub = h->ub; s.label = bi_y(h, b); s.nB = h->nB; s.bDof = h->bDof; s.biDimVal = (float)h->biDimVal; s.ubar_b = nullptr;
+  s.w0 = (float)h->w[0]; s.w1 = (float)h->w[1]; s.w2 = (float)h->w[2];
+  s.part = h->losspart + (long)sblk * 3;
+  HIPCHK(vn_seed_launch(s, bgrid, h->stream));
+  if (lossdst)
+    HIPCHK(vn_reduce_launch(nullptr, 0, 0, h->losspart, sblk + bgrid, h->bDof, h->nB, s.w0, s.w1, s.w2, lossdst, h->stream));
+  return VN_OK;
+}
+
 // forward + weak-form epilogue; with_seeds = also produce backward seeds.
 int run_forward_and_seed(vn_engine* h, const Batch& b, bool with_seeds, float* lossVec, float* lossdst) {
   const long nT = b.n_k * h->cfg.integ_num;
+  if (!with_seeds && b.Xu && !h->layered && (h->use_fused16 || h->two_pass) && h->has_fe && !h->eval_rowwise)
+    return eval_dedup(h, b, lossVec, lossdst);
   if (h->layered) {
     VnRows s0{}, s1{};
     s0.X = b.Input; s0.G = b.gcoef; s0.u = h->u; s0.ud = h->ud; s0.n = nT;
@@ -1314,6 +1353,7 @@ int vn_debug_calibrate_f64(vn_engine* h, double ghz, double out[3]) {
 int vn_debug_point_route(vn_engine* h, int32_t per_thread) {
   if (!h) return fail(VN_EINVAL, "null handle");
   h->no_gtable = (per_thread & 4) != 0;
+  h->eval_rowwise = (per_thread & 8) != 0;
   per_thread &= 3;
   if (per_thread == 2 && !kWithF32Point)
     return fail(VN_EUNSUPPORTED, "route 2 (f32-MFMA point kernels for the networks the bf16-piece kernels serve) exists in the tests' "
