@@ -241,6 +241,20 @@ def test_fullsize_dedup_formulation(cfg3):
     assert np.array_equal(_grad(eng), g_row)
 
 
+def test_unique_points_on_the_device_equal_the_host_maps(cfg3):
+    """unique_points with a CUDA device (torch.unique + stable argsort, round 6) returns bit for bit the maps of the NumPy path -- unique
+    keys ascending, first occurrences, rows of a point in increasing order -- on a 1.28 M-row block of config 3."""
+    from varnet_amd.varnet import unique_points
+    vn, td = cfg3
+    fd = vn.fixData
+    blk = td.mor[0]['Input_host'][:20000 * fd.integNum]
+    a = unique_points(blk, fd.feDim, fd.hVec)
+    b = unique_points(blk, fd.feDim, fd.hVec, vn.engine.device)
+    assert len(a[0]) < blk.shape[0] / 4
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x, y)
+
+
 def test_loss_lag_blocks_are_exact_on_device(tmp_path):
     """train()'s read-back schedule on the real engine (round 6: lossLag defaults to 8 on uniform sampling): blocks of epochs behind ONE
     loss read-back give bit for bit the losses, checkpoints, parameters and step count of the reference's one read-back per epoch --

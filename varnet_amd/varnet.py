@@ -41,16 +41,38 @@ size = np.size
 DEDUP_MODEL = {'row_ps': 4.5, 'point_ps': 6.2, 'asm_ps': 10.0, 'fixed_us': 20.0, 'param_ns': 2.2}
 
 
-def unique_points(Input, feDim, hVec):
+def unique_points(Input, feDim, hVec, device=None):
     """
     Unique quadrature points of an `Input` block (rows = test function x quadrature point).
     On the uniform grid the 2^feDim hat functions around an element share its quadrature points
     (VarNet.py:576-588), so rows repeat; coordinates reached from different nodes differ only by
     fp64 rounding and are merged on a lattice of h/4096.  Returns (first-occurrence row of every
     unique point, uid [n] row -> unique point, rowptr [U+1], rowidx [n] CSR inverse).
+    With a CUDA `device` the sorts run there (torch.unique / stable argsort: the same maps, bit for bit, as the NumPy path --
+    unique keys ascending, first occurrences, rows of a point in increasing order; 1.4 s -> 0.1 s at 15.4 M rows).
     """
     X = np.asarray(Input)[:, :feDim]
     h = np.reshape(np.asarray(hVec, dtype=float), (1, feDim))
+    if device is not None and getattr(device, 'type', None) == 'cuda':
+        import torch
+        Xd = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float64), device=device)
+        k = torch.round((Xd - Xd.min(dim=0, keepdim=True).values) / torch.as_tensor(h, device=device) * 4096.0).to(torch.int64)
+        kmax = k.max(dim=0).values.tolist()
+        bits = [int(np.ceil(np.log2(max(int(m), 1) + 1))) for m in kmax]
+        if sum(bits) <= 62:
+            key = torch.zeros(k.shape[0], dtype=torch.int64, device=device)
+            for d in range(feDim):
+                key = (key << bits[d]) | k[:, d]
+            _, uid = torch.unique(key, sorted=True, return_inverse=True)
+            U = int(uid.max().item()) + 1
+            n = uid.shape[0]
+            first = torch.full((U,), n, dtype=torch.int64, device=device).scatter_reduce_(
+                0, uid, torch.arange(n, dtype=torch.int64, device=device), reduce='amin', include_self=True)
+            rowidx = torch.argsort(uid, stable=True)
+            rowptr = torch.zeros(U + 1, dtype=torch.int64, device=device)
+            rowptr[1:] = torch.cumsum(torch.bincount(uid, minlength=U), 0)
+            return (first.cpu().numpy(), uid.to(torch.int32).cpu().numpy(), rowptr.to(torch.int32).cpu().numpy(),
+                    rowidx.to(torch.int32).cpu().numpy())
     k = np.rint((X - X.min(axis=0, keepdims=True)) / h * 4096.0).astype(np.int64)
     bits = [int(np.ceil(np.log2(max(int(k[:, d].max()), 1) + 1))) for d in range(feDim)]
     if sum(bits) <= 62:
@@ -704,7 +726,7 @@ class ManageTrainData:
                 key = (mb, bi)
                 if key not in cache:
                     blk = d['Input_host'][n0 * q:n1 * q]
-                    first, uid, rowptr, rowidx = unique_points(blk, fd.feDim, fd.hVec)
+                    first, uid, rowptr, rowidx = unique_points(blk, fd.feDim, fd.hVec, getattr(vn.engine, 'device', None))
                     cache[key] = (vn.engine.dev(blk[first]), uid, rowptr, rowidx)
                 Xu, uid, rowptr, rowidx = cache[key]
                 # not applicable was decided above; an engine error here is a real failure and propagates
