@@ -37,7 +37,8 @@ IMPORTS_DONE = 'imports_done'          # the stage that starts the deadline cloc
 # and including the communicator agreement, where a rank can sit in a call that has no timeout of its own -- and measures
 # the time since THAT breadcrumb.  A rank past the bootstrap (comm_done, data, warmup, timed, ... or any stage a user script
 # marks) is healthy however long it runs; a rank that writes no breadcrumbs at all is covered by the import grace + deadline
-# counted from the start.  An overall wall-clock limit is opt-in ($VN_LAUNCH_OVERALL_S / $VN_RANK_OVERALL_S).
+# counted from the start (a script that marks no stage and prepares for longer than that sets $VN_LAUNCH_DEADLINE_S=0: no bootstrap
+# deadline).  An overall wall-clock limit is opt-in ($VN_LAUNCH_OVERALL_S / $VN_RANK_OVERALL_S).
 BOOTSTRAP_STAGES = ('start', IMPORTS_DONE, 'pg_init', 'build_problem', 'probe', 'id_bcast', 'comm_init', 'comm_agree')
 
 
@@ -99,12 +100,12 @@ def rank_watchdog(deadline_s=None, what='rank', overall_s=None):
 
     def run():
         while True:
-            if done.wait(min(1.0, max(0.05, deadline_s / 4))):
+            if done.wait(min(1.0, max(0.05, abs(deadline_s) / 4))):
                 return
             now = time.time()
             in_bootstrap = mark_stage.last is None or mark_stage.last in BOOTSTRAP_STAGES
             stale = now - max(mark_stage.t_last, t_arm)
-            if in_bootstrap and stale >= deadline_s:
+            if deadline_s > 0 and in_bootstrap and stale >= deadline_s:
                 why = "%s deadline of %.0f s expired in bootstrap stage %s" % (what, deadline_s, mark_stage.last)
             elif overall_s and now - t_arm >= overall_s:
                 why = "%s overall limit of %.0f s expired" % (what, overall_s)
@@ -207,7 +208,7 @@ def spawn_ranks(argv, nproc, env_extra=None, poll_s=0.2, deadline_s=None, import
                     st = read_stages(stage_files[r])
                     if st and st[-1][1] not in BOOTSTRAP_STAGES:
                         continue
-                    if now - max(st[-1][0] if st else t_clock, t_clock) >= deadline_s:
+                    if deadline_s > 0 and now - max(st[-1][0] if st else t_clock, t_clock) >= deadline_s:     # (<= 0: no bootstrap deadline)
                         wedged.append(r)
                 if wedged:
                     status, ended_by = 124, 'launch deadline of %.0f s expired (rank%s %s in one bootstrap stage that long)' % (
